@@ -1,0 +1,152 @@
+/* vc2.h -- C ABI of the MI355X-native VidCom2 token-compression hot path (libvc2hip.so).
+ *
+ * The reference (xuyang-liu16/VidCom2) has no FFI: its boundary is the Python module
+ * token_compressor/vidcom2/vidcom2.py.  Each entry point below names the reference function
+ * (file:line) whose tensor work it replaces; vidcom2_amd/vidcom2.py binds them with ctypes
+ * and re-exposes the reference's Python names and signatures.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; no torch / C++ types cross this boundary
+ *   - every pointer is a DEVICE pointer unless the name says host; `stream` is a hipStream_t
+ *     passed as void* (NULL = the legacy default stream)
+ *   - functions only ENQUEUE work on `stream`; none of them synchronises, allocates or frees
+ *     device memory (the caller passes a workspace sized by vc2_workspace_bytes)
+ *   - return 0 on success, a negative VC2_ERR_* otherwise (nothing was enqueued on error);
+ *     vc2_last_error() gives a thread-local message
+ *   - dtype codes: 0 = fp32, 1 = bf16, 2 = fp16.  All arithmetic follows the reference's
+ *     "every op in the input dtype" behaviour: each torch op is evaluated exactly and rounded
+ *     fp32 -> T (DESIGN.md "Numerics contract"); index outputs are int64 like torch's
+ *   - row-major contiguous tensors; 16-byte aligned base pointers
+ */
+#ifndef VC2_H_
+#define VC2_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC2_F32 0
+#define VC2_BF16 1
+#define VC2_F16 2
+
+#define VC2_OK 0
+#define VC2_ERR_ARG (-1)          /* bad argument (null pointer, non-positive size, bad dtype) */
+#define VC2_ERR_SHAPE (-2)        /* rows not divisible by tokens-per-frame (torch .view RuntimeError) */
+#define VC2_ERR_UNSUPPORTED (-3)  /* shape outside what the kernels cover (see vc2_limits) */
+#define VC2_ERR_LAUNCH (-4)       /* hipLaunch failure; message in vc2_last_error() */
+#define VC2_ERR_WORKSPACE (-5)    /* workspace too small */
+
+#define VC2_MAP_LINEAR 0          /* vidcom2.py:99-103  _map_linear_offset */
+#define VC2_MAP_GRID_VID 1        /* vidcom2.py:105-115 _map_grid_vid      */
+#define VC2_MAP_LOCAL 2           /* per-frame local indices (select_outlier_indices output) */
+
+const char* vc2_last_error(void);
+const char* vc2_version(void);
+
+/* Workspace (bytes) needed by any entry point below for an [F*N, D] input. */
+int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes);
+
+/* Upper bound on the number of kept tokens sum(ks) for a given base_scale: lets the caller
+ * allocate the output of vc2_compress before the budgets are known (the reference learns K
+ * from a host sync, vidcom2.py:72). */
+int64_t vc2_kept_capacity(int64_t F, int64_t N, double base_scale);
+
+/* ---- stage entry points ------------------------------------------------------------ */
+
+/* vidcom2.py:40  x.var(dim=0, unbiased=False) -> var T[D] (also fp32-widened copy var_f32[D],
+ * may be NULL).  Sweep 1 of X. */
+int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes,
+                 void* var_T, float* var_f32, void* stream);
+
+/* vidcom2.py:41-42  torch.topk(var, k, largest=False): the SET of the k selected channels as a
+ * byte mask mask[D] (1 = selected), with ties at the k-th value broken exactly like the CPU
+ * reference (libstdc++ introselect).  var_f32 = widened T values. */
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, void* ws, size_t ws_bytes,
+                    uint8_t* mask, void* stream);
+
+/* vidcom2.py:43  x[:, idx] column gather -> out T[R, C]; idx int64[C] on device. */
+int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C,
+                    void* out, void* stream);
+
+/* vidcom2.py:45-62  compute_gaussian_scores over the channels with mask[c] != 0 (mask NULL =
+ * all channels, i.e. x already holds the selected features).  Sweeps 2 and 3 of X.
+ * Outputs: v_T, f_T  T[F,N] (may be NULL), total_f32 fp32-widened RN_T(v+f) [F,N] (vidcom2.py:33),
+ * s_f32[F] = -mean(v, -1) widened (vidcom2.py:32). */
+int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
+               void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32,
+               void* stream);
+
+/* vidcom2.py:64-68  compute_scales(scores, base, temp) on T[F] -> scales T[F]. */
+int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws,
+                       size_t ws_bytes, void* scales_T, void* stream);
+
+/* vidcom2.py:72-77  ks = (scales*tpf).round().long().clamp(min=1); per frame the k_f smallest
+ * total scores (CPU-reference tie-breaking), ascending.  map_mode selects the index mapping
+ * fused into the output (VC2_MAP_*; grid_h only for GRID_VID).  Outputs: ks int64[F],
+ * offs int64[F+1] (exclusive prefix of ks), idx_out int64[cap] and K_out[0] = number of indices
+ * written (K_out[1] = 1 if it would have exceeded `cap`; then nothing past cap is written). */
+int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int dtype,
+               int map_mode, int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs,
+               int64_t* idx_out, int64_t cap, int64_t* K_out, void* stream);
+
+/* vidcom2.py:99-103 / :105-115 as standalone mappers: local per-frame indices (concatenated,
+ * with ks/offs) -> global indices. */
+int vc2_map_indices(const int64_t* local_idx, const int64_t* ks, const int64_t* offs, int64_t F,
+                    int map_mode, int64_t stride_or_h, int64_t* out, void* stream);
+
+/* vidcom2.py:91 / :96  flat[global_idx]: dst[j,:] = src[idx[j],:] for j < K_dev[0] (K read on
+ * device; at most `cap` rows). */
+int vc2_gather_rows(const void* src, int64_t src_rows, int64_t D, int dtype, const int64_t* idx,
+                    const int64_t* K_dev, int64_t cap, void* dst, void* stream);
+
+/* ---- one-shot hot path -------------------------------------------------------------- */
+
+/* vidcom2.py:15-36  vidcom2_compression for the "linear" mapper (llava_ov / qwen*), and for
+ * "grid_vid" when gather_src/map_mode say so: everything from the feature tensor resident in HBM
+ * to kept rows + indices + budgets, enqueued back-to-back with no host round trip.
+ *   x           T[F*N, D]
+ *   gather_src  rows to gather from (x itself for linear; img_feat for grid_vid), gather_rows rows
+ *   out_rows    T[cap, D]; idx_out int64[cap]; ks int64[F]; K_out int64[2] (see vc2_select)
+ *   v_T/f_T     optional T[F,N] score outputs (NULL to skip)
+ */
+int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale,
+                 int map_mode, int64_t grid_h, const void* gather_src, int64_t gather_rows,
+                 void* ws, size_t ws_bytes, void* out_rows, int64_t* idx_out, int64_t cap,
+                 int64_t* ks, int64_t* K_out, void* v_T, void* f_T, void* stream);
+
+/* ---- frame-sharded multi-GPU building blocks -------------------------
+ * A rank holds frames [f0, f0+F_local) of a video with F_total frames.  Between the local
+ * sweeps the Python layer all-gathers three small fp64/fp32 vectors over RCCL:
+ *   1. per-rank column sums   stats[2][D]  (sum x, sum x^2)            -> vc2_chan_var_from_stats
+ *   2. per-rank centre sums   csum[D]      (sum of normalised tokens)  -> vc2_scores_phase2
+ *   3. per-frame uniqueness   s[F_local]                               -> vc2_select on F_total */
+int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes,
+                   double* stats /*[2][D]*/, void* stream);
+int vc2_chan_var_from_stats(const double* stats /*[P][2][D]*/, int64_t P, int64_t R_total, int64_t D,
+                            int dtype, void* var_T, float* var_f32, void* stream);
+int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
+                      void* ws, size_t ws_bytes, double* csum /*[D]*/, void* stream);
+int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
+                      const double* csum_all /*[P][D]*/, int64_t P, int64_t R_total, void* ws,
+                      size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32,
+                      void* stream);
+
+/* ---- small device utilities used by tests / bench ----------------------------------- */
+/* exp over every T bit pattern as the path computes it: out[i] = RN_T(exp(in[i])) (KAT). */
+int vc2_kat_exp(const void* in_T, int64_t n, int dtype, void* out_T, void* stream);
+/* RN_T round trip of fp32 values (KAT for the conversion instructions). */
+int vc2_kat_round(const float* in, int64_t n, int dtype, void* out_T, void* stream);
+
+/* ---- host helper -------------------------------------------------------------------- */
+/* torch.topk(v, k, largest=False, sorted=sorted) ORDER on host memory (ATen TopKImpl.h:
+ * libstdc++ partial_sort / nth_element + sort).  Used only by the standalone
+ * select_low_var_channels API, whose return value exposes the reference's column order. */
+int vc2_host_topk_order(const float* v_host, int64_t n, int64_t k, int sorted, int64_t* idx_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VC2_H_ */

@@ -1,0 +1,114 @@
+"""ctypes binding of libvc2hip.so (the C ABI declared in include/vc2.h).
+
+The library holds every hand-written gfx950 kernel of the hot path.  There is NO fallback:
+if the shared object is missing or a tensor is not on a ROCm device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "_lib", "libvc2hip.so")
+
+DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+MAP_LINEAR, MAP_GRID_VID, MAP_LOCAL = 0, 1, 2
+
+_ERR_SHAPE, _ERR_UNSUPPORTED = -2, -3
+
+_lib: Optional[ctypes.CDLL] = None
+
+_vp, _i64, _i32, _dbl, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+
+# name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/vc2.h one to one
+_SIGNATURES = {
+    "vc2_workspace_bytes": [_i64, _i64, _i64, _i32, ctypes.POINTER(_sz)],
+    "vc2_kept_capacity": [_i64, _i64, _dbl],
+    "vc2_chan_var": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp, _vp],
+    "vc2_chan_select": [_vp, _i64, _i64, _vp, _sz, _vp, _vp],
+    "vc2_gather_cols": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
+    "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "vc2_compute_scales": [_vp, _i64, _dbl, _dbl, _i32, _vp, _sz, _vp, _vp],
+    "vc2_select": [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _sz, _vp, _vp, _vp, _i64, _vp, _vp],
+    "vc2_map_indices": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
+    "vc2_gather_rows": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
+    "vc2_compress": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
+                     _vp, _vp, _vp, _vp],
+    "vc2_chan_stats": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp],
+    "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
+    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _sz, _vp, _vp],
+    "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
+    "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
+    "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],
+    "vc2_last_error": [],
+    "vc2_version": [],
+}
+_RESTYPES = {"vc2_kept_capacity": _i64, "vc2_last_error": ctypes.c_char_p, "vc2_version": ctypes.c_char_p}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    """Load libvc2hip.so (built by __graft_entry__.build()); fail loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"vidcom2_amd: HIP extension {LIB_PATH} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU or PyTorch fallback for this path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().vc2_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == _ERR_SHAPE:
+        raise RuntimeError(f"{what}: {msg}")
+    if rc == _ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what} must be a torch.Tensor, got {type(t).__name__}")
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            f"vidcom2_amd: {what} lives on {t.device}; this package only runs its HIP kernels on a ROCm "
+            "device (torch device type 'cuda'). There is no CPU fallback -- move the tensor to the GPU.")
+    if t.dtype not in DTYPE_CODE and t.dtype != torch.int64 and t.dtype != torch.uint8 and t.dtype != torch.float64:
+        raise TypeError(f"{what}: unsupported dtype {t.dtype} (fp32 / bf16 / fp16 only)")
+
+
+def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace_bytes(F: int, N: int, D: int, dtype) -> int:
+    out = _sz(0)
+    check(lib().vc2_workspace_bytes(F, N, D, DTYPE_CODE[dtype], ctypes.byref(out)), "vc2_workspace_bytes")
+    return int(out.value)
+
+
+def workspace(F: int, N: int, D: int, dtype, device) -> torch.Tensor:
+    return torch.empty(workspace_bytes(F, N, D, dtype), dtype=torch.uint8, device=device)

@@ -1,0 +1,1073 @@
+// vc2_kernels.hip -- MI355X (gfx950) kernels + C ABI of the VidCom2 token-compression hot path.
+//
+// Replaces the tensor work of token_compressor/vidcom2/vidcom2.py:15-115 (reference).  The pass
+// is three dependent streaming sweeps over X[F*N, D] plus O(F*N) scalar work:
+//
+//   sweep 1  k_chan_stats      per-channel sum / sum-of-squares (fp64)        vidcom2.py:40
+//            k_stats_reduce    fixed-order partial reduce -> var (T)
+//            k_chan_select     lowest-variance half, CPU-reference ties       vidcom2.py:41-42
+//   sweep 2  k_norm_colsum     token L2 norms, x^ = x/||x||, per-frame sums   vidcom2.py:47-52
+//            k_centres         frame / video centres (T)
+//   sweep 3  k_dist            squared distances to both centres              vidcom2.py:61
+//            k_token_epilogue  5-scale Gaussian sums, v+f, per-frame mean     vidcom2.py:62,32-33
+//            k_budget          softmax budgets, ks, offsets                   vidcom2.py:64-68,72
+//            k_select          per-frame bottom-k (libstdc++ ties) + mapping  vidcom2.py:74-77,99-115
+//            k_gather_rows     kept rows                                      vidcom2.py:91,96
+//
+// HBM-bound: no dense contraction exists in the reference, so no MFMA.  All global
+// loads are 16 B/lane coalesced along D; reductions are fixed-order (no float atomics) so results
+// are run-to-run deterministic.  Built with -ffp-contract=off (see vc2_device.h).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "vc2_device.h"
+#include "vc2_select.h"
+
+using namespace vc2;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ======================================================================================
+// sweep 1: per-channel statistics
+// ======================================================================================
+// grid = (column slabs of 64 lanes x VEC, row groups); block = 4 waves sharing one slab, wave w
+// takes rows r0+w, r0+w+4, ...  Each lane accumulates sum(x-K) and sum((x-K)^2) in fp64 for its
+// VEC columns, K = x[0][c] (a shift: constant columns give exactly 0 and the final subtraction
+// is well conditioned).  The 4 waves combine through LDS; one partial per (row group, column).
+constexpr int kStatsWaves = 4;
+
+template <int DT, int VEC, int U>
+__global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __restrict__ x, int64_t R,
+                                                                 int D, int CV, int rows_per_group,
+                                                                 double* __restrict__ part) {
+  __shared__ double sm[kStatsWaves][2 * VEC][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cv = blockIdx.x * 64 + lane;
+  const bool active = cv < CV;
+  const int64_t r0 = int64_t(blockIdx.y) * rows_per_group;
+  const int64_t r1 = min(R, r0 + rows_per_group);
+  double s[VEC], q[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s[j] = 0.0; q[j] = 0.0; }
+  if (active) {
+    float kf[VEC];
+    unpack<DT, VEC>(load_raw<DT, VEC>(x, int64_t(cv) * VEC), kf);
+    double K[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) K[j] = double(kf[j]);
+    for (int64_t r = r0 + wave; r < r1; r += int64_t(kStatsWaves) * U) {
+      RawVec<DT, VEC> raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t rr = r + int64_t(u) * kStatsWaves;
+        raw[u] = rr < r1 ? load_raw<DT, VEC>(x, rr * D + int64_t(cv) * VEC) : zero_raw<DT, VEC>();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t rr = r + int64_t(u) * kStatsWaves;
+        if (rr < r1) {
+          float v[VEC];
+          unpack<DT, VEC>(raw[u], v);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const double d = double(v[j]) - K[j];
+            s[j] += d;
+            q[j] = fma(d, d, q[j]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sm[wave][j][lane] = s[j]; sm[wave][VEC + j][lane] = q[j]; }
+  __syncthreads();
+  if (wave == 0 && active) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < kStatsWaves; ++w) { a += sm[w][j][lane]; b += sm[w][VEC + j][lane]; }
+      const int64_t c = int64_t(cv) * VEC + j;
+      part[(int64_t(blockIdx.y) * 2 + 0) * D + c] = a;
+      part[(int64_t(blockIdx.y) * 2 + 1) * D + c] = b;
+    }
+  }
+}
+
+// Fixed-order reduce of the G row-group partials -> per-rank (mean, M2) in fp64, and (when
+// var_f32 != nullptr, single-rank case) the variance rounded fp64 -> fp32 -> T.
+template <int DT>
+__global__ void k_stats_reduce(const double* __restrict__ part, int G, const void* __restrict__ x,
+                               int64_t R, int D, double* __restrict__ stats, void* __restrict__ var_T,
+                               float* __restrict__ var_f32) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  double s = 0.0, q = 0.0;
+  for (int g = 0; g < G; ++g) {
+    s += part[(int64_t(g) * 2 + 0) * D + c];
+    q += part[(int64_t(g) * 2 + 1) * D + c];
+  }
+  const double K = double(ldT<DT>(x, c));
+  const double n = double(R);
+  const double mean = K + s / n;
+  double m2 = q - s * s / n;
+  if (m2 < 0.0) m2 = 0.0;
+  if (stats) { stats[c] = mean; stats[D + c] = m2; }
+  if (var_f32) {
+    const float v = rnT<DT>(float(m2 / n));
+    var_f32[c] = v;
+    if (var_T) stT<DT>(var_T, c, v);
+  }
+}
+
+// Multi-rank combine (Chan et al.): stats[P][2][D] = per-rank (mean, M2), equal-size ranks are not
+// assumed: counts[p] rows each.  var = M2_total / R_total, rounded fp64 -> fp32 -> T.
+template <int DT>
+__global__ void k_var_from_stats(const double* __restrict__ stats, const int64_t* __restrict__ counts,
+                                 int P, int64_t n_each, int D, void* __restrict__ var_T,
+                                 float* __restrict__ var_f32) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  double ntot = 0.0, msum = 0.0;
+  for (int p = 0; p < P; ++p) {
+    const double n = counts ? double(counts[p]) : double(n_each);
+    ntot += n;
+    msum += n * stats[(int64_t(p) * 2 + 0) * D + c];
+  }
+  const double mean = msum / ntot;
+  double m2 = 0.0;
+  for (int p = 0; p < P; ++p) {
+    const double n = counts ? double(counts[p]) : double(n_each);
+    const double d = stats[(int64_t(p) * 2 + 0) * D + c] - mean;
+    m2 += stats[(int64_t(p) * 2 + 1) * D + c] + n * d * d;
+  }
+  const float v = rnT<DT>(float(m2 / ntot));
+  if (var_f32) var_f32[c] = v;
+  if (var_T) stT<DT>(var_T, c, v);
+}
+
+// ======================================================================================
+// channel selection (single workgroup; D <= 8192)
+// ======================================================================================
+constexpr int kSelNT = 1024;
+
+__global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
+                                                        uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SelShared S = sel_carve(smem, D);
+  for (int i = threadIdx.x; i < D; i += kSelNT) {
+    S.key[i] = topk_key(var_f32[i]);
+    S.idx[i] = uint16_t(i);
+    mask[i] = (k >= D) ? 1 : 0;
+  }
+  __syncthreads();
+  topk_smallest_block<kSelNT>(S, D, k);
+  __syncthreads();
+  if (k < D)
+    for (int i = threadIdx.x; i < k; i += kSelNT) mask[S.idx[i]] = 1;
+}
+
+template <int DT>
+__global__ void k_gather_cols(const void* __restrict__ x, int64_t R, int D, const int64_t* __restrict__ idx,
+                              int C, void* __restrict__ out) {
+  const int64_t r = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  const int64_t c = idx[j];
+  if constexpr (Tr<DT>::ES == 4) {
+    static_cast<float*>(out)[r * C + j] = static_cast<const float*>(x)[r * D + c];
+  } else {
+    static_cast<uint16_t*>(out)[r * C + j] = static_cast<const uint16_t*>(x)[r * D + c];
+  }
+}
+
+// ======================================================================================
+// sweeps 2 and 3: row-wide workgroups, one column vector (VEC channels) per thread
+// ======================================================================================
+// A workgroup owns a contiguous run of token rows of ONE frame (split s of frame f); thread t owns
+// channels [t*VEC, t*VEC+VEC).  Rows are processed RB at a time: RB independent 16-byte loads per
+// lane in flight, then per-row reductions: wave shuffle -> LDS -> fixed-order sum.
+constexpr int kRB = 8;        // rows per batch
+constexpr int kMaxWaves = 16; // 1024 threads
+
+// sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and
+// the per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels.
+template <int DT, int VEC>
+__global__ __launch_bounds__(1024) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
+                                                      int S, int rows_per_split,
+                                                      const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ den_out,
+                                                      double* __restrict__ part) {
+  __shared__ double red[2][kRB][kMaxWaves];
+  __shared__ float dens[2][kRB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int f = blockIdx.x / S, sp = blockIdx.x % S;
+  const int n0 = sp * rows_per_split;
+  const int n1 = min(N, n0 + rows_per_split);
+  const bool active = tid < CV;
+  const int64_t col0 = int64_t(tid) * VEC;
+  bool m[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) m[j] = active && (mask == nullptr || mask[col0 + j] != 0);
+  double cs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) cs[j] = 0.0;
+
+  int buf = 0;
+  for (int nb = n0; nb < n1; nb += kRB, buf ^= 1) {
+    RawVec<DT, VEC> raw[kRB];
+#pragma unroll
+    for (int r = 0; r < kRB; ++r) {
+      const int n = nb + r;
+      raw[r] = (active && n < n1) ? load_raw<DT, VEC>(x, (int64_t(f) * N + n) * D + col0)
+                                  : zero_raw<DT, VEC>();
+    }
+    float v[kRB][VEC];
+#pragma unroll
+    for (int r = 0; r < kRB; ++r) {
+      unpack<DT, VEC>(raw[r], v[r]);
+      double p = 0.0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (m[j]) p = fma(double(v[r][j]), double(v[r][j]), p);
+      p = wave_sum(p);
+      if (lane == 0) red[buf][r][wave] = p;
+    }
+    __syncthreads();
+    if (tid < kRB) {
+      double n2 = 0.0;
+      for (int w = 0; w < nwaves; ++w) n2 += red[buf][tid][w];
+      const float norm = rnT<DT>(float(sqrt(n2)));
+      // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
+      float dn = rnT<DT>(fmaxf(norm, 1e-12f));
+      if (norm != norm) dn = norm;
+      dens[buf][tid] = dn;
+      if (nb + tid < n1) den_out[int64_t(f) * N + nb + tid] = dn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kRB; ++r) {
+      if (nb + r < n1) {
+        const float dn = dens[buf][r];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          if (m[j]) cs[j] += double(rnT<DT>(v[r][j] / dn));
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part[int64_t(blockIdx.x) * D + col0 + j] = cs[j];
+  }
+}
+
+// centres: frame_center[f][c] = mean_T(sum_n x^), csum[c] = sum_f (frame sums) in fp64 (fixed order:
+// frame lanes then lane order), and -- single rank -- vid_center[c] = mean_T(csum, F*N).
+// grid = ceil(D/64) workgroups of 64 columns x FL frame lanes.
+constexpr int kCentreFL = 16;
+
+template <int DT>
+__global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __restrict__ part, int F, int S,
+                                                             int N, int D, float* __restrict__ fc,
+                                                             double* __restrict__ csum,
+                                                             float* __restrict__ vc, int64_t R_total) {
+  __shared__ double sm[kCentreFL][64];
+  const int cl = threadIdx.x & 63, fl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double acc = 0.0;
+  if (c < D) {
+    for (int f = fl; f < F; f += kCentreFL) {
+      double sf = 0.0;
+      for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * D + c];
+      fc[int64_t(f) * D + c] = mean_T<DT>(sf, N);
+      acc += sf;
+    }
+  }
+  sm[fl][cl] = acc;
+  __syncthreads();
+  if (fl == 0 && c < D) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kCentreFL; ++i) t += sm[i][cl];
+    if (csum) csum[c] = t;
+    if (vc) vc[c] = mean_T<DT>(t, R_total);
+  }
+}
+
+template <int DT>
+__global__ void k_vid_centre(const double* __restrict__ csum_all, int P, int D, int64_t R_total,
+                             float* __restrict__ vc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  double t = 0.0;
+  for (int p = 0; p < P; ++p) t += csum_all[int64_t(p) * D + c];
+  vc[c] = mean_T<DT>(t, R_total);
+}
+
+// sweep 3: dist_v[r] = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with the frame centre
+// (vidcom2.py:61), x^ recomputed from X and den.
+template <int DT, int VEC>
+__global__ __launch_bounds__(1024) void k_dist(const void* __restrict__ x, int N, int D, int CV, int S,
+                                               int rows_per_split, const uint8_t* __restrict__ mask,
+                                               const float* __restrict__ den, const float* __restrict__ vc,
+                                               const float* __restrict__ fc, float* __restrict__ dv_out,
+                                               float* __restrict__ df_out) {
+  __shared__ double red[2][2][kRB][kMaxWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int f = blockIdx.x / S, sp = blockIdx.x % S;
+  const int n0 = sp * rows_per_split;
+  const int n1 = min(N, n0 + rows_per_split);
+  const bool active = tid < CV;
+  const int64_t col0 = int64_t(tid) * VEC;
+  bool m[VEC];
+  float cvv[VEC], cff[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    m[j] = active && (mask == nullptr || mask[col0 + j] != 0);
+    cvv[j] = active ? vc[col0 + j] : 0.f;
+    cff[j] = active ? fc[int64_t(f) * D + col0 + j] : 0.f;
+  }
+  int buf = 0;
+  for (int nb = n0; nb < n1; nb += kRB, buf ^= 1) {
+    RawVec<DT, VEC> raw[kRB];
+    float dn[kRB];
+#pragma unroll
+    for (int r = 0; r < kRB; ++r) {
+      const int n = nb + r;
+      const bool ok = n < n1;
+      raw[r] = (active && ok) ? load_raw<DT, VEC>(x, (int64_t(f) * N + n) * D + col0)
+                              : zero_raw<DT, VEC>();
+      dn[r] = ok ? den[int64_t(f) * N + n] : 1.f;
+    }
+#pragma unroll
+    for (int r = 0; r < kRB; ++r) {
+      float v[VEC];
+      unpack<DT, VEC>(raw[r], v);
+      double pv = 0.0, pf = 0.0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (m[j]) {
+          const float xh = rnT<DT>(v[j] / dn[r]);
+          const float a = rnT<DT>(xh - cvv[j]);
+          const float b = rnT<DT>(xh - cff[j]);
+          pv += double(rnT<DT>(a * a));
+          pf += double(rnT<DT>(b * b));
+        }
+      }
+      pv = wave_sum(pv);
+      pf = wave_sum(pf);
+      if (lane == 0) { red[buf][0][r][wave] = pv; red[buf][1][r][wave] = pf; }
+    }
+    __syncthreads();
+    if (tid < 2 * kRB) {
+      const int which = tid / kRB, r = tid % kRB;
+      if (nb + r < n1) {
+        double t = 0.0;
+        for (int w = 0; w < nwaves; ++w) t += red[buf][which][r][w];
+        const float d = rnT<DT>(float(t));
+        (which ? df_out : dv_out)[int64_t(f) * N + nb + r] = d;
+      }
+    }
+  }
+}
+
+// per-token epilogue (vidcom2.py:62, :32-33): 5-scale Gaussian sums of both distances, total = v+f,
+// and per frame s = -mean(v).  One workgroup per frame.
+template <int DT>
+__device__ __forceinline__ float gauss_sum(float dist) {
+  const float two_a[5] = {0.25f, 0.5f, 1.0f, 2.0f, 4.0f};   // 2*alpha, alpha = 2^-3 .. 2^1
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const float arg = rnT<DT>((-dist) / two_a[a]);
+    const float e = rnT<DT>(float(exp(double(arg))));
+    acc = (a == 0) ? e : rnT<DT>(acc + e);                   // Python sum(): 0 + t1 is exact
+  }
+  return acc;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_token_epilogue(const float* __restrict__ dv,
+                                                        const float* __restrict__ df, int N,
+                                                        void* __restrict__ v_T, void* __restrict__ f_T,
+                                                        float* __restrict__ total, float* __restrict__ s_out) {
+  __shared__ double sm[4];
+  const int f = blockIdx.x;
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const int64_t i = int64_t(f) * N + n;
+    const float v = gauss_sum<DT>(dv[i]);
+    const float g = gauss_sum<DT>(df[i]);
+    if (v_T) stT<DT>(v_T, i, v);
+    if (f_T) stT<DT>(f_T, i, g);
+    total[i] = rnT<DT>(v + g);
+    acc += double(v);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = sm[0] + sm[1] + sm[2] + sm[3];
+    s_out[f] = -mean_T<DT>(t, N);
+  }
+}
+
+// ======================================================================================
+// budgets (vidcom2.py:64-68, :72): single workgroup over the F frame scores
+// ======================================================================================
+constexpr int kBudNT = 256;
+
+__device__ __forceinline__ double block_sum_256(double v, double* sm) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* sm) {
+  v = wave_max_nanprop(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int i = 1; i < 4; ++i) {
+    const float t = sm[i];
+    r = (r != r) ? r : ((t != t) ? t : fmaxf(r, t));
+  }
+  return r;
+}
+
+// scales = clamp(base * (1 + softmax((s - max s)/temp) - mean(softmax)), max=1) with every op in T.
+template <int DT>
+__global__ __launch_bounds__(kBudNT) void k_scales(const float* __restrict__ s, int F, float base, float temp,
+                                                   float* __restrict__ zbuf, float* __restrict__ scales_f32,
+                                                   void* __restrict__ scales_T) {
+  __shared__ double smd[4];
+  __shared__ float smf[4];
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  bool first = true;
+  for (int i = tid; i < F; i += kBudNT) {
+    const float v = s[i];
+    mx = first ? v : ((mx != mx) ? mx : ((v != v) ? v : fmaxf(mx, v)));
+    first = false;
+  }
+  mx = block_max_256(mx, smf);
+  float zmax = -INFINITY;
+  for (int i = tid; i < F; i += kBudNT) {
+    const float d = rnT<DT>(s[i] - mx);
+    const float z = rnT<DT>(d / temp);
+    zbuf[i] = z;
+    zmax = (zmax != zmax) ? zmax : ((z != z) ? z : fmaxf(zmax, z));
+  }
+  zmax = block_max_256(zmax, smf);
+  double es = 0.0;
+  for (int i = tid; i < F; i += kBudNT) es += double(float(exp(double(zbuf[i] - zmax))));
+  const double esum = block_sum_256(es, smd);
+  double ps = 0.0;
+  for (int i = tid; i < F; i += kBudNT) {
+    const double e = double(float(exp(double(zbuf[i] - zmax))));
+    const float p = rnT<DT>(float(e / esum));
+    zbuf[i] = p;
+    ps += double(p);
+  }
+  const double psum = block_sum_256(ps, smd);
+  const float pmean = mean_T<DT>(psum, F);
+  for (int i = tid; i < F; i += kBudNT) {
+    float t = rnT<DT>(1.0f + zbuf[i]);
+    t = rnT<DT>(t - pmean);
+    t = rnT<DT>(base * t);
+    if (t > 1.0f) t = 1.0f;
+    if (scales_f32) scales_f32[i] = t;
+    if (scales_T) stT<DT>(scales_T, i, t);
+  }
+}
+
+// ks = clamp_min(long(round(RN_T(scales * tpf))), 1); offs = exclusive prefix; K and overflow flag.
+// extra_per_frame rows are reserved after each frame's kept tokens (grid_vid newlines).
+template <int DT>
+__global__ __launch_bounds__(kBudNT) void k_ks(const float* __restrict__ scales_f32, int F, int N,
+                                               int extra_per_frame, int64_t cap, int64_t* __restrict__ ks,
+                                               int64_t* __restrict__ offs, int64_t* __restrict__ K_out) {
+  __shared__ int64_t wtot[4];
+  __shared__ int64_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base_i = 0; base_i < F; base_i += kBudNT) {
+    const int i = base_i + tid;
+    int64_t k = 0;
+    if (i < F) {
+      float t = rnT<DT>(scales_f32[i] * float(N));
+      t = rintf(t);
+      k = (t != t) ? int64_t(1) : int64_t(t);
+      if (k < 1) k = 1;
+      if (k > N) k = N;        // unreachable (scales <= 1); keeps the kernels in-bounds regardless
+      ks[i] = k;
+    }
+    int64_t v = (i < F) ? k + extra_per_frame : 0;
+    const int64_t mine = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (lane == 63) wtot[wave] = v;
+    __syncthreads();
+    int64_t b = carry;
+    for (int w = 0; w < wave; ++w) b += wtot[w];
+    if (i < F) offs[i] = b + v - mine;
+    __syncthreads();
+    if (tid == kBudNT - 1) carry = b + v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    offs[F] = carry;
+    K_out[0] = carry;
+    K_out[1] = carry > cap ? 1 : 0;
+  }
+}
+
+template <int DT>
+__global__ void k_widen(const void* __restrict__ in, int64_t n, float* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ldT<DT>(in, i);
+}
+
+// ======================================================================================
+// per-frame selection + index mapping (vidcom2.py:74-77, :99-115): one workgroup per frame
+// ======================================================================================
+constexpr int kFrameNT = 256;
+
+__global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total, int N,
+                                                     const int64_t* __restrict__ ks,
+                                                     const int64_t* __restrict__ offs, int map_mode,
+                                                     int grid_h, int64_t stride, int64_t cap,
+                                                     int64_t* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SelShared S = sel_carve(smem, N);
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int k = int(ks[f]);
+  const int64_t o0 = offs[f];
+  for (int i = tid; i < N; i += kFrameNT) {
+    S.key[i] = topk_key(total[int64_t(f) * N + i]);
+    S.idx[i] = uint16_t(i);
+  }
+  __syncthreads();
+  topk_smallest_block<kFrameNT>(S, N, k);
+  __syncthreads();
+  // kept flags (reuse la), then ordered compaction = idx.sort().values
+  for (int i = tid; i < N; i += kFrameNT) S.la[i] = (k >= N) ? 1 : 0;
+  __syncthreads();
+  if (k < N)
+    for (int i = tid; i < k; i += kFrameNT) S.la[S.idx[i]] = 1;
+  __syncthreads();
+  const int E = (N + kFrameNT - 1) / kFrameNT;
+  const int b = tid * E, e = min(N, b + E);
+  uint32_t cnt = 0;
+  for (int p = b; p < e; ++p) cnt += S.la[p];
+  uint32_t excl, tot;
+  block_scan_pair<kFrameNT>(cnt, excl, tot, S.wtot);
+  int64_t o = o0 + excl;
+  for (int p = b; p < e; ++p) {
+    if (S.la[p]) {
+      int64_t g;
+      if (map_mode == VC2_MAP_LINEAR) g = int64_t(p) + int64_t(f) * stride;
+      else if (map_mode == VC2_MAP_GRID_VID)
+        g = int64_t(f) * grid_h * (grid_h + 1) + int64_t(p / grid_h) * (grid_h + 1) + (p % grid_h);
+      else g = p;
+      if (o < cap) idx_out[o] = g;
+      ++o;
+    }
+  }
+  if (map_mode == VC2_MAP_GRID_VID) {   // the frame's h newline rows follow its kept tokens
+    for (int a = tid; a < grid_h; a += kFrameNT) {
+      const int64_t oo = o0 + k + a;
+      if (oo < cap) idx_out[oo] = int64_t(f) * grid_h * (grid_h + 1) + int64_t(a) * (grid_h + 1) + grid_h;
+    }
+  }
+}
+
+// standalone mappers on already-selected local indices
+__global__ void k_map_indices(const int64_t* __restrict__ local, const int64_t* __restrict__ ks,
+                              const int64_t* __restrict__ offs, int map_mode, int64_t stride_or_h,
+                              int64_t* __restrict__ out) {
+  const int f = blockIdx.x;
+  const int64_t k = ks[f], o0 = offs[f];
+  if (map_mode == VC2_MAP_GRID_VID) {
+    const int64_t h = stride_or_h, w = h + 1;
+    const int64_t d0 = o0 + int64_t(f) * h;
+    for (int64_t j = threadIdx.x; j < k; j += blockDim.x) {
+      const int64_t p = local[o0 + j];
+      out[d0 + j] = int64_t(f) * h * w + (p / h) * w + (p % h);
+    }
+    for (int64_t a = threadIdx.x; a < h; a += blockDim.x) out[d0 + k + a] = int64_t(f) * h * w + a * w + h;
+  } else {
+    for (int64_t j = threadIdx.x; j < k; j += blockDim.x)
+      out[o0 + j] = local[o0 + j] + int64_t(f) * stride_or_h;
+  }
+}
+
+// kept-row gather: dst[j,:] = src[idx[j],:], 16 B per lane; one workgroup per output row.
+__global__ __launch_bounds__(256) void k_gather_rows(const unsigned char* __restrict__ src,
+                                                     int64_t src_rows, int64_t row_bytes,
+                                                     const int64_t* __restrict__ idx,
+                                                     const int64_t* __restrict__ K_dev, int64_t cap,
+                                                     unsigned char* __restrict__ dst) {
+  const int64_t K = min(K_dev[0], cap);
+  for (int64_t j = blockIdx.x; j < K; j += gridDim.x) {
+    const int64_t r = idx[j];
+    if (r < 0 || r >= src_rows) continue;
+    const unsigned char* s = src + r * row_bytes;
+    unsigned char* d = dst + j * row_bytes;
+    if ((row_bytes & 15) == 0) {
+      const int64_t nv = row_bytes >> 4;
+      for (int64_t t = threadIdx.x; t < nv; t += blockDim.x)
+        reinterpret_cast<uint4*>(d)[t] = reinterpret_cast<const uint4*>(s)[t];
+    } else {
+      for (int64_t t = threadIdx.x; t < row_bytes; t += blockDim.x) d[t] = s[t];
+    }
+  }
+}
+
+// ---- known-answer-test kernels -------------------------------------------------------
+template <int DT>
+__global__ void k_kat_exp(const void* __restrict__ in, int64_t n, void* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) stT<DT>(out, i, float(exp(double(ldT<DT>(in, i)))));
+}
+template <int DT>
+__global__ void k_kat_round(const float* __restrict__ in, int64_t n, void* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) stT<DT>(out, i, in[i]);
+}
+
+// ======================================================================================
+// host side: workspace plan + launchers
+// ======================================================================================
+struct Plan {
+  int64_t F, N, D, R;
+  int dt, ES, VEC, CV, TPB;     // VEC actually used (1 = scalar fallback), column vectors, threads
+  int G, rows_per_group;        // sweep-1 row groups
+  int S, rows_per_split;        // sweep-2/3 splits per frame
+  // workspace offsets (bytes)
+  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_den, o_part_col, o_fc, o_csum, o_vc,
+      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_tmp_f32, total_bytes;
+};
+
+int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
+  if (F <= 0 || N <= 0 || D <= 0) return fail(VC2_ERR_ARG, "F, N, D must be positive (got %lld, %lld, %lld)",
+                                              (long long)F, (long long)N, (long long)D);
+  if (dt < 0 || dt > 2) return fail(VC2_ERR_ARG, "unknown dtype code %d", dt);
+  p->F = F; p->N = N; p->D = D; p->R = F * N; p->dt = dt;
+  p->ES = dt == VC2_F32 ? 4 : 2;
+  const int full = dt == VC2_F32 ? 4 : 8;
+  p->VEC = (D % full == 0) ? full : 1;
+  p->CV = int(D / p->VEC);
+  if (p->CV > 1024)
+    return fail(VC2_ERR_UNSUPPORTED, "D=%lld needs %d column vectors per row; at most 1024 are supported "
+                "(D <= 8192 for 16-bit, <= 4096 for fp32, D %% %d == 0)", (long long)D, p->CV, full);
+  p->TPB = int(cdiv(p->CV, 64) * 64);
+  const int64_t slabs = cdiv(p->CV, 64);
+  int64_t g = std::max<int64_t>(1, std::min<int64_t>(128, cdiv(1024, slabs)));
+  p->rows_per_group = int(std::max<int64_t>(cdiv(p->R, g), 32));
+  p->G = int(cdiv(p->R, p->rows_per_group));
+  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, cdiv(512, F)));
+  p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), kRB));
+  p->rows_per_split = int(cdiv(p->rows_per_split, kRB) * kRB);
+  p->S = int(cdiv(N, p->rows_per_split));
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
+  p->o_part_stats = take(size_t(p->G) * 2 * D * 8);
+  p->o_stats = take(size_t(2) * D * 8);
+  p->o_var_f32 = take(size_t(D) * 4);
+  p->o_var_T = take(size_t(D) * 4);
+  p->o_mask = take(size_t(D));
+  p->o_den = take(size_t(p->R) * 4);
+  p->o_part_col = take(size_t(F) * p->S * D * 8);
+  p->o_fc = take(size_t(F) * D * 4);
+  p->o_csum = take(size_t(D) * 8);
+  p->o_vc = take(size_t(D) * 4);
+  p->o_dv = take(size_t(p->R) * 4);
+  p->o_df = take(size_t(p->R) * 4);
+  p->o_total = take(size_t(p->R) * 4);
+  p->o_s = take(size_t(F) * 4);
+  p->o_zbuf = take(size_t(F) * 4);
+  p->o_scales_f32 = take(size_t(F) * 4);
+  p->o_scales_T = take(size_t(F) * 4);
+  p->o_offs = take(size_t(F + 1) * 8);
+  p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
+  p->total_bytes = o;
+  return VC2_OK;
+}
+
+template <typename T> T* wsp(void* ws, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(ws) + off); }
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return VC2_OK;
+}
+
+#define VC2_DISPATCH_DT(dt, ...)                                    \
+  switch (dt) {                                                     \
+    case VC2_F32: { constexpr int DT = VC2_F32; __VA_ARGS__; } break;   \
+    case VC2_BF16: { constexpr int DT = VC2_BF16; __VA_ARGS__; } break; \
+    default: { constexpr int DT = VC2_F16; __VA_ARGS__; } break;        \
+  }
+// VEC is either the dtype's 16-byte vector width or 1
+#define VC2_DISPATCH_VEC(p, ...)                                            \
+  VC2_DISPATCH_DT((p).dt, if ((p).VEC == 1) { constexpr int VEC = 1; __VA_ARGS__; } \
+                  else { constexpr int VEC = Tr<DT>::VEC; __VA_ARGS__; })
+
+int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
+  if (!ws) return fail(VC2_ERR_ARG, "workspace pointer is null");
+  if (ws_bytes < p.total_bytes)
+    return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total_bytes);
+  return VC2_OK;
+}
+
+// sweep 1 -> (mean, M2) stats and/or var
+int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, void* var_T, float* var_f32,
+                      hipStream_t st) {
+  double* part = wsp<double>(ws, p.o_part_stats);
+  dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
+  VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8>), grid, dim3(kStatsWaves * 64), 0, st, x,
+                                          p.R, int(p.D), p.CV, p.rows_per_group, part));
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_stats_reduce<DT>), dim3(unsigned(cdiv(p.D, 128))), dim3(128), 0,
+                                           st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32));
+  return check_launch("chan_stats");
+}
+
+int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, hipStream_t st) {
+  if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
+                                   (long long)k, (long long)D);
+  const size_t smem = size_t(D) * 10 + 16 * 4 + 64;
+  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask);
+  return check_launch("chan_select");
+}
+
+int launch_phase1(const Plan& p, const void* x, const uint8_t* mask, void* ws, bool single_rank, hipStream_t st) {
+  float* den = wsp<float>(ws, p.o_den);
+  double* part = wsp<double>(ws, p.o_part_col);
+  VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_norm_colsum<DT, VEC>), dim3(unsigned(p.F * p.S)), dim3(p.TPB), 0, st,
+                                          x, int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask, den, part));
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kCentreFL), 0,
+                                           st, part, int(p.F), p.S, int(p.N), int(p.D), wsp<float>(ws, p.o_fc),
+                                           wsp<double>(ws, p.o_csum),
+                                           single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr, p.R));
+  return check_launch("scores phase 1");
+}
+
+int launch_phase2(const Plan& p, const void* x, const uint8_t* mask, void* ws, void* v_T, void* f_T,
+                  float* total, float* s, hipStream_t st) {
+  VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_dist<DT, VEC>), dim3(unsigned(p.F * p.S)), dim3(p.TPB), 0, st, x,
+                                          int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask,
+                                          wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc), wsp<float>(ws, p.o_fc),
+                                          wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df)));
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
+                                           wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df), int(p.N), v_T, f_T,
+                                           total, s));
+  return check_launch("scores phase 2");
+}
+
+int launch_scales(int dt, const float* s, int64_t F, double base, double temp, float* zbuf, float* scales_f32,
+                  void* scales_T, hipStream_t st) {
+  VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_scales<DT>), dim3(1), dim3(kBudNT), 0, st, s, int(F), float(base),
+                                         float(temp), zbuf, scales_f32, scales_T));
+  return check_launch("compute_scales");
+}
+
+int launch_select(int dt, const float* total, const float* scales_f32, int64_t F, int64_t N, int map_mode,
+                  int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
+                  hipStream_t st) {
+  const int extra = map_mode == VC2_MAP_GRID_VID ? int(grid_h) : 0;
+  VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_ks<DT>), dim3(1), dim3(kBudNT), 0, st, scales_f32, int(F), int(N),
+                                         extra, cap, ks, offs, K_out));
+  const size_t smem = size_t(N) * 10 + 16 * 4 + 64;
+  hipLaunchKernelGGL(k_select, dim3(unsigned(F)), dim3(kFrameNT), smem, st, total, int(N), ks, offs, map_mode,
+                     int(grid_h), N, cap, idx_out);
+  return check_launch("select");
+}
+
+int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, const int64_t* idx,
+                       const int64_t* K_dev, int64_t cap, void* dst, hipStream_t st) {
+  if (cap <= 0) return VC2_OK;
+  const unsigned grid = unsigned(std::min<int64_t>(cap, 16384));
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, st, static_cast<const unsigned char*>(src),
+                     src_rows, D * ES, idx, K_dev, cap, static_cast<unsigned char*>(dst));
+  return check_launch("gather_rows");
+}
+
+}  // namespace
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+const char* vc2_last_error(void) { return g_err; }
+const char* vc2_version(void) { return "vidcom2_amd 0.1 (gfx950)"; }
+
+int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
+  if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  *out_bytes = p.total_bytes;
+  return VC2_OK;
+}
+
+int64_t vc2_kept_capacity(int64_t F, int64_t N, double base_scale) {
+  // sum_f scale_f = base*F up to the T rounding of four ops per frame (<= 2^-6 relative in bf16);
+  // each k_f = max(1, round(scale_f*N)) adds at most 1.5 -> a safe, tight bound, capped at F*N.
+  if (F <= 0 || N <= 0) return 0;
+  double b = base_scale > 0 ? base_scale : 0.0;
+  double cap = b * double(F) * double(N) * 1.04 + 2.0 * double(F) + 64.0;
+  double full = double(F) * double(N);
+  return int64_t(cap < full ? cap : full);
+}
+
+int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes, double* stats,
+                   void* stream) {
+  if (!x || !stats) return fail(VC2_ERR_ARG, "null pointer");
+  Plan p;
+  int rc = make_plan(1, R, D, dtype, &p);   // stats do not depend on the frame structure
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  return launch_chan_stats(p, x, ws, stats, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int vc2_chan_var_from_stats(const double* stats, int64_t P, int64_t R_total, int64_t D, int dtype, void* var_T,
+                            float* var_f32, void* stream) {
+  if (!stats || P <= 0 || D <= 0 || R_total <= 0 || R_total % P) return fail(VC2_ERR_ARG, "bad stats arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(D, 128))), dim3(128), 0, st,
+                                            stats, (const int64_t*)nullptr, int(P), R_total / P, int(D), var_T,
+                                            var_f32));
+  return check_launch("var_from_stats");
+}
+
+int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes, void* var_T,
+                 float* var_f32, void* stream) {
+  if (!x) return fail(VC2_ERR_ARG, "x is null");
+  Plan p;
+  int rc = make_plan(1, R, D, dtype, &p);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  float* vf = var_f32 ? var_f32 : wsp<float>(ws, p.o_var_f32);
+  return launch_chan_stats(p, x, ws, nullptr, var_T, vf, static_cast<hipStream_t>(stream));
+}
+
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, void* ws, size_t ws_bytes, uint8_t* mask,
+                    void* stream) {
+  (void)ws; (void)ws_bytes;
+  if (!var_f32 || !mask) return fail(VC2_ERR_ARG, "null pointer");
+  if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
+  return launch_chan_select(var_f32, D, k, mask, static_cast<hipStream_t>(stream));
+}
+
+int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
+                    void* stream) {
+  if (!x || !idx || !out) return fail(VC2_ERR_ARG, "null pointer");
+  if (R <= 0 || C <= 0) return VC2_OK;
+  if (R > 65535LL * 65535LL) return fail(VC2_ERR_UNSUPPORTED, "too many rows");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // grid.y is limited to 65535: loop in slices of rows
+  for (int64_t r0 = 0; r0 < R; r0 += 65535) {
+    const int64_t nr = std::min<int64_t>(65535, R - r0);
+    const int ES = dtype == VC2_F32 ? 4 : 2;
+    const void* xs = static_cast<const char*>(x) + r0 * D * ES;
+    void* os = static_cast<char*>(out) + r0 * C * ES;
+    VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_gather_cols<DT>), dim3(unsigned(cdiv(C, 256)), unsigned(nr)),
+                                              dim3(256), 0, st, xs, nr, int(D), idx, int(C), os));
+  }
+  return check_launch("gather_cols");
+}
+
+int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask, void* ws,
+                      size_t ws_bytes, double* csum, void* stream) {
+  if (!x) return fail(VC2_ERR_ARG, "x is null");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = launch_phase1(p, x, mask, ws, /*single_rank=*/false, st);
+  if (rc) return rc;
+  if (csum) {
+    hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(D) * 8, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "csum copy: %s", hipGetErrorString(e));
+  }
+  return VC2_OK;
+}
+
+int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
+                      const double* csum_all, int64_t P, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
+                      void* f_T, float* total_f32, float* s_f32, void* stream) {
+  if (!x || !csum_all || P <= 0) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(D, 128))), dim3(128), 0, st,
+                                            csum_all, int(P), int(D), R_total, wsp<float>(ws, p.o_vc)));
+  float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
+  float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
+  return launch_phase2(p, x, mask, ws, v_T, f_T, total, s, st);
+}
+
+int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask, void* ws,
+               size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
+  if (!x) return fail(VC2_ERR_ARG, "x is null");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((rc = launch_phase1(p, x, mask, ws, /*single_rank=*/true, st))) return rc;
+  float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
+  float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
+  return launch_phase2(p, x, mask, ws, v_T, f_T, total, s, st);
+}
+
+int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws, size_t ws_bytes,
+                       void* scales_T, void* stream) {
+  if (!s_T || !scales_T || F <= 0) return fail(VC2_ERR_ARG, "bad compute_scales arguments");
+  // only needs 3*F floats of scratch
+  const size_t need = align_up(size_t(F) * 4) * 3;
+  if (!ws || ws_bytes < need) return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* s32 = wsp<float>(ws, 0);
+  float* zbuf = wsp<float>(ws, align_up(size_t(F) * 4));
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_widen<DT>), dim3(unsigned(cdiv(F, 256))), dim3(256), 0, st, s_T, F,
+                                            s32));
+  return launch_scales(dtype, s32, F, base, temp, zbuf, nullptr, scales_T, st);
+}
+
+int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int dtype, int map_mode,
+               int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs, int64_t* idx_out,
+               int64_t cap, int64_t* K_out, void* stream) {
+  if (!scores_T || !scales_T || !ks || !offs || !idx_out || !K_out || F <= 0 || N <= 0)
+    return fail(VC2_ERR_ARG, "bad select arguments");
+  if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
+  if (map_mode == VC2_MAP_GRID_VID && (grid_h <= 0 || grid_h * grid_h != N))
+    return fail(VC2_ERR_ARG, "grid_vid mapping needs N == grid_h^2");
+  const size_t o_sc = align_up(size_t(F) * N * 4);
+  const size_t need = o_sc + align_up(size_t(F) * 4);
+  if (!ws || ws_bytes < need) return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* tot = wsp<float>(ws, 0);
+  float* sc = wsp<float>(ws, o_sc);
+  VC2_DISPATCH_DT(dtype, {
+    hipLaunchKernelGGL((k_widen<DT>), dim3(unsigned(cdiv(F * N, 256))), dim3(256), 0, st, scores_T, F * N, tot);
+    hipLaunchKernelGGL((k_widen<DT>), dim3(unsigned(cdiv(F, 256))), dim3(256), 0, st, scales_T, F, sc);
+  });
+  return launch_select(dtype, tot, sc, F, N, map_mode, grid_h, ks, offs, idx_out, cap, K_out, st);
+}
+
+int vc2_map_indices(const int64_t* local_idx, const int64_t* ks, const int64_t* offs, int64_t F, int map_mode,
+                    int64_t stride_or_h, int64_t* out, void* stream) {
+  if (!local_idx || !ks || !offs || !out || F <= 0) return fail(VC2_ERR_ARG, "bad map arguments");
+  hipLaunchKernelGGL(k_map_indices, dim3(unsigned(F)), dim3(128), 0, static_cast<hipStream_t>(stream), local_idx,
+                     ks, offs, map_mode, stride_or_h, out);
+  return check_launch("map_indices");
+}
+
+int vc2_gather_rows(const void* src, int64_t src_rows, int64_t D, int dtype, const int64_t* idx,
+                    const int64_t* K_dev, int64_t cap, void* dst, void* stream) {
+  if (!src || !idx || !K_dev || !dst) return fail(VC2_ERR_ARG, "null pointer");
+  return launch_gather_rows(src, src_rows, D, dtype == VC2_F32 ? 4 : 2, idx, K_dev, cap, dst,
+                            static_cast<hipStream_t>(stream));
+}
+
+int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale, int map_mode,
+                 int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
+                 void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
+                 void* stream) {
+  if (!x || !idx_out || !ks || !K_out) return fail(VC2_ERR_ARG, "null pointer");
+  if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
+  if (map_mode == VC2_MAP_GRID_VID && (grid_h <= 0 || grid_h * grid_h != N))
+    return fail(VC2_ERR_ARG, "grid_vid mapping needs N == grid_h^2");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* var_f32 = wsp<float>(ws, p.o_var_f32);
+  uint8_t* mask = wsp<uint8_t>(ws, p.o_mask);
+  if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st))) return rc;
+  const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
+  if ((rc = launch_chan_select(var_f32, D, kc, mask, st))) return rc;
+  if ((rc = launch_phase1(p, x, mask, ws, true, st))) return rc;
+  float* total = wsp<float>(ws, p.o_total);
+  float* s = wsp<float>(ws, p.o_s);
+  if ((rc = launch_phase2(p, x, mask, ws, v_T, f_T, total, s, st))) return rc;
+  float* scales = wsp<float>(ws, p.o_scales_f32);
+  if ((rc = launch_scales(dtype, s, F, base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
+  if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
+                          cap, K_out, st)))
+    return rc;
+  if (out_rows && gather_src)
+    rc = launch_gather_rows(gather_src, gather_rows, D, p.ES, idx_out, K_out, cap, out_rows, st);
+  return rc;
+}
+
+int vc2_kat_exp(const void* in_T, int64_t n, int dtype, void* out_T, void* stream) {
+  if (!in_T || !out_T) return fail(VC2_ERR_ARG, "null pointer");
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_kat_exp<DT>), dim3(unsigned(cdiv(n, 256))), dim3(256), 0,
+                                            static_cast<hipStream_t>(stream), in_T, n, out_T));
+  return check_launch("kat_exp");
+}
+int vc2_kat_round(const float* in, int64_t n, int dtype, void* out_T, void* stream) {
+  if (!in || !out_T) return fail(VC2_ERR_ARG, "null pointer");
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_kat_round<DT>), dim3(unsigned(cdiv(n, 256))), dim3(256), 0,
+                                            static_cast<hipStream_t>(stream), in, n, out_T));
+  return check_launch("kat_round");
+}
+
+int vc2_host_topk_order(const float* v, int64_t n, int64_t k, int sorted, int64_t* idx) {
+  if (!v || !idx || n < 0 || k < 0 || k > n) return fail(VC2_ERR_ARG, "bad topk arguments");
+  if (k == 0) return VC2_OK;
+  using elem_t = std::pair<float, int64_t>;
+  std::vector<elem_t> q(static_cast<size_t>(n));
+  for (int64_t j = 0; j < n; ++j) q[size_t(j)] = {v[j], j};
+  auto less = [](const elem_t& a, const elem_t& b) {
+    return ((!std::isnan(a.first) && std::isnan(b.first)) || (a.first < b.first));
+  };
+  if (k * 64 <= n) {
+    std::partial_sort(q.begin(), q.begin() + k, q.end(), less);
+  } else {
+    std::nth_element(q.begin(), q.begin() + (k - 1), q.end(), less);
+    if (sorted) std::sort(q.begin(), q.begin() + (k - 1), less);
+  }
+  for (int64_t j = 0; j < k; ++j) idx[j] = q[size_t(j)].second;
+  return VC2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""Bit-portable synthetic [F, N, D] frame-token embeddings.
+
+Every value is produced by integer arithmetic (splitmix64) followed by ONE
+int->fp32 conversion and fp32 multiplies/adds evaluated one numpy ufunc at a
+time (no FMA contraction), then one round-to-nearest-even cast to the target
+dtype. The result is therefore bit-identical on any IEEE-754 machine, which is
+what lets the golden fixtures under tests/golden/ store only a seed plus the
+sha256 of the generated tensor instead of the tensor itself.
+
+Distributions
+  "iid"   x = g                       (plain ~N(0,1))
+  "drift" x[f,n,c] = s_c * ((b[n,c] + 0.3*e[f,n,c]) + t_f * d[c]),
+          t_f = f/(F-1): a static per-position "scene" b shared by all frames,
+          per-frame noise e, and a slow global drift d so later frames move away
+          from the video centre -> non-trivial per-frame budgets.  s_c is a
+          per-channel scale in {2^(k/2)} so channel variances spread over ~2 decades.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_INV_STD = np.float32(1.0 / 37837.2)   # Irwin-Hall(4) of 16-bit uniforms has std 37837.2
+_SQRT2 = np.float32(1.41421356)
+
+_TID_B, _TID_E, _TID_D, _TID_S, _TID_IID = 1, 2, 3, 4, 5
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def gauss(seed: int, tensor_id: int, start: int, count: int) -> np.ndarray:
+    """count ~N(0,1) fp32 variates for flat indices [start, start+count) of stream (seed, tensor_id)."""
+    idx = np.arange(start, start + count, dtype=np.uint64)
+    # stream base = splitmix64(seed * 2^8 + tensor_id): decorrelates neighbouring seeds/streams
+    base = _splitmix64(np.array([(int(seed) << 8) + int(tensor_id)], dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        key = base + idx
+    h = _splitmix64(key)
+    m = np.uint64(0xFFFF)
+    s = (h & m) + ((h >> np.uint64(16)) & m) + ((h >> np.uint64(32)) & m) + (h >> np.uint64(48))
+    return (s.astype(np.int64) - 131070).astype(np.float32) * _INV_STD
+
+
+def _channel_scale(seed: int, D: int) -> np.ndarray:
+    g = gauss(seed, _TID_S, 0, D)
+    k = np.rint(g * np.float32(2.0)).astype(np.int64)          # half-octave steps
+    k = np.clip(k, -6, 6)
+    base = np.ldexp(np.float32(1.0), (k >> 1).astype(np.int32)).astype(np.float32)
+    return np.where((k & 1) == 1, base * _SQRT2, base).astype(np.float32)
+
+
+def make_fp32(F: int, N: int, D: int, seed: int = 0, dist: str = "drift") -> np.ndarray:
+    """fp32 [F, N, D] master tensor (cast with :func:`to_torch`)."""
+    out = np.empty((F, N, D), dtype=np.float32)
+    if dist == "iid":
+        for f in range(F):
+            out[f] = gauss(seed, _TID_IID, f * N * D, N * D).reshape(N, D)
+        return out
+    if dist != "drift":
+        raise ValueError(f"unknown dist {dist!r}")
+    b = gauss(seed, _TID_B, 0, N * D).reshape(N, D)
+    d = gauss(seed, _TID_D, 0, D)
+    s = _channel_scale(seed, D)
+    denom = np.float32(max(F - 1, 1))
+    for f in range(F):
+        e = gauss(seed, _TID_E, f * N * D, N * D).reshape(N, D)
+        t = np.float32(f) / denom
+        v = b + np.float32(0.3) * e
+        v = v + t * d
+        out[f] = s * v
+    return out
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 bit patterns (uint16), NaN-preserving."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    lsb = (u >> np.uint32(16)) & np.uint32(1)
+    r = ((u + np.uint32(0x7FFF) + lsb) >> np.uint32(16)).astype(np.uint16)
+    nan = (u & np.uint32(0x7FFFFFFF)) > np.uint32(0x7F800000)
+    return np.where(nan, ((u >> np.uint32(16)) | np.uint32(0x40)).astype(np.uint16), r)
+
+
+def to_torch(x32: np.ndarray, dtype):
+    """Cast the fp32 master to a torch tensor of `dtype` (fp32 / bf16 / fp16), RNE."""
+    import torch
+    if dtype == torch.float32:
+        return torch.from_numpy(np.ascontiguousarray(x32))
+    if dtype == torch.bfloat16:
+        bits = f32_to_bf16_bits(x32)
+        return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16).reshape(x32.shape)
+    if dtype == torch.float16:
+        return torch.from_numpy(x32.astype(np.float16))
+    raise ValueError(f"unsupported dtype {dtype}")
+
+
+def make(F: int, N: int, D: int, dtype, seed: int = 0, dist: str = "drift"):
+    """[F*N, D] torch tensor in `dtype` -- the `flattened_feat` the hooks hand to the path."""
+    return to_torch(make_fp32(F, N, D, seed, dist), dtype).reshape(F * N, D)
+
+
+def sha256_tensor(t) -> str:
+    """sha256 over the raw bytes of a contiguous CPU tensor (dtype-agnostic)."""
+    import torch
+    t = t.detach().cpu().contiguous()
+    raw = t.view(torch.uint8).numpy().tobytes() if t.numel() else b""
+    return hashlib.sha256(raw).hexdigest()
