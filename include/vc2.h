@@ -140,6 +140,13 @@ int vc2_kat_exp(const void* in_T, int64_t n, int dtype, void* out_T, void* strea
 /* RN_T round trip of fp32 values (KAT for the conversion instructions). */
 int vc2_kat_round(const float* in, int64_t n, int dtype, void* out_T, void* stream);
 
+/* ---- per-kernel timing (bench.py roofline leg) ----------------------------------------
+ * When enabled every kernel launch is bracketed by hipEvents on its own stream.
+ * vc2_profile_collect synchronises on them and returns accumulated milliseconds / launch counts
+ * per kernel (returns the number of kernels reported). */
+int vc2_profile_enable(int on);
+int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, int64_t* launches);
+
 /* ---- host helper -------------------------------------------------------------------- */
 /* torch.topk(v, k, largest=False, sorted=sorted) ORDER on host memory (ATen TopKImpl.h:
  * libstdc++ partial_sort / nth_element + sort).  Used only by the standalone

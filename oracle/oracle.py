@@ -22,7 +22,7 @@ __all__ = [
     "build", "chan_var", "topk_smallest", "select_low_var_channel_idx", "select_low_var_channels",
     "compute_gaussian_scores", "gaussian_debug", "fuse", "compute_scales", "compute_ks",
     "select_outlier_indices", "map_linear_offset", "map_grid_vid", "compress_indices",
-    "vidcom2_compression", "set_num_threads",
+    "vidcom2_compression", "set_num_threads", "exp_T",
 ]
 
 
@@ -176,6 +176,14 @@ def map_grid_vid(indices: List[torch.Tensor], h: int) -> torch.Tensor:
     loc = torch.cat(indices).contiguous()
     out = torch.empty(loc.numel() + len(indices) * h, dtype=torch.int64)
     _L().vc2o_map_grid_vid(_p(loc), _p(ks), _i64(len(indices)), _i64(h), _p(out))
+    return out
+
+
+def exp_T(x: torch.Tensor) -> torch.Tensor:
+    """RN_T(exp(x)) as the Gaussian kernel evaluates it."""
+    x = _prep(x)
+    out = torch.empty_like(x)
+    _L().vc2o_exp_T(_p(x), _i64(x.numel()), _DT[x.dtype], _p(out))
     return out
 
 

@@ -397,6 +397,12 @@ int vc2o_compress_indices(const void* x, int64_t F, int64_t N, int64_t D, int dt
   return 0;
 }
 
+// exp exactly as the Gaussian kernel evaluates it (vidcom2.py:62): out = RN_T(RN_f32(exp(x))) -- KAT hook
+int vc2o_exp_T(const void* in, int64_t n, int dt, void* out) {
+  for (int64_t i = 0; i < n; ++i) store_T(out, i, dt, float(std::exp(double(load_T(in, i, dt)))));
+  return 0;
+}
+
 // flat[global_idx] row gather (vidcom2.py:91 / :96)
 int vc2o_gather_rows(const void* src, const int64_t* idx, int64_t K, int64_t D, int dt,
                      void* dst) {

@@ -1,0 +1,105 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vc2.h declares; host-side logic of the
+plugin API (argument validation, error behaviour, capacity bound, host top-k order)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+import vidcom2_amd as vc
+from vidcom2_amd import _ffi, synth
+
+from conftest import DT, ROOT, load_core_cases, load_topk_kat
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "vc2.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vc2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_symbols()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/vc2.h but not exported by libvc2hip.so"
+    # and the Python binding covers the same set
+    assert sorted(_ffi.EXPORTED_SYMBOLS) == names
+    assert b"gfx950" in _ffi.lib().vc2_version()
+
+
+def test_reference_api_surface():
+    # token_compressor/vidcom2/__init__.py:2-22 names + MODEL_SPECS (vidcom2.py:7-13)
+    for n in ("vidcom2_compression", "select_low_var_channels", "compute_gaussian_scores", "compute_scales",
+              "select_outlier_indices", "map_features", "_map_linear_offset", "_map_grid_vid"):
+        assert n in vc.__all__ and callable(getattr(vc, n))
+    assert vc.MODEL_SPECS["llava_ov"] == {"tpf": 196, "mapper": "linear"}
+    assert vc.MODEL_SPECS["llava_vid"] == {"tpf": 169, "mapper": "grid_vid", "grid": 13}
+    assert all(vc.MODEL_SPECS[m]["tpf"] is None for m in ("qwen2_vl", "qwen2_5_vl", "qwen3_vl"))
+    from vidcom2_amd.vidcom2 import _multi_scale_gaussian  # noqa: F401  (importable like the reference's)
+
+
+def test_error_behaviour_matches_reference():
+    x = torch.zeros(20, 8)
+    with pytest.raises(ValueError, match="Unknown model: nope"):
+        vc.vidcom2_compression(x, model="nope")
+    with pytest.raises(ValueError, match="frame_token_len required for qwen2_5_vl"):
+        vc.vidcom2_compression(x, model="qwen2_5_vl")
+    with pytest.raises(ValueError, match="img_feat required for grid mapping"):
+        vc.vidcom2_compression(torch.zeros(338, 8), model="llava_vid")
+    with pytest.raises(ValueError, match="img_feat required for grid mapping"):
+        vc.map_features([torch.zeros(1, dtype=torch.long)], x, None, vc.MODEL_SPECS["llava_vid"])
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly on CPU tensors instead of silently computing on the host."""
+    x = synth.make(2, 10, 8, torch.float32, 0, "iid")
+    for fn in (lambda: vc.vidcom2_compression(x, model="qwen2_vl", frame_token_len=10),
+               lambda: vc.select_low_var_channels(x), lambda: vc.compute_gaussian_scores(x, 10),
+               lambda: vc.compute_scales(torch.zeros(4), 0.25),
+               lambda: vc.select_outlier_indices(torch.zeros(2, 10), torch.zeros(2), 10)):
+        with pytest.raises(RuntimeError, match="no CPU fallback|No CPU|CPU fallback"):
+            fn()
+
+
+def test_workspace_and_limits():
+    assert _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16) < 64 << 20
+    with pytest.raises(NotImplementedError):
+        _ffi.workspace_bytes(2, 10, 16384, torch.float32)       # > 1024 column vectors per row
+    with pytest.raises(RuntimeError):
+        _ffi.workspace_bytes(0, 10, 64, torch.float32)
+
+
+def test_kept_capacity_bounds_every_fixture():
+    L = _ffi.lib()
+    for c in load_core_cases():
+        cap = L.vc2_kept_capacity(c["F"], c["N"], c["base"])
+        assert c["K"] <= cap <= c["F"] * c["N"]
+    assert L.vc2_kept_capacity(128, 196, 0.25) < 0.3 * 128 * 196
+
+
+@pytest.mark.parametrize("i", range(0, 315, 3))
+def test_host_topk_order_kat(i):
+    v, k, srt, dn, want = TOPK[i]
+    t = torch.from_numpy(v.copy()).to(DT[dn]).float().contiguous()
+    out = torch.empty(k, dtype=torch.int64)
+    rc = _ffi.lib().vc2_host_topk_order(ctypes.c_void_p(t.data_ptr()), t.numel(), k, int(srt),
+                                        ctypes.c_void_p(out.data_ptr()))
+    assert rc == 0 and out.tolist() == want.tolist()
+
+
+TOPK = load_topk_kat()
+
+
+def test_synth_is_deterministic():
+    a = synth.make(3, 7, 16, torch.bfloat16, 5, "drift")
+    b = synth.make(3, 7, 16, torch.bfloat16, 5, "drift")
+    assert torch.equal(a, b) and not torch.equal(a, synth.make(3, 7, 16, torch.bfloat16, 6, "drift"))
+    x32 = synth.make_fp32(4, 5, 8, 1)
+    assert np.array_equal(x32[2:4], synth.make_fp32_frames(4, 5, 8, 2, 2, 1))
+    bits = synth.f32_to_bf16_bits(np.array([1.0, 1.00390625, 1.01171875, np.inf, -0.0], np.float32))
+    assert bits.tolist() == [0x3F80, 0x3F80, 0x3F82, 0x7F80, 0x8000]    # ties-to-even

@@ -1,0 +1,117 @@
+"""CPU: the oracle (oracle/vc2_oracle.cpp) against the golden vectors captured from the reference
+itself (tests/golden/make_golden.py).  This is the pin that lets the oracle stand in for the
+reference on the GPU box."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from vidcom2_amd import synth
+
+from conftest import DT, case_id, load_core_cases, load_json, load_topk_kat, make_input
+
+CASES = load_core_cases()
+# the two 25k-token shapes cost ~15 s each to regenerate on CPU: keep one of each dtype there
+CPU_CASES = [c for c in CASES if c["F"] * c["N"] * c["D"] <= 32 * 196 * 3584 or c["dtype"] == "bf16"]
+
+
+@pytest.mark.parametrize("c", CPU_CASES, ids=case_id)
+def test_full_pass_vs_reference(c):
+    x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
+    assert synth.sha256_tensor(x) == c["x_sha256"], "synthetic generator is not bit-portable"
+    o = O.compress_indices(x, c["N"], c["base"])
+    _, var = O.select_low_var_channel_idx(x)
+    # variance and channel ORDER (ascending variance, libstdc++ tie order): always bit-exact
+    assert synth.sha256_tensor(var) == c["var_sha256"]
+    assert o["chan_idx"].tolist() == c["chan_idx"]
+    # scores: fp32 within 1e-5 of the reference (north_star tolerance); half types bit-exact except the
+    # few accumulation-order-fragile values counted at generation time (DESIGN.md "Numerics contract")
+    vh, fh = o["v"][0, :16].float().tolist(), o["f"][0, :16].float().tolist()
+    if c["dtype"] == "f32":
+        assert np.allclose(vh, c["v_head"], rtol=0, atol=1e-5) and np.allclose(fh, c["f_head"], rtol=0, atol=1e-5)
+        assert abs(float(o["v"].double().mean()) - c["v_mean"]) < 1e-6
+    elif c["oracle"]["v_mismatch"] == 0 and c["oracle"]["f_mismatch"] == 0:
+        assert synth.sha256_tensor(o["v"]) == c["v_sha256"]
+        assert synth.sha256_tensor(o["f"]) == c["f_sha256"]
+    assert o["ks"].tolist() == c["ks"], "per-frame budgets differ from the reference"
+    if c["stable"]:
+        assert o["global_idx"].tolist() == c["global_idx"], "kept indices differ from the reference"
+        assert synth.sha256_tensor(x[o["global_idx"]]) == c["out_sha256"]
+    else:
+        # reference scores within one rounding of an op boundary: indices may differ in a few frames
+        a, b = set(o["global_idx"].tolist()), set(c["global_idx"])
+        assert len(a) == len(b) and len(a & b) / len(b) > 0.95
+
+
+def test_stable_fraction_documented():
+    """All fp32 and all small/medium bf16 fixtures are index-exact; what is not is half precision at
+    >= 5k tokens (fp16) / >= 20k tokens (bf16), where the reference's own fp32 accumulation order
+    decides a rounding."""
+    unstable = [c for c in CASES if not c["stable"]]
+    assert all(c["dtype"] != "f32" for c in unstable)
+    assert all(c["oracle"]["ks"] and c["oracle"]["chan_idx"] for c in CASES)
+    assert all(c["F"] * c["N"] >= 2500 for c in unstable)
+    assert len(unstable) <= 11
+
+
+@pytest.mark.parametrize("i", range(0, 315, 1))
+def test_topk_kat(i):
+    v, k, srt, dn, want = TOPK[i]
+    t = torch.from_numpy(v.copy()).to(DT[dn])
+    assert O.topk_smallest(t, k, srt).tolist() == want.tolist()
+
+
+TOPK = load_topk_kat()
+
+
+def test_scales_kat():
+    cases = load_json("scales_kat.json")
+    n_equal = 0
+    for c in cases:
+        s = torch.tensor(c["s"], dtype=torch.float32).to(DT[c["dtype"]])
+        sc = O.compute_scales(s, c["base"])
+        want = torch.tensor(c["scales"], dtype=torch.float32)
+        if c["dtype"] == "f32":
+            assert torch.allclose(sc, want, rtol=0, atol=1e-6)
+        n_equal += bool(torch.equal(sc.float(), want))
+        assert O.compute_ks(sc, c["tpf"]) == c["ks"]
+    assert n_equal >= len(cases) - 8     # fp32 softmax differs in the last bit on a few hand-made vectors
+
+
+def test_exp_table():
+    """RN_T(exp(x)) over every bf16 / fp16 bit pattern equals torch.exp's table (sha256 pinned)."""
+    kat = load_json("misc_kat.json")["exp"]
+    for dn in ("bf16", "f16"):
+        bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+        x = bits.view(DT[dn])
+        e = O.exp_T(x)
+        e = torch.where(e.isnan(), torch.full_like(e, float("nan")), e)   # canonical NaN payload
+        assert hashlib.sha256(e.view(torch.int16).numpy().tobytes()).hexdigest() == kat[dn]["sha256"]
+
+
+def test_mappers_and_errors():
+    kat = load_json("misc_kat.json")
+    m = kat["map_linear"]
+    assert O.map_linear_offset([torch.tensor(i) for i in m["indices"]], m["tpf"]).tolist() == m["out"]
+    g = kat["map_grid_vid"]
+    assert O.map_grid_vid([torch.tensor(i) for i in g["indices"]], g["h"]).tolist() == g["out"]
+    x = synth.make(2, 10, 8, torch.float32, 0, "iid")
+    with pytest.raises(ValueError, match="Unknown model: nope"):
+        O.vidcom2_compression(x, model="nope")
+    with pytest.raises(ValueError, match="frame_token_len required for qwen2_5_vl"):
+        O.vidcom2_compression(x, model="qwen2_5_vl")
+    with pytest.raises(ValueError, match="img_feat required for grid mapping"):
+        O.vidcom2_compression(synth.make(2, 169, 8, torch.float32, 0, "iid"), model="llava_vid")
+    with pytest.raises(RuntimeError):
+        O.vidcom2_compression(x, model="qwen2_vl", frame_token_len=7)
+    t = kat["tensor_tpf"]
+    xq = synth.make(t["F"], t["N"], t["D"], DT[t["dtype"]], t["seed"], t["dist"])
+    out = O.vidcom2_compression(xq, model="qwen2_vl", frame_token_len=torch.tensor([25]))
+    assert list(out.shape) == t["shape"] and synth.sha256_tensor(out) == t["out_sha256"]
+    v = kat["llava_vid_e2e"]
+    flat = synth.make(v["F"], v["h"] * v["h"], v["D"], DT[v["dtype"]], v["flat_seed"], "drift")
+    img = synth.make(v["F"], v["h"] * (v["h"] + 1), v["D"], DT[v["dtype"]], v["img_seed"], "iid")
+    out = O.vidcom2_compression(flat, model="llava_vid", base_scale=v["base"], img_feat=img)
+    assert list(out.shape) == v["shape"] and synth.sha256_tensor(out) == v["out_sha256"]

@@ -44,6 +44,8 @@ _SIGNATURES = {
     "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
     "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
     "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],
+    "vc2_profile_enable": [_i32],
+    "vc2_profile_collect": [_i32, _vp, _vp, _vp],
     "vc2_last_error": [],
     "vc2_version": [],
 }
@@ -112,3 +114,17 @@ def workspace_bytes(F: int, N: int, D: int, dtype) -> int:
 
 def workspace(F: int, N: int, D: int, dtype, device) -> torch.Tensor:
     return torch.empty(workspace_bytes(F, N, D, dtype), dtype=torch.uint8, device=device)
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().vc2_profile_enable(int(bool(on))), "vc2_profile_enable")
+
+
+def profile_collect() -> dict:
+    """{kernel name: (total_ms, launches)} accumulated since profile_enable(True)."""
+    n = 16
+    names = (ctypes.c_char_p * n)()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int64 * n)()
+    got = lib().vc2_profile_collect(n, names, ms, cnt)
+    return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(got) if cnt[i]}

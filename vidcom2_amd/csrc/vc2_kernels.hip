@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
 }
 
 template <int DT>
-__global__ void k_gather_cols(const void* __restrict__ x, int64_t R, int D, const int64_t* __restrict__ idx,
+__global__ void k_gather_cols(const void* __restrict__ x, int64_t /*R*/, int D, const int64_t* __restrict__ idx,
                               int C, void* __restrict__ out) {
   const int64_t r = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,6 +732,28 @@ int check_launch(const char* what) {
   return VC2_OK;
 }
 
+// ---- optional per-kernel timing (bench.py's roofline leg): hipEvents around every launch --------
+enum KernelId { KID_STATS = 0, KID_STATS_REDUCE, KID_CHAN_SELECT, KID_NORM_COLSUM, KID_CENTRES, KID_DIST,
+                KID_EPILOGUE, KID_SCALES, KID_KS, KID_SELECT, KID_GATHER_ROWS, KID_OTHER, KID_COUNT };
+const char* const kKernelNames[KID_COUNT] = {"k_chan_stats", "k_stats_reduce", "k_chan_select", "k_norm_colsum",
+                                             "k_centres", "k_dist", "k_token_epilogue", "k_scales", "k_ks",
+                                             "k_select", "k_gather_rows", "other"};
+struct ProfRec { int id; hipEvent_t a, b; };
+bool g_prof = false;
+std::vector<ProfRec> g_prof_recs;
+double g_prof_ms[KID_COUNT];
+int64_t g_prof_n[KID_COUNT];
+
+struct ProfScope {
+  int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) {
+    if (g_prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+  }
+  ~ProfScope() {
+    if (g_prof && a) { (void)hipEventRecord(b, st); g_prof_recs.push_back({id, a, b}); }
+  }
+};
+
 #define VC2_DISPATCH_DT(dt, ...)                                    \
   switch (dt) {                                                     \
     case VC2_F32: { constexpr int DT = VC2_F32; __VA_ARGS__; } break;   \
@@ -755,10 +777,12 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, voi
                       hipStream_t st) {
   double* part = wsp<double>(ws, p.o_part_stats);
   dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
+  { ProfScope ps_(KID_STATS, st);
   VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8>), grid, dim3(kStatsWaves * 64), 0, st, x,
-                                          p.R, int(p.D), p.CV, p.rows_per_group, part));
+                                          p.R, int(p.D), p.CV, p.rows_per_group, part)); }
+  { ProfScope ps_(KID_STATS_REDUCE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_stats_reduce<DT>), dim3(unsigned(cdiv(p.D, 128))), dim3(128), 0,
-                                           st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32));
+                                           st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32)); }
   return check_launch("chan_stats");
 }
 
@@ -766,36 +790,42 @@ int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = size_t(D) * 10 + 16 * 4 + 64;
-  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask);
+  { ProfScope ps_(KID_CHAN_SELECT, st);
+  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask); }
   return check_launch("chan_select");
 }
 
 int launch_phase1(const Plan& p, const void* x, const uint8_t* mask, void* ws, bool single_rank, hipStream_t st) {
   float* den = wsp<float>(ws, p.o_den);
   double* part = wsp<double>(ws, p.o_part_col);
+  { ProfScope ps_(KID_NORM_COLSUM, st);
   VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_norm_colsum<DT, VEC>), dim3(unsigned(p.F * p.S)), dim3(p.TPB), 0, st,
-                                          x, int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask, den, part));
+                                          x, int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask, den, part)); }
+  { ProfScope ps_(KID_CENTRES, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kCentreFL), 0,
                                            st, part, int(p.F), p.S, int(p.N), int(p.D), wsp<float>(ws, p.o_fc),
                                            wsp<double>(ws, p.o_csum),
-                                           single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr, p.R));
+                                           single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr, p.R)); }
   return check_launch("scores phase 1");
 }
 
 int launch_phase2(const Plan& p, const void* x, const uint8_t* mask, void* ws, void* v_T, void* f_T,
                   float* total, float* s, hipStream_t st) {
+  { ProfScope ps_(KID_DIST, st);
   VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_dist<DT, VEC>), dim3(unsigned(p.F * p.S)), dim3(p.TPB), 0, st, x,
                                           int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask,
                                           wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc), wsp<float>(ws, p.o_fc),
-                                          wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df)));
+                                          wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df))); }
+  { ProfScope ps_(KID_EPILOGUE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
                                            wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df), int(p.N), v_T, f_T,
-                                           total, s));
+                                           total, s)); }
   return check_launch("scores phase 2");
 }
 
 int launch_scales(int dt, const float* s, int64_t F, double base, double temp, float* zbuf, float* scales_f32,
                   void* scales_T, hipStream_t st) {
+  ProfScope ps_(KID_SCALES, st);
   VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_scales<DT>), dim3(1), dim3(kBudNT), 0, st, s, int(F), float(base),
                                          float(temp), zbuf, scales_f32, scales_T));
   return check_launch("compute_scales");
@@ -805,11 +835,13 @@ int launch_select(int dt, const float* total, const float* scales_f32, int64_t F
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   hipStream_t st) {
   const int extra = map_mode == VC2_MAP_GRID_VID ? int(grid_h) : 0;
+  { ProfScope ps_(KID_KS, st);
   VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_ks<DT>), dim3(1), dim3(kBudNT), 0, st, scales_f32, int(F), int(N),
-                                         extra, cap, ks, offs, K_out));
+                                         extra, cap, ks, offs, K_out)); }
   const size_t smem = size_t(N) * 10 + 16 * 4 + 64;
+  { ProfScope ps_(KID_SELECT, st);
   hipLaunchKernelGGL(k_select, dim3(unsigned(F)), dim3(kFrameNT), smem, st, total, int(N), ks, offs, map_mode,
-                     int(grid_h), N, cap, idx_out);
+                     int(grid_h), N, cap, idx_out); }
   return check_launch("select");
 }
 
@@ -817,6 +849,7 @@ int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, con
                        const int64_t* K_dev, int64_t cap, void* dst, hipStream_t st) {
   if (cap <= 0) return VC2_OK;
   const unsigned grid = unsigned(std::min<int64_t>(cap, 16384));
+  ProfScope ps_(KID_GATHER_ROWS, st);
   hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, st, static_cast<const unsigned char*>(src),
                      src_rows, D * ES, idx, K_dev, cap, static_cast<unsigned char*>(dst));
   return check_launch("gather_rows");
@@ -1049,6 +1082,35 @@ int vc2_kat_round(const float* in, int64_t n, int dtype, void* out_T, void* stre
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_kat_round<DT>), dim3(unsigned(cdiv(n, 256))), dim3(256), 0,
                                             static_cast<hipStream_t>(stream), in, n, out_T));
   return check_launch("kat_round");
+}
+
+int vc2_profile_enable(int on) {
+  if (on && !g_prof) {
+    for (int i = 0; i < KID_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
+  }
+  g_prof = on != 0;
+  return VC2_OK;
+}
+
+int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, int64_t* launches) {
+  // synchronises on the recorded events, accumulates and frees them
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_prof_ms[r.id] += double(ms);
+      g_prof_n[r.id] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof_recs.clear();
+  const int n = max_kernels < KID_COUNT ? max_kernels : int(KID_COUNT);
+  for (int i = 0; i < n; ++i) {
+    if (names) names[i] = kKernelNames[i];
+    if (total_ms) total_ms[i] = g_prof_ms[i];
+    if (launches) launches[i] = g_prof_n[i];
+  }
+  return n;
 }
 
 int vc2_host_topk_order(const float* v, int64_t n, int64_t k, int sorted, int64_t* idx) {

@@ -57,12 +57,12 @@ def _channel_scale(seed: int, D: int) -> np.ndarray:
     return np.where((k & 1) == 1, base * _SQRT2, base).astype(np.float32)
 
 
-def make_fp32(F: int, N: int, D: int, seed: int = 0, dist: str = "drift") -> np.ndarray:
-    """fp32 [F, N, D] master tensor (cast with :func:`to_torch`)."""
-    out = np.empty((F, N, D), dtype=np.float32)
+def make_fp32_frames(F: int, N: int, D: int, f0: int, count: int, seed: int = 0, dist: str = "drift") -> np.ndarray:
+    """fp32 frames [f0, f0+count) of the F-frame video (lets each rank build only its own shard)."""
+    out = np.empty((count, N, D), dtype=np.float32)
     if dist == "iid":
-        for f in range(F):
-            out[f] = gauss(seed, _TID_IID, f * N * D, N * D).reshape(N, D)
+        for i in range(count):
+            out[i] = gauss(seed, _TID_IID, (f0 + i) * N * D, N * D).reshape(N, D)
         return out
     if dist != "drift":
         raise ValueError(f"unknown dist {dist!r}")
@@ -70,13 +70,19 @@ def make_fp32(F: int, N: int, D: int, seed: int = 0, dist: str = "drift") -> np.
     d = gauss(seed, _TID_D, 0, D)
     s = _channel_scale(seed, D)
     denom = np.float32(max(F - 1, 1))
-    for f in range(F):
+    for i in range(count):
+        f = f0 + i
         e = gauss(seed, _TID_E, f * N * D, N * D).reshape(N, D)
         t = np.float32(f) / denom
         v = b + np.float32(0.3) * e
         v = v + t * d
-        out[f] = s * v
+        out[i] = s * v
     return out
+
+
+def make_fp32(F: int, N: int, D: int, seed: int = 0, dist: str = "drift") -> np.ndarray:
+    """fp32 [F, N, D] master tensor (cast with :func:`to_torch`)."""
+    return make_fp32_frames(F, N, D, 0, F, seed, dist)
 
 
 def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
