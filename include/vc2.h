@@ -134,6 +134,14 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
                       size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32,
                       void* stream);
 
+/* Step 3 of the sharded path: s_all_f32[F_total] = the all-gathered per-frame uniqueness scores
+ * (fp32-widened T values); budgets are computed over all F_total frames, selection + gather only for
+ * this rank's frames [f0, f0+F_local).  idx_out holds LOCAL linear indices (f_local*N + n). */
+int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F_total, int64_t f0,
+                       int64_t F_local, int64_t N, int64_t D, double base_scale, int dtype, void* ws,
+                       size_t ws_bytes, int64_t* ks, int64_t* idx_out, int64_t cap, int64_t* K_out,
+                       const void* gather_src, void* out_rows, void* stream);
+
 /* ---- small device utilities used by tests / bench ----------------------------------- */
 /* exp over every T bit pattern as the path computes it: out[i] = RN_T(exp(in[i])) (KAT). */
 int vc2_kat_exp(const void* in_T, int64_t n, int dtype, void* out_T, void* stream);

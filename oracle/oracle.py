@@ -22,7 +22,7 @@ __all__ = [
     "build", "chan_var", "topk_smallest", "select_low_var_channel_idx", "select_low_var_channels",
     "compute_gaussian_scores", "gaussian_debug", "fuse", "compute_scales", "compute_ks",
     "select_outlier_indices", "map_linear_offset", "map_grid_vid", "compress_indices",
-    "vidcom2_compression", "set_num_threads", "exp_T",
+    "vidcom2_compression", "set_num_threads", "exp_T", "gaussian_scores_sharded",
 ]
 
 
@@ -177,6 +177,26 @@ def map_grid_vid(indices: List[torch.Tensor], h: int) -> torch.Tensor:
     out = torch.empty(loc.numel() + len(indices) * h, dtype=torch.int64)
     _L().vc2o_map_grid_vid(_p(loc), _p(ks), _i64(len(indices)), _i64(h), _p(out))
     return out
+
+
+def gaussian_scores_sharded(x: torch.Tensor, chan_idx: torch.Tensor, tpf: int, csum_all=None, R_total: int = 0):
+    """Shard-local scores.  Returns (v, f, csum_local[C] float64); csum_all [P, C] float64 (all shards'
+    csum_local stacked) + R_total switch the video centre to the whole video's."""
+    x = _prep(x)
+    R, D = x.shape
+    C = chan_idx.numel()
+    if tpf <= 0 or R % tpf:
+        _chk(-2, "compute_gaussian_scores")
+    F, T = R // tpf, x.dtype
+    v, f = torch.empty(F, tpf, dtype=T), torch.empty(F, tpf, dtype=T)
+    csum = torch.empty(C, dtype=torch.float64)
+    ci = chan_idx.contiguous().to(torch.int64)
+    cin = csum_all.contiguous().to(torch.float64) if csum_all is not None else None
+    P = cin.shape[0] if cin is not None else 0
+    _chk(_L().vc2o_gaussian_scores_ex(_p(x), _i64(R), _i64(D), _DT[T], _p(ci), _i64(C), _i64(tpf), _p(cin), _i64(P),
+                                      _i64(R_total), _p(csum), _p(v), _p(f), _p(None), _p(None), _p(None), _p(None),
+                                      _p(None)), "gaussian_scores_sharded")
+    return v, f, csum
 
 
 def exp_T(x: torch.Tensor) -> torch.Tensor:

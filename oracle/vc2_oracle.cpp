@@ -183,9 +183,13 @@ int vc2o_select_low_var_channels(const void* x, int64_t R, int64_t D, int dt, in
 //   x: T[R, D] row-major (R = F*N), idx: int64[C] the selected channels.
 //   Optional debug outputs (may be null): norm T[R], vid_center T[C], frame_center T[F,C],
 //   dist_v / dist_f T[R].
-int vc2o_gaussian_scores(const void* x, int64_t R, int64_t D, int dt, const int64_t* idx,
-                         int64_t C, int64_t tpf, void* v_out, void* f_out, void* norm_out,
-                         void* vc_out, void* fc_out, void* dv_out, void* df_out) {
+// Sharded form (frame-sharded multi-GPU): csum_out (double[C], may be null) receives
+// this shard's sum of normalised tokens; csum_in (double[P][C], may be null) + R_total give the video
+// centre of the WHOLE video instead of the local one.
+int vc2o_gaussian_scores_ex(const void* x, int64_t R, int64_t D, int dt, const int64_t* idx,
+                            int64_t C, int64_t tpf, const double* csum_in, int64_t P, int64_t R_total,
+                            double* csum_out, void* v_out, void* f_out, void* norm_out,
+                            void* vc_out, void* fc_out, void* dv_out, void* df_out) {
   if (tpf <= 0 || R % tpf != 0) return -2;  // torch: .view(-1, tpf, C) RuntimeError
   const int64_t F = R / tpf, N = tpf;
   // F.normalize: x / x.norm(2, -1, keepdim).clamp_min(1e-12).expand_as(x)
@@ -219,7 +223,14 @@ int vc2o_gaussian_scores(const void* x, int64_t R, int64_t D, int dt, const int6
       t += fsum[Z(f * C + j)];
       fc[Z(f * C + j)] = mean_T(fsum[Z(f * C + j)], N, dt);
     }
-    vc[Z(j)] = mean_T(t, R, dt);
+    if (csum_out) csum_out[j] = t;
+    if (csum_in) {
+      t = 0.0;
+      for (int64_t p = 0; p < P; ++p) t += csum_in[p * C + j];
+      vc[Z(j)] = mean_T(t, R_total, dt);
+    } else {
+      vc[Z(j)] = mean_T(t, R, dt);
+    }
   }
   // _multi_scale_gaussian (vidcom2.py:59-62), alphas = 2^-3..2^1
   static const float two_a[5] = {0.25f, 0.5f, 1.0f, 2.0f, 4.0f};
@@ -254,6 +265,13 @@ int vc2o_gaussian_scores(const void* x, int64_t R, int64_t D, int dt, const int6
   if (vc_out) for (int64_t j = 0; j < C; ++j) store_T(vc_out, j, dt, vc[Z(j)]);
   if (fc_out) for (int64_t i = 0; i < F * C; ++i) store_T(fc_out, i, dt, fc[Z(i)]);
   return 0;
+}
+
+int vc2o_gaussian_scores(const void* x, int64_t R, int64_t D, int dt, const int64_t* idx,
+                         int64_t C, int64_t tpf, void* v_out, void* f_out, void* norm_out,
+                         void* vc_out, void* fc_out, void* dv_out, void* df_out) {
+  return vc2o_gaussian_scores_ex(x, R, D, dt, idx, C, tpf, nullptr, 0, 0, nullptr, v_out, f_out, norm_out,
+                                 vc_out, fc_out, dv_out, df_out);
 }
 
 // vidcom2.py:32-33 call-site expressions: s = -vid_score.mean(-1) (T[F]); total = v + f (T[F,N])

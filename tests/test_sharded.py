@@ -1,0 +1,121 @@
+"""Frame-sharded path.  CPU: world_size-2 gloo run of the collective logic with the
+oracle-backed stages.  GPU: P = 1, 2, 4 logical ranks on one device through the HIP stage entry
+points -- results must not depend on the world size and must equal the unsharded pass."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as O
+from vidcom2_amd import synth
+from vidcom2_amd.sharded import ShardedCompressor
+
+from _oracle_stages import OracleStages
+
+SHAPE = (8, 49, 64, 0.25)      # F_total, N, D, base
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, dtype_name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        F, N, D, base = SHAPE
+        dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[dtype_name]
+        x = synth.make(F, N, D, dtype, 3, "drift")
+        Fl = F // world
+        xl = x[rank * Fl * N: (rank + 1) * Fl * N].contiguous()
+        sc = ShardedCompressor(Fl, N, D, dtype, "cpu", base, stages=OracleStages(Fl, N, D, dtype, base))
+        res = sc(xl)
+        q.put((rank, res.global_idx.tolist(), res.ks.tolist(), synth.sha256_tensor(res.rows)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f32"])
+def test_gloo_world2_matches_unsharded(dtype_name):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    F, N, D, base = SHAPE
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[dtype_name]
+    x = synth.make(F, N, D, dtype, 3, "drift")
+    ref = O.compress_indices(x, N, base)
+    gidx = sum((g[1] for g in got), [])
+    ks = sum((g[2] for g in got), [])
+    assert ks == ref["ks"].tolist()
+    assert gidx == ref["global_idx"].tolist()
+    # each rank's rows are the kept rows of its own frames
+    for r, gi, _, sha in got:
+        assert synth.sha256_tensor(x[torch.tensor(gi, dtype=torch.int64)]) == sha
+
+
+def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev):
+    """P logical ranks, one HipStages each, exchanges done by stacking (what all_gather returns)."""
+    from vidcom2_amd.sharded import HipStages
+    Fl = F // P
+    shards = [x[p * Fl * N: (p + 1) * Fl * N].contiguous() for p in range(P)]
+    st = [HipStages(Fl, N, D, dtype, dev, base) for _ in range(P)]
+    stats_all = torch.stack([s.chan_stats(xs).clone() for s, xs in zip(st, shards)])
+    for s in st:
+        s.select_channels(stats_all, F * N)
+    csum_all = torch.stack([s.phase1(xs).clone() for s, xs in zip(st, shards)])
+    s_all = torch.cat([s.phase2(xs, csum_all, F * N).clone() for s, xs in zip(st, shards)])
+    out = []
+    for p, (s, xs) in enumerate(zip(st, shards)):
+        s.select(xs, s_all, p * Fl)
+        out.append(s.result(p * Fl))
+    return out, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(8, 49, 64, "bf16", 0.25), (16, 196, 1024, "bf16", 0.25), (16, 196, 1024, "f32", 0.25),
+                                  (32, 196, 3584, "bf16", 0.25), (16, 169, 512, "f16", 0.15)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_world_size_invariance_on_gpu(case):
+    import vidcom2_amd as vc
+    F, N, D, dn, base = case
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[dn]
+    dev = torch.device("cuda:0")
+    x = synth.make(F, N, D, dtype, 1, "drift")
+    xd = x.to(dev)
+    ref = O.compress_indices(x, N, base)
+    whole = vc.compress(xd, N, base)
+    assert torch.equal(whole.global_idx.cpu(), ref["global_idx"])
+    for P in (1, 2, 4):
+        res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, base, P, dev)
+        gidx = torch.cat([r.global_idx for r in res]).cpu()
+        ks = torch.cat([r.ks for r in res]).cpu()
+        assert ks.tolist() == ref["ks"].tolist(), f"P={P}"
+        assert torch.equal(gidx, ref["global_idx"]), f"P={P}"
+        assert all(torch.equal(s.mask, st[0].mask) for s in st)
+        rows = torch.cat([r.rows for r in res])
+        assert torch.equal(rows, whole.rows)
+
+
+@pytest.mark.gpu
+def test_sharded_compressor_single_process():
+    """world_size 1 (no process group): the ShardedCompressor object itself == the fused pass."""
+    import vidcom2_amd as vc
+    dev = torch.device("cuda:0")
+    x = synth.make(32, 196, 3584, torch.bfloat16, 0, "drift").to(dev)
+    sc = ShardedCompressor(32, 196, 3584, torch.bfloat16, dev, 0.25)
+    r = sc(x)
+    w = vc.compress(x, 196, 0.25)
+    assert torch.equal(r.global_idx, w.global_idx) and torch.equal(r.ks, w.ks) and torch.equal(r.rows, w.rows)

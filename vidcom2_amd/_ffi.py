@@ -41,6 +41,8 @@ _SIGNATURES = {
     "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
     "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _sz, _vp, _vp],
     "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
+                           _vp, _vp],
     "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
     "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
     "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],

@@ -668,6 +668,8 @@ __global__ void k_kat_round(const float* __restrict__ in, int64_t n, void* __res
 // ======================================================================================
 // host side: workspace plan + launchers
 // ======================================================================================
+constexpr int64_t kMaxFramesTotal = 65536;   // frames of the WHOLE video in the frame-sharded path
+
 struct Plan {
   int64_t F, N, D, R;
   int dt, ES, VEC, CV, TPB;     // VEC actually used (1 = scalar fallback), column vectors, threads
@@ -715,8 +717,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_df = take(size_t(p->R) * 4);
   p->o_total = take(size_t(p->R) * 4);
   p->o_s = take(size_t(F) * 4);
-  p->o_zbuf = take(size_t(F) * 4);
-  p->o_scales_f32 = take(size_t(F) * 4);
+  p->o_zbuf = take(size_t(std::max<int64_t>(F, kMaxFramesTotal)) * 4);       // whole-video frame count
+  p->o_scales_f32 = take(size_t(std::max<int64_t>(F, kMaxFramesTotal)) * 4);  // (frame-sharded case)
   p->o_scales_T = take(size_t(F) * 4);
   p->o_offs = take(size_t(F + 1) * 8);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
@@ -1068,6 +1070,33 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
     return rc;
   if (out_rows && gather_src)
     rc = launch_gather_rows(gather_src, gather_rows, D, p.ES, idx_out, K_out, cap, out_rows, st);
+  return rc;
+}
+
+int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F_total, int64_t f0,
+                       int64_t F_local, int64_t N, int64_t D, double base_scale, int dtype, void* ws,
+                       size_t ws_bytes, int64_t* ks, int64_t* idx_out, int64_t cap, int64_t* K_out,
+                       const void* gather_src, void* out_rows, void* stream) {
+  if (!total_f32 || !s_all_f32 || !ks || !idx_out || !K_out) return fail(VC2_ERR_ARG, "null pointer");
+  if (F_total <= 0 || F_local <= 0 || f0 < 0 || f0 + F_local > F_total || F_total > kMaxFramesTotal)
+    return fail(VC2_ERR_ARG, "bad frame range [%lld, %lld) of %lld", (long long)f0, (long long)(f0 + F_local),
+                (long long)F_total);
+  if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
+  Plan p;
+  int rc = make_plan(F_local, N, D, dtype, &p);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* scales = wsp<float>(ws, p.o_scales_f32);
+  // budgets over ALL frames of the video (softmax + mean are global, vidcom2.py:66-67) ...
+  if ((rc = launch_scales(dtype, s_all_f32, F_total, base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st)))
+    return rc;
+  // ... selection only for this rank's frames
+  if ((rc = launch_select(dtype, total_f32, scales + f0, F_local, N, VC2_MAP_LINEAR, 0, ks,
+                          wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out, st)))
+    return rc;
+  if (out_rows && gather_src)
+    rc = launch_gather_rows(gather_src, F_local * N, D, p.ES, idx_out, K_out, cap, out_rows, st);
   return rc;
 }
 

@@ -1,0 +1,143 @@
+"""Frame-sharded VidCom2 compression across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank p holds frames
+[p*F_local, (p+1)*F_local) of ONE video.  The pass shards by frame with three tiny exchange steps --
+every message is <= a few hundred KB, i.e. latency-bound, so each is a single all-gather followed by
+a fixed-order local reduction (NOT an all-reduce: the fixed order makes every rank compute the same
+bits, and the same bits for every world size up to fp64 rounding of the partial sums):
+
+  after sweep 1   per-rank channel statistics (mean, M2)  fp64 [2, D]   -> identical channel mask
+  after sweep 2   per-rank sums of normalised tokens       fp64 [D]      -> identical video centre
+  after sweep 3   per-frame uniqueness scores  -mean(v)    fp32 [F_local] -> global softmax budgets
+                  (the RCCL all-gather BASELINE.json's north_star names)
+
+Kept rows stay sharded by frame (each rank returns the kept rows / indices of its own frames); the
+reference has no multi-GPU form of this path -- its only parallelism is document-level DP in the
+harness (lmms-eval/lmms_eval/evaluator.py:488-491), which is the "replicas only" case.
+
+The arithmetic lives behind a small stage interface so that the collective logic can be exercised on
+CPU with gloo (tests inject an oracle-backed stage object); the default stages are the HIP kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _ffi
+from ._ffi import DTYPE_CODE, check, lib, ptr, stream_ptr
+
+
+@dataclass
+class ShardResult:
+    rows: Optional[torch.Tensor]     # [K_local, D] kept rows of this rank's frames
+    local_idx: torch.Tensor          # int64 [K_local]  f_local*N + n
+    global_idx: torch.Tensor         # int64 [K_local]  index into the whole video's [F_total*N] tokens
+    ks: torch.Tensor                 # int64 [F_local]
+    K: int
+
+
+class HipStages:
+    """The five shard-local stages on the HIP kernels (include/vc2.h 'frame-sharded building blocks')."""
+
+    def __init__(self, F: int, N: int, D: int, dtype, device, base_scale: float, gather: bool = True):
+        self.F, self.N, self.D, self.dtype, self.device, self.base = F, N, D, dtype, torch.device(device), base_scale
+        self.code = DTYPE_CODE[dtype]
+        L = lib()
+        self.ws = _ffi.workspace(F, N, D, dtype, self.device)
+        self.stats = torch.empty((2, D), dtype=torch.float64, device=self.device)
+        self.csum = torch.empty(D, dtype=torch.float64, device=self.device)
+        self.var_f32 = torch.empty(D, dtype=torch.float32, device=self.device)
+        self.mask = torch.empty(D, dtype=torch.uint8, device=self.device)
+        self.total = torch.empty(F * N, dtype=torch.float32, device=self.device)
+        self.s = torch.empty(F, dtype=torch.float32, device=self.device)
+        # a rank can hold the globally dominant frame: sum of its scales <= base * (F_local + 1)
+        self.cap = min(F * N, int(L.vc2_kept_capacity(F + 1, N, base_scale)))
+        self.idx = torch.empty(self.cap, dtype=torch.int64, device=self.device)
+        self.ks = torch.empty(F, dtype=torch.int64, device=self.device)
+        self.kout = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
+
+    def _st(self):
+        return stream_ptr(self.device)
+
+    def chan_stats(self, x):
+        check(lib().vc2_chan_stats(ptr(x), self.F * self.N, self.D, self.code, ptr(self.ws), self.ws.numel(),
+                                   ptr(self.stats), self._st()), "vc2_chan_stats")
+        return self.stats
+
+    def select_channels(self, stats_all, R_total):
+        P = stats_all.shape[0]
+        check(lib().vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, ptr(self.var_f32),
+                                            self._st()), "vc2_chan_var_from_stats")
+        check(lib().vc2_chan_select(ptr(self.var_f32), self.D, int(self.D * 0.5), None, 0, ptr(self.mask), self._st()),
+              "vc2_chan_select")
+
+    def phase1(self, x):
+        check(lib().vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, ptr(self.mask), ptr(self.ws),
+                                      self.ws.numel(), ptr(self.csum), self._st()), "vc2_scores_phase1")
+        return self.csum
+
+    def phase2(self, x, csum_all, R_total):
+        check(lib().vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, ptr(self.mask), ptr(csum_all),
+                                      csum_all.shape[0], R_total, ptr(self.ws), self.ws.numel(), None, None,
+                                      ptr(self.total), ptr(self.s), self._st()), "vc2_scores_phase2")
+        return self.s
+
+    def select(self, x, s_all, f0):
+        check(lib().vc2_select_sharded(ptr(self.total), ptr(s_all), s_all.numel(), f0, self.F, self.N, self.D,
+                                       float(self.base), self.code, ptr(self.ws), self.ws.numel(), ptr(self.ks),
+                                       ptr(self.idx), self.cap, ptr(self.kout),
+                                       ptr(x if self.rows is not None else None), ptr(self.rows), self._st()),
+              "vc2_select_sharded")
+
+    def result(self, f0):
+        K, overflow = self.kout.tolist()                    # the path's single host sync
+        if overflow:
+            raise RuntimeError(f"vidcom2_amd: kept-token capacity {self.cap} exceeded (K={K})")
+        li = self.idx[:K]
+        return ShardResult(self.rows[:K] if self.rows is not None else None, li, li + f0 * self.N, self.ks, int(K))
+
+
+def _all_gather(t: torch.Tensor, group, world: int) -> torch.Tensor:
+    """[world, *t.shape] stacked in rank order (one all-gather; RCCL on GPU tensors, gloo on CPU)."""
+    flat = t.contiguous().reshape(-1)
+    out = torch.empty(world * flat.numel(), dtype=t.dtype, device=t.device)
+    if world == 1:
+        out.copy_(flat)
+    else:
+        dist.all_gather_into_tensor(out, flat, group=group)
+    return out.reshape((world,) + tuple(t.shape))
+
+
+class ShardedCompressor:
+    """Frame-sharded pass; every rank calls enqueue(x_local) + finish() collectively."""
+
+    def __init__(self, F_local: int, N: int, D: int, dtype, device, base_scale: float = 0.25, group=None,
+                 stages=None, gather: bool = True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.F, self.N, self.D = int(F_local), int(N), int(D)
+        self.F_total = self.F * self.world
+        self.f0 = self.rank * self.F
+        self.stages = stages if stages is not None else HipStages(self.F, self.N, self.D, dtype, device, base_scale,
+                                                                  gather)
+
+    def enqueue(self, x_local: torch.Tensor) -> None:
+        st, W = self.stages, self.world
+        R_total = self.F_total * self.N
+        stats_all = _all_gather(st.chan_stats(x_local), self.group, W)          # exchange 1: [W, 2, D] fp64
+        st.select_channels(stats_all, R_total)
+        csum_all = _all_gather(st.phase1(x_local), self.group, W)               # exchange 2: [W, D] fp64
+        s_all = _all_gather(st.phase2(x_local, csum_all, R_total), self.group, W)   # exchange 3: [W, F_local]
+        st.select(x_local, s_all.reshape(-1), self.f0)
+
+    def finish(self) -> ShardResult:
+        return self.stages.result(self.f0)
+
+    def __call__(self, x_local: torch.Tensor) -> ShardResult:
+        self.enqueue(x_local)
+        return self.finish()
