@@ -61,23 +61,24 @@ int64_t vc2_kept_capacity(int64_t F, int64_t N, double base_scale);
 int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes,
                  void* var_T, float* var_f32, void* stream);
 
-/* vidcom2.py:41-42  torch.topk(var, k, largest=False): the SET of the k selected channels as a
- * byte mask mask[D] (1 = selected), with ties at the k-th value broken exactly like the CPU
- * reference (libstdc++ introselect).  var_f32 = widened T values. */
-int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, void* ws, size_t ws_bytes,
-                    uint8_t* mask, void* stream);
+/* vidcom2.py:41-42  torch.topk(var, k, largest=False): the SET of the k selected channels, with ties
+ * at the k-th value broken exactly like the CPU reference (libstdc++ introselect; SURVEY.md
+ * Appendix A).  var_f32 = widened T values.  Outputs (either may be NULL): byte mask mask[D]
+ * (1 = selected) and the ascending channel list cols[k] the scoring sweeps consume. */
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
+                    void* stream);
 
 /* vidcom2.py:43  x[:, idx] column gather -> out T[R, C]; idx int64[C] on device. */
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C,
                     void* out, void* stream);
 
-/* vidcom2.py:45-62  compute_gaussian_scores over the channels with mask[c] != 0 (mask NULL =
- * all channels, i.e. x already holds the selected features).  Sweeps 2 and 3 of X.
+/* vidcom2.py:45-62  compute_gaussian_scores over the C channels listed (ascending) in cols[C]
+ * (cols NULL = all channels, C == D, i.e. x already holds the selected features).  Sweeps 2 and 3 of X.
  * Outputs: v_T, f_T  T[F,N] (may be NULL), total_f32 fp32-widened RN_T(v+f) [F,N] (vidcom2.py:33),
  * s_f32[F] = -mean(v, -1) widened (vidcom2.py:32). */
-int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
-               void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32,
-               void* stream);
+int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+               int64_t C, void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32,
+               float* s_f32, void* stream);
 
 /* vidcom2.py:64-68  compute_scales(scores, base, temp) on T[F] -> scales T[F]. */
 int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws,
@@ -127,12 +128,12 @@ int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, siz
                    double* stats /*[2][D]*/, void* stream);
 int vc2_chan_var_from_stats(const double* stats /*[P][2][D]*/, int64_t P, int64_t R_total, int64_t D,
                             int dtype, void* var_T, float* var_f32, void* stream);
-int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
-                      void* ws, size_t ws_bytes, double* csum /*[D]*/, void* stream);
-int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
-                      const double* csum_all /*[P][D]*/, int64_t P, int64_t R_total, void* ws,
-                      size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32,
-                      void* stream);
+int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+                      int64_t C, void* ws, size_t ws_bytes, double* csum /*[C]*/, void* stream);
+int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+                      int64_t C, const double* csum_all /*[P][csum_stride]*/, int64_t P,
+                      int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
+                      void* f_T, float* total_f32, float* s_f32, void* stream);
 
 /* Step 3 of the sharded path: s_all_f32[F_total] = the all-gathered per-frame uniqueness scores
  * (fp32-widened T values); budgets are computed over all F_total frames, selection + gather only for

@@ -129,8 +129,10 @@ def test_selection_kat(i):
     t = torch.from_numpy(v.copy()).to(DT[dn]).float().to(dev())
     want_set = sorted(want.tolist())
     mask = torch.zeros(n, dtype=torch.uint8, device=dev())
-    check(lib().vc2_chan_select(ptr(t), n, k, None, 0, ptr(mask), stream_ptr(dev())), "chan_select")
+    cols = torch.full((n,), -1, dtype=torch.int32, device=dev())
+    check(lib().vc2_chan_select(ptr(t), n, k, ptr(mask), ptr(cols), stream_ptr(dev())), "chan_select")
     assert mask.cpu().nonzero().flatten().tolist() == want_set
+    assert cols[:k].cpu().tolist() == want_set and bool((cols[k:] == -1).all())
     # per-frame path: 3 identical frames with scale = k/n  ->  ks = k
     if n >= 17:
         F = 3

@@ -117,17 +117,32 @@ __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __r
 
 // Fixed-order reduce of the G row-group partials -> per-rank (mean, M2) in fp64, and (when
 // var_f32 != nullptr, single-rank case) the variance rounded fp64 -> fp32 -> T.
+// Workgroup = 64 columns x 16 partial lanes; lane gl sums partials gl, gl+16, ... then the 16 lane
+// sums are added in lane order (a fixed order: deterministic).
+constexpr int kRedGL = 16;
+
 template <int DT>
-__global__ void k_stats_reduce(const double* __restrict__ part, int G, const void* __restrict__ x,
-                               int64_t R, int D, double* __restrict__ stats, void* __restrict__ var_T,
-                               float* __restrict__ var_f32) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+__global__ __launch_bounds__(64 * kRedGL) void k_stats_reduce(const double* __restrict__ part, int G,
+                                                              const void* __restrict__ x, int64_t R, int D,
+                                                              double* __restrict__ stats, void* __restrict__ var_T,
+                                                              float* __restrict__ var_f32) {
+  __shared__ double sm[2][kRedGL][64];
+  const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double s = 0.0, q = 0.0;
-  for (int g = 0; g < G; ++g) {
-    s += part[(int64_t(g) * 2 + 0) * D + c];
-    q += part[(int64_t(g) * 2 + 1) * D + c];
+  if (c < D) {
+    for (int g = gl; g < G; g += kRedGL) {
+      s += part[(int64_t(g) * 2 + 0) * D + c];
+      q += part[(int64_t(g) * 2 + 1) * D + c];
+    }
   }
+  sm[0][gl][cl] = s;
+  sm[1][gl][cl] = q;
+  __syncthreads();
+  if (gl != 0 || c >= D) return;
+  s = 0.0; q = 0.0;
+#pragma unroll
+  for (int i = 0; i < kRedGL; ++i) { s += sm[0][i][cl]; q += sm[1][i][cl]; }
   const double K = double(ldT<DT>(x, c));
   const double n = double(R);
   const double mean = K + s / n;
@@ -173,19 +188,35 @@ __global__ void k_var_from_stats(const double* __restrict__ stats, const int64_t
 constexpr int kSelNT = 1024;
 
 __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
-                                                        uint8_t* __restrict__ mask) {
+                                                        uint8_t* __restrict__ mask, int* __restrict__ cols) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelShared S = sel_carve(smem, D);
-  for (int i = threadIdx.x; i < D; i += kSelNT) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < D; i += kSelNT) {
     S.key[i] = topk_key(var_f32[i]);
     S.idx[i] = uint16_t(i);
-    mask[i] = (k >= D) ? 1 : 0;
   }
   __syncthreads();
   topk_smallest_block<kSelNT>(S, D, k);
   __syncthreads();
+  // kept flags (reuse la), mask bytes, and the ascending list of kept channels (ordered compaction)
+  for (int i = tid; i < D; i += kSelNT) S.la[i] = (k >= D) ? 1 : 0;
+  __syncthreads();
   if (k < D)
-    for (int i = threadIdx.x; i < k; i += kSelNT) mask[S.idx[i]] = 1;
+    for (int i = tid; i < k; i += kSelNT) S.la[S.idx[i]] = 1;
+  __syncthreads();
+  const int E = (D + kSelNT - 1) / kSelNT;
+  const int b = tid * E, e = min(D, b + E);
+  uint32_t cnt = 0;
+  for (int p = b; p < e; ++p) cnt += S.la[p];
+  uint32_t excl, tot;
+  block_scan_pair<kSelNT>(cnt, excl, tot, S.wtot);
+  int o = int(excl);
+  for (int p = b; p < e; ++p) {
+    const bool on = S.la[p] != 0;
+    if (mask) mask[p] = on ? 1 : 0;
+    if (on) { if (cols) cols[o] = p; ++o; }
+  }
 }
 
 template <int DT>
@@ -203,194 +234,211 @@ __global__ void k_gather_cols(const void* __restrict__ x, int64_t /*R*/, int D, 
 }
 
 // ======================================================================================
-// sweeps 2 and 3: row-wide workgroups, one column vector (VEC channels) per thread
+// sweeps 2 and 3: one wave per token row over the COMPACTED selected channels
 // ======================================================================================
-// A workgroup owns a contiguous run of token rows of ONE frame (split s of frame f); thread t owns
-// channels [t*VEC, t*VEC+VEC).  Rows are processed RB at a time: RB independent 16-byte loads per
-// lane in flight, then per-row reductions: wave shuffle -> LDS -> fixed-order sum.
-constexpr int kRB = 8;        // rows per batch
-constexpr int kMaxWaves = 16; // 1024 threads
+// Only the C selected channels (ascending list cols[C]; nullptr = all D channels) enter the scores,
+// but they are scattered at 50 % density over every 128-byte line, so the whole row is streamed:
+// each wave DMAs its row straight into LDS (global_load_lds, 16 B per lane, no VGPR round trip) and
+// then gathers just the selected elements from LDS -- lane l owns compact positions l, l+64, ... --
+// which halves the VALU work of both sweeps.  A workgroup (4 waves) serves rows of ONE frame.
+constexpr int kRowWaves = 4;
 
-// sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and
-// the per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
 template <int DT, int VEC>
-__global__ __launch_bounds__(1024) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
-                                                      int S, int rows_per_split,
-                                                      const uint8_t* __restrict__ mask,
-                                                      float* __restrict__ den_out,
-                                                      double* __restrict__ part) {
-  __shared__ double red[2][kRB][kMaxWaves];
-  __shared__ float dens[2][kRB];
+__device__ __forceinline__ void stage_row(const void* __restrict__ x, int64_t row, int D, int CV,
+                                          unsigned char* rowbuf, int lane) {
+  constexpr int ES = Tr<DT>::ES;
+  const unsigned char* src = static_cast<const unsigned char*>(x) + row * int64_t(D) * ES;
+  if constexpr (VEC == 1) {
+    for (int c = lane; c < D; c += 64) {
+      if constexpr (ES == 4) reinterpret_cast<float*>(rowbuf)[c] = reinterpret_cast<const float*>(src)[c];
+      else reinterpret_cast<uint16_t*>(rowbuf)[c] = reinterpret_cast<const uint16_t*>(src)[c];
+    }
+  } else {
+    const int nch = (CV + 63) >> 6;
+    for (int j = 0; j < nch; ++j) {
+      const int cv = j * 64 + lane;
+      if (cv < CV)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(src + int64_t(cv) * 16), (lds_void_t*)(rowbuf + j * 1024),
+                                         16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int DT> __device__ __forceinline__ float lds_elem(const unsigned char* rowbuf, int c) {
+  if constexpr (DT == VC2_F32) return reinterpret_cast<const float*>(rowbuf)[c];
+  else if constexpr (DT == VC2_BF16)
+    return __uint_as_float(uint32_t(reinterpret_cast<const uint16_t*>(rowbuf)[c]) << 16);
+  else return float(reinterpret_cast<const _Float16*>(rowbuf)[c]);
+}
+
+// x^ = RN_f32(v / dn) through one fp64 multiply: inv = RN_f64(1/dn); a quotient of two fp32 numbers is
+// never closer than 2^-49 (relative) to a fp32 rounding boundary, the fp64 product is within 2^-52 of
+// it, so the final fp64->fp32 rounding lands where the IEEE fp32 division does -- at a third of the
+// instructions of v_div_scale/v_rcp/v_fma*4/v_div_fmas/v_div_fixup.
+__device__ __forceinline__ float div_via_f64(float v, double inv) { return float(double(v) * inv); }
+
+__host__ __device__ inline size_t row_lds_bytes(int D, int ES) { return (size_t(D) * ES + 15) / 16 * 16; }
+
+// sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and the
+// per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels (compact order).
+// NPLB = compile-time bound on compact positions per lane (ceil(C/64) <= NPLB).
+template <int DT, int VEC, int NPLB>
+__global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
+                                                                int C, const int* __restrict__ cols, int S,
+                                                                int rows_per_split, float* __restrict__ den_out,
+                                                                double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const size_t rowb = row_lds_bytes(D, Tr<DT>::ES);
+  unsigned char* rows = smem;                                    // [kRowWaves][rowb]; later double sacc[C]
+  uint16_t* colsL = reinterpret_cast<uint16_t*>(smem + kRowWaves * rowb);   // [C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nwaves = blockDim.x >> 6;
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
-  const bool active = tid < CV;
-  const int64_t col0 = int64_t(tid) * VEC;
-  bool m[VEC];
+  for (int p = tid; p < C; p += kRowWaves * 64) colsL[p] = uint16_t(cols ? cols[p] : p);
+  __syncthreads();
+  unsigned char* rowbuf = rows + wave * rowb;
+  double acc[NPLB];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) m[j] = active && (mask == nullptr || mask[col0 + j] != 0);
-  double cs[VEC];
+  for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
+  for (int n = n0 + wave; n < n1; n += kRowWaves) {
+    const int64_t row = int64_t(f) * N + n;
+    stage_row<DT, VEC>(x, row, D, CV, rowbuf, lane);
+    float xv[NPLB];
+    double t = 0.0;
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) cs[j] = 0.0;
-
-  int buf = 0;
-  for (int nb = n0; nb < n1; nb += kRB, buf ^= 1) {
-    RawVec<DT, VEC> raw[kRB];
-#pragma unroll
-    for (int r = 0; r < kRB; ++r) {
-      const int n = nb + r;
-      raw[r] = (active && n < n1) ? load_raw<DT, VEC>(x, (int64_t(f) * N + n) * D + col0)
-                                  : zero_raw<DT, VEC>();
+    for (int i = 0; i < NPLB; ++i) {
+      const int p = i * 64 + lane;
+      xv[i] = p < C ? lds_elem<DT>(rowbuf, colsL[p]) : 0.f;
+      t = fma(double(xv[i]), double(xv[i]), t);
     }
-    float v[kRB][VEC];
+    const double n2 = wave_sum(t);
+    const float norm = rnT<DT>(float(sqrt(n2)));
+    // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
+    float dn = rnT<DT>(fmaxf(norm, 1e-12f));
+    if (norm != norm) dn = norm;
+    const double inv = 1.0 / double(dn);
+    if (lane == 0) den_out[row] = dn;
 #pragma unroll
-    for (int r = 0; r < kRB; ++r) {
-      unpack<DT, VEC>(raw[r], v[r]);
-      double p = 0.0;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j)
-        if (m[j]) p = fma(double(v[r][j]), double(v[r][j]), p);
-      p = wave_sum(p);
-      if (lane == 0) red[buf][r][wave] = p;
+    for (int i = 0; i < NPLB; ++i) {
+      const int p = i * 64 + lane;
+      if (p < C) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
     }
-    __syncthreads();
-    if (tid < kRB) {
-      double n2 = 0.0;
-      for (int w = 0; w < nwaves; ++w) n2 += red[buf][tid][w];
-      const float norm = rnT<DT>(float(sqrt(n2)));
-      // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
-      float dn = rnT<DT>(fmaxf(norm, 1e-12f));
-      if (norm != norm) dn = norm;
-      dens[buf][tid] = dn;
-      if (nb + tid < n1) den_out[int64_t(f) * N + nb + tid] = dn;
-    }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+  }
+  // combine the 4 waves' column sums in wave order (fixed order) through LDS, then one partial per block
+  __syncthreads();
+  double* sacc = reinterpret_cast<double*>(rows);                // C*8 <= kRowWaves*rowb
+  for (int w = 0; w < kRowWaves; ++w) {
+    if (wave == w) {
 #pragma unroll
-    for (int r = 0; r < kRB; ++r) {
-      if (nb + r < n1) {
-        const float dn = dens[buf][r];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          if (m[j]) cs[j] += double(rnT<DT>(v[r][j] / dn));
+      for (int i = 0; i < NPLB; ++i) {
+        const int p = i * 64 + lane;
+        if (p < C) sacc[p] = (w == 0 ? 0.0 : sacc[p]) + acc[i];
       }
     }
+    __syncthreads();
   }
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) part[int64_t(blockIdx.x) * D + col0 + j] = cs[j];
-  }
+  for (int p = tid; p < C; p += kRowWaves * 64) part[int64_t(blockIdx.x) * C + p] = sacc[p];
 }
 
-// centres: frame_center[f][c] = mean_T(sum_n x^), csum[c] = sum_f (frame sums) in fp64 (fixed order:
-// frame lanes then lane order), and -- single rank -- vid_center[c] = mean_T(csum, F*N).
-// grid = ceil(D/64) workgroups of 64 columns x FL frame lanes.
+// centres (compact channel space): frame_center[f][p] = mean_T(sum_n x^) and per-frame-group column
+// sums (fp64, fixed order).  grid = (ceil(C/64), ceil(F/16)); workgroup = 64 columns x 16 frames.
 constexpr int kCentreFL = 16;
 
 template <int DT>
 __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __restrict__ part, int F, int S,
-                                                             int N, int D, float* __restrict__ fc,
-                                                             double* __restrict__ csum,
-                                                             float* __restrict__ vc, int64_t R_total) {
+                                                             int N, int C, float* __restrict__ fc,
+                                                             double* __restrict__ csum_part) {
   __shared__ double sm[kCentreFL][64];
   const int cl = threadIdx.x & 63, fl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  double acc = 0.0;
-  if (c < D) {
-    for (int f = fl; f < F; f += kCentreFL) {
-      double sf = 0.0;
-      for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * D + c];
-      fc[int64_t(f) * D + c] = mean_T<DT>(sf, N);
-      acc += sf;
-    }
+  const int f = blockIdx.y * kCentreFL + fl;
+  double sf = 0.0;
+  if (c < C && f < F) {
+    for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
+    fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
   }
-  sm[fl][cl] = acc;
+  sm[fl][cl] = sf;
   __syncthreads();
-  if (fl == 0 && c < D) {
+  if (fl == 0 && c < C) {
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < kCentreFL; ++i) t += sm[i][cl];
-    if (csum) csum[c] = t;
-    if (vc) vc[c] = mean_T<DT>(t, R_total);
+    csum_part[int64_t(blockIdx.y) * C + c] = t;
   }
 }
 
+// video centre from NP partial sums (frame groups of one rank, or the all-gathered per-rank sums):
+// csum_out[c] = sum_p parts[p*stride + c] (fp64) and/or vc[c] = mean_T(that, R_total)  (vidcom2.py:51)
 template <int DT>
-__global__ void k_vid_centre(const double* __restrict__ csum_all, int P, int D, int64_t R_total,
-                             float* __restrict__ vc) {
+__global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t stride, int C, int64_t R_total,
+                             double* __restrict__ csum_out, float* __restrict__ vc) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+  if (c >= C) return;
   double t = 0.0;
-  for (int p = 0; p < P; ++p) t += csum_all[int64_t(p) * D + c];
-  vc[c] = mean_T<DT>(t, R_total);
+  for (int p = 0; p < NP; ++p) t += parts[int64_t(p) * stride + c];
+  if (csum_out) csum_out[c] = t;
+  if (vc) vc[c] = mean_T<DT>(t, R_total);
 }
 
 // sweep 3: dist_v[r] = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with the frame centre
 // (vidcom2.py:61), x^ recomputed from X and den.
 template <int DT, int VEC>
-__global__ __launch_bounds__(1024) void k_dist(const void* __restrict__ x, int N, int D, int CV, int S,
-                                               int rows_per_split, const uint8_t* __restrict__ mask,
-                                               const float* __restrict__ den, const float* __restrict__ vc,
-                                               const float* __restrict__ fc, float* __restrict__ dv_out,
-                                               float* __restrict__ df_out) {
-  __shared__ double red[2][2][kRB][kMaxWaves];
+__global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
+                                                         const int* __restrict__ cols, int S, int rows_per_split,
+                                                         const float* __restrict__ den,
+                                                         const float* __restrict__ vc,
+                                                         const float* __restrict__ fc,
+                                                         float* __restrict__ dv_out, float* __restrict__ df_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const size_t rowb = row_lds_bytes(D, Tr<DT>::ES);
+  unsigned char* rows = smem;                                             // [kRowWaves][rowb]
+  float2* cen = reinterpret_cast<float2*>(smem + kRowWaves * rowb);       // [C] (video, frame) centre
+  uint16_t* colsL = reinterpret_cast<uint16_t*>(cen + C);                 // [C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nwaves = blockDim.x >> 6;
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
-  const bool active = tid < CV;
-  const int64_t col0 = int64_t(tid) * VEC;
-  bool m[VEC];
-  float cvv[VEC], cff[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    m[j] = active && (mask == nullptr || mask[col0 + j] != 0);
-    cvv[j] = active ? vc[col0 + j] : 0.f;
-    cff[j] = active ? fc[int64_t(f) * D + col0 + j] : 0.f;
+  for (int p = tid; p < C; p += kRowWaves * 64) {
+    colsL[p] = uint16_t(cols ? cols[p] : p);
+    cen[p] = make_float2(vc[p], fc[int64_t(f) * C + p]);
   }
-  int buf = 0;
-  for (int nb = n0; nb < n1; nb += kRB, buf ^= 1) {
-    RawVec<DT, VEC> raw[kRB];
-    float dn[kRB];
-#pragma unroll
-    for (int r = 0; r < kRB; ++r) {
-      const int n = nb + r;
-      const bool ok = n < n1;
-      raw[r] = (active && ok) ? load_raw<DT, VEC>(x, (int64_t(f) * N + n) * D + col0)
-                              : zero_raw<DT, VEC>();
-      dn[r] = ok ? den[int64_t(f) * N + n] : 1.f;
-    }
-#pragma unroll
-    for (int r = 0; r < kRB; ++r) {
-      float v[VEC];
-      unpack<DT, VEC>(raw[r], v);
-      double pv = 0.0, pf = 0.0;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if (m[j]) {
-          const float xh = rnT<DT>(v[j] / dn[r]);
-          const float a = rnT<DT>(xh - cvv[j]);
-          const float b = rnT<DT>(xh - cff[j]);
-          pv += double(rnT<DT>(a * a));
-          pf += double(rnT<DT>(b * b));
-        }
-      }
-      pv = wave_sum(pv);
-      pf = wave_sum(pf);
-      if (lane == 0) { red[buf][0][r][wave] = pv; red[buf][1][r][wave] = pf; }
-    }
-    __syncthreads();
-    if (tid < 2 * kRB) {
-      const int which = tid / kRB, r = tid % kRB;
-      if (nb + r < n1) {
-        double t = 0.0;
-        for (int w = 0; w < nwaves; ++w) t += red[buf][which][r][w];
-        const float d = rnT<DT>(float(t));
-        (which ? df_out : dv_out)[int64_t(f) * N + nb + r] = d;
+  __syncthreads();
+  unsigned char* rowbuf = rows + wave * rowb;
+  const int npl = (C + 63) >> 6;
+  for (int n = n0 + wave; n < n1; n += kRowWaves) {
+    const int64_t row = int64_t(f) * N + n;
+    stage_row<DT, VEC>(x, row, D, CV, rowbuf, lane);
+    const double inv = 1.0 / double(den[row]);
+    double pv = 0.0, pf = 0.0;
+#pragma unroll 4
+    for (int i = 0; i < npl; ++i) {
+      const int p = i * 64 + lane;
+      if (p < C) {
+        const float v = lds_elem<DT>(rowbuf, colsL[p]);
+        const float2 ce = cen[p];
+        const float xh = rnT<DT>(div_via_f64(v, inv));
+        const float a = rnT<DT>(xh - ce.x);
+        const float b = rnT<DT>(xh - ce.y);
+        pv += double(rnT<DT>(a * a));
+        pf += double(rnT<DT>(b * b));
       }
     }
+    pv = wave_sum(pv);
+    pf = wave_sum(pf);
+    if (lane == 0) {
+      dv_out[row] = rnT<DT>(float(pv));
+      df_out[row] = rnT<DT>(float(pf));
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -506,49 +554,12 @@ __global__ __launch_bounds__(kBudNT) void k_scales(const float* __restrict__ s, 
   }
 }
 
-// ks = clamp_min(long(round(RN_T(scales * tpf))), 1); offs = exclusive prefix; K and overflow flag.
-// extra_per_frame rows are reserved after each frame's kept tokens (grid_vid newlines).
-template <int DT>
-__global__ __launch_bounds__(kBudNT) void k_ks(const float* __restrict__ scales_f32, int F, int N,
-                                               int extra_per_frame, int64_t cap, int64_t* __restrict__ ks,
-                                               int64_t* __restrict__ offs, int64_t* __restrict__ K_out) {
-  __shared__ int64_t wtot[4];
-  __shared__ int64_t carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base_i = 0; base_i < F; base_i += kBudNT) {
-    const int i = base_i + tid;
-    int64_t k = 0;
-    if (i < F) {
-      float t = rnT<DT>(scales_f32[i] * float(N));
-      t = rintf(t);
-      k = (t != t) ? int64_t(1) : int64_t(t);
-      if (k < 1) k = 1;
-      if (k > N) k = N;        // unreachable (scales <= 1); keeps the kernels in-bounds regardless
-      ks[i] = k;
-    }
-    int64_t v = (i < F) ? k + extra_per_frame : 0;
-    const int64_t mine = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int64_t t = __shfl_up(v, o, 64);
-      if (lane >= o) v += t;
-    }
-    if (lane == 63) wtot[wave] = v;
-    __syncthreads();
-    int64_t b = carry;
-    for (int w = 0; w < wave; ++w) b += wtot[w];
-    if (i < F) offs[i] = b + v - mine;
-    __syncthreads();
-    if (tid == kBudNT - 1) carry = b + v;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    offs[F] = carry;
-    K_out[0] = carry;
-    K_out[1] = carry > cap ? 1 : 0;
-  }
+// k_f = clamp_min(long(round(RN_T(scale_f * tpf))), 1)   (vidcom2.py:72)
+template <int DT> __device__ __forceinline__ int budget_k(float scale, int N) {
+  float t = rnT<DT>(scale * float(N));
+  t = rintf(t);                                    // round-half-even, like torch.round
+  int k = (t != t) ? 1 : (t < 1.f ? 1 : (t > float(N) ? N : int(t)));   // NaN.long() clamps to 1; scale <= 1
+  return k;
 }
 
 template <int DT>
@@ -560,31 +571,51 @@ __global__ void k_widen(const void* __restrict__ in, int64_t n, float* __restric
 // ======================================================================================
 // per-frame selection + index mapping (vidcom2.py:74-77, :99-115): one workgroup per frame
 // ======================================================================================
-constexpr int kFrameNT = 256;
+// One wave per frame (no workgroup barriers anywhere): the wave computes its own output offset as the
+// sum of the budgets of all earlier frames, replays torch.topk's selection on its N scores in LDS,
+// and writes the kept token indices ascending, already mapped (linear / grid_vid / local).
+constexpr int kFrameNT = 64;
 
-__global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total, int N,
-                                                     const int64_t* __restrict__ ks,
-                                                     const int64_t* __restrict__ offs, int map_mode,
-                                                     int grid_h, int64_t stride, int64_t cap,
-                                                     int64_t* __restrict__ idx_out) {
+template <int DT>
+__global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total,
+                                                     const float* __restrict__ scales_f32, int F, int N,
+                                                     int map_mode, int grid_h, int64_t stride, int64_t cap,
+                                                     int64_t* __restrict__ ks, int64_t* __restrict__ offs,
+                                                     int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelShared S = sel_carve(smem, N);
   const int f = blockIdx.x, tid = threadIdx.x;
-  const int k = int(ks[f]);
-  const int64_t o0 = offs[f];
+  const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
+  // budgets: offs[f] = sum_{f' < f} (k_f' + extra)
+  int64_t before = 0;
+  for (int i = tid; i < f; i += kFrameNT) before += budget_k<DT>(scales_f32[i], N) + extra;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+  const int k = budget_k<DT>(scales_f32[f], N);
+  const int64_t o0 = before;
+  if (tid == 0) {
+    ks[f] = k;
+    offs[f] = o0;
+    if (f == F - 1) {
+      const int64_t K = o0 + k + extra;
+      offs[F] = K;
+      K_out[0] = K;
+      K_out[1] = K > cap ? 1 : 0;
+    }
+  }
   for (int i = tid; i < N; i += kFrameNT) {
     S.key[i] = topk_key(total[int64_t(f) * N + i]);
     S.idx[i] = uint16_t(i);
   }
-  __syncthreads();
+  sel_sync<kFrameNT>();
   topk_smallest_block<kFrameNT>(S, N, k);
-  __syncthreads();
+  sel_sync<kFrameNT>();
   // kept flags (reuse la), then ordered compaction = idx.sort().values
   for (int i = tid; i < N; i += kFrameNT) S.la[i] = (k >= N) ? 1 : 0;
-  __syncthreads();
+  sel_sync<kFrameNT>();
   if (k < N)
     for (int i = tid; i < k; i += kFrameNT) S.la[S.idx[i]] = 1;
-  __syncthreads();
+  sel_sync<kFrameNT>();
   const int E = (N + kFrameNT - 1) / kFrameNT;
   const int b = tid * E, e = min(N, b + E);
   uint32_t cnt = 0;
@@ -676,7 +707,7 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups
   int S, rows_per_split;        // sweep-2/3 splits per frame
   // workspace offsets (bytes)
-  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_den, o_part_col, o_fc, o_csum, o_vc,
+  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
       o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_tmp_f32, total_bytes;
 };
 
@@ -694,12 +725,11 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
                 "(D <= 8192 for 16-bit, <= 4096 for fp32, D %% %d == 0)", (long long)D, p->CV, full);
   p->TPB = int(cdiv(p->CV, 64) * 64);
   const int64_t slabs = cdiv(p->CV, 64);
-  int64_t g = std::max<int64_t>(1, std::min<int64_t>(128, cdiv(1024, slabs)));
+  int64_t g = std::max<int64_t>(1, std::min<int64_t>(128, cdiv(640, slabs)));
   p->rows_per_group = int(std::max<int64_t>(cdiv(p->R, g), 32));
   p->G = int(cdiv(p->R, p->rows_per_group));
   int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, cdiv(512, F)));
-  p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), kRB));
-  p->rows_per_split = int(cdiv(p->rows_per_split, kRB) * kRB);
+  p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), std::min<int64_t>(N, 8 * kRowWaves)));
   p->S = int(cdiv(N, p->rows_per_split));
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
@@ -708,10 +738,12 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_var_f32 = take(size_t(D) * 4);
   p->o_var_T = take(size_t(D) * 4);
   p->o_mask = take(size_t(D));
+  p->o_cols = take(size_t(D) * 4);
   p->o_den = take(size_t(p->R) * 4);
   p->o_part_col = take(size_t(F) * p->S * D * 8);
   p->o_fc = take(size_t(F) * D * 4);
   p->o_csum = take(size_t(D) * 8);
+  p->o_csum_part = take(size_t(cdiv(F, kCentreFL)) * D * 8);
   p->o_vc = take(size_t(D) * 4);
   p->o_dv = take(size_t(p->R) * 4);
   p->o_df = take(size_t(p->R) * 4);
@@ -738,7 +770,7 @@ int check_launch(const char* what) {
 enum KernelId { KID_STATS = 0, KID_STATS_REDUCE, KID_CHAN_SELECT, KID_NORM_COLSUM, KID_CENTRES, KID_DIST,
                 KID_EPILOGUE, KID_SCALES, KID_KS, KID_SELECT, KID_GATHER_ROWS, KID_OTHER, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"k_chan_stats", "k_stats_reduce", "k_chan_select", "k_norm_colsum",
-                                             "k_centres", "k_dist", "k_token_epilogue", "k_scales", "k_ks",
+                                             "k_centres", "k_dist", "k_token_epilogue", "k_scales", "k_ks(unused)",
                                              "k_select", "k_gather_rows", "other"};
 struct ProfRec { int id; hipEvent_t a, b; };
 bool g_prof = false;
@@ -783,41 +815,97 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, voi
   VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8>), grid, dim3(kStatsWaves * 64), 0, st, x,
                                           p.R, int(p.D), p.CV, p.rows_per_group, part)); }
   { ProfScope ps_(KID_STATS_REDUCE, st);
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_stats_reduce<DT>), dim3(unsigned(cdiv(p.D, 128))), dim3(128), 0,
-                                           st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32)); }
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_stats_reduce<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
+                                           0, st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32)); }
   return check_launch("chan_stats");
 }
 
-int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, hipStream_t st) {
+int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, hipStream_t st) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = size_t(D) * 10 + 16 * 4 + 64;
+  static bool attr_set = false;
+  if (smem > 48 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chan_select),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(k_chan_select): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
   { ProfScope ps_(KID_CHAN_SELECT, st);
-  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask); }
+  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols); }
   return check_launch("chan_select");
 }
 
-int launch_phase1(const Plan& p, const void* x, const uint8_t* mask, void* ws, bool single_rank, hipStream_t st) {
-  float* den = wsp<float>(ws, p.o_den);
+template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what) {
+  if (smem <= 48 * 1024) return VC2_OK;
+  if (smem > 160 * 1024 - 256) return fail(VC2_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (D too large)", what, smem);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 256);
+  if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+  return VC2_OK;
+}
+
+template <int DT, int VEC, int NPLB>
+int launch_norm_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
+  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(C) * 2 + 16;
+  int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB>, smem, "k_norm_colsum");
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
+                     int(p.N), int(p.D), p.CV, C, cols, p.S, p.rows_per_split, wsp<float>(ws, p.o_den),
+                     wsp<double>(ws, p.o_part_col));
+  return VC2_OK;
+}
+template <int DT, int VEC>
+int launch_norm_v(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
+  const int npl = int(cdiv(C, 64));
+  if (npl <= 8) return launch_norm_t<DT, VEC, 8>(p, x, cols, C, ws, st);
+  if (npl <= 16) return launch_norm_t<DT, VEC, 16>(p, x, cols, C, ws, st);
+  if (npl <= 32) return launch_norm_t<DT, VEC, 32>(p, x, cols, C, ws, st);
+  if (npl <= 64) return launch_norm_t<DT, VEC, 64>(p, x, cols, C, ws, st);
+  return fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels (C=%d)", C);
+}
+
+// sweep 2 + centres.  single_rank: also the video centre; else only the rank's csum (for the all-gather).
+int launch_phase1(const Plan& p, const void* x, const int* cols, int C, void* ws, bool single_rank, hipStream_t st) {
   double* part = wsp<double>(ws, p.o_part_col);
+  double* cpart = wsp<double>(ws, p.o_csum_part);
+  const int FG = int(cdiv(p.F, kCentreFL));
   { ProfScope ps_(KID_NORM_COLSUM, st);
-  VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_norm_colsum<DT, VEC>), dim3(unsigned(p.F * p.S)), dim3(p.TPB), 0, st,
-                                          x, int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask, den, part)); }
+  int rc = VC2_OK;
+  VC2_DISPATCH_VEC(p, rc = (launch_norm_v<DT, VEC>(p, x, cols, C, ws, st)));
+  if (rc) return rc; }
   { ProfScope ps_(KID_CENTRES, st);
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kCentreFL), 0,
-                                           st, part, int(p.F), p.S, int(p.N), int(p.D), wsp<float>(ws, p.o_fc),
-                                           wsp<double>(ws, p.o_csum),
-                                           single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr, p.R)); }
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
+                                           dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, int(p.N), C,
+                                           wsp<float>(ws, p.o_fc), cpart));
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
+                                           cpart, FG, int64_t(C), C, p.R,
+                                           single_rank ? (double*)nullptr : wsp<double>(ws, p.o_csum),
+                                           single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr)); }
   return check_launch("scores phase 1");
 }
 
-int launch_phase2(const Plan& p, const void* x, const uint8_t* mask, void* ws, void* v_T, void* f_T,
+template <int DT, int VEC>
+int launch_dist_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
+  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(C) * (8 + 2) + 16;
+  int rc = allow_big_lds(&k_dist<DT, VEC>, smem, "k_dist");
+  if (rc) return rc;
+  // one workgroup per (frame, split); splits sized so that F*S2 covers the chip a few times over
+  const int S2 = int(std::max<int64_t>(1, std::min<int64_t>(cdiv(p.N, 4 * kRowWaves), cdiv(1024, p.F))));
+  const int rps = int(cdiv(p.N, S2));
+  const int S2e = int(cdiv(p.N, rps));
+  hipLaunchKernelGGL((k_dist<DT, VEC>), dim3(unsigned(p.F * S2e)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
+                     int(p.D), p.CV, C, cols, S2e, rps, wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
+                     wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df));
+  return VC2_OK;
+}
+
+int launch_phase2(const Plan& p, const void* x, const int* cols, int C, void* ws, void* v_T, void* f_T,
                   float* total, float* s, hipStream_t st) {
   { ProfScope ps_(KID_DIST, st);
-  VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_dist<DT, VEC>), dim3(unsigned(p.F * p.S)), dim3(p.TPB), 0, st, x,
-                                          int(p.N), int(p.D), p.CV, p.S, p.rows_per_split, mask,
-                                          wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc), wsp<float>(ws, p.o_fc),
-                                          wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df))); }
+  int rc = VC2_OK;
+  VC2_DISPATCH_VEC(p, rc = (launch_dist_t<DT, VEC>(p, x, cols, C, ws, st)));
+  if (rc) return rc; }
   { ProfScope ps_(KID_EPILOGUE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
                                            wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df), int(p.N), v_T, f_T,
@@ -836,14 +924,11 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 int launch_select(int dt, const float* total, const float* scales_f32, int64_t F, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   hipStream_t st) {
-  const int extra = map_mode == VC2_MAP_GRID_VID ? int(grid_h) : 0;
-  { ProfScope ps_(KID_KS, st);
-  VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_ks<DT>), dim3(1), dim3(kBudNT), 0, st, scales_f32, int(F), int(N),
-                                         extra, cap, ks, offs, K_out)); }
   const size_t smem = size_t(N) * 10 + 16 * 4 + 64;
-  { ProfScope ps_(KID_SELECT, st);
-  hipLaunchKernelGGL(k_select, dim3(unsigned(F)), dim3(kFrameNT), smem, st, total, int(N), ks, offs, map_mode,
-                     int(grid_h), N, cap, idx_out); }
+  ProfScope ps_(KID_SELECT, st);
+  VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F)), dim3(kFrameNT), smem, st, total,
+                                         scales_f32, int(F), int(N), map_mode, int(grid_h), N, cap, ks, offs,
+                                         idx_out, K_out));
   return check_launch("select");
 }
 
@@ -917,12 +1002,10 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
   return launch_chan_stats(p, x, ws, nullptr, var_T, vf, static_cast<hipStream_t>(stream));
 }
 
-int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, void* ws, size_t ws_bytes, uint8_t* mask,
-                    void* stream) {
-  (void)ws; (void)ws_bytes;
-  if (!var_f32 || !mask) return fail(VC2_ERR_ARG, "null pointer");
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, void* stream) {
+  if (!var_f32 || (!mask && !cols)) return fail(VC2_ERR_ARG, "null pointer");
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
-  return launch_chan_select(var_f32, D, k, mask, static_cast<hipStream_t>(stream));
+  return launch_chan_select(var_f32, D, k, mask, cols, static_cast<hipStream_t>(stream));
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -943,51 +1026,61 @@ int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_
   return check_launch("gather_cols");
 }
 
-int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask, void* ws,
-                      size_t ws_bytes, double* csum, void* stream) {
+static int check_cols(const int32_t* cols, int64_t C, int64_t D) {
+  if (C <= 0 || C > D || (!cols && C != D)) return fail(VC2_ERR_ARG, "bad channel list (C=%lld, D=%lld)", (long long)C, (long long)D);
+  if (C > 4096) return fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels (C=%lld)", (long long)C);
+  return VC2_OK;
+}
+
+int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
+                      void* ws, size_t ws_bytes, double* csum, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
+  { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  rc = launch_phase1(p, x, mask, ws, /*single_rank=*/false, st);
+  rc = launch_phase1(p, x, cols, int(C), ws, /*single_rank=*/false, st);
   if (rc) return rc;
   if (csum) {
-    hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(D) * 8, hipMemcpyDeviceToDevice, st);
+    hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "csum copy: %s", hipGetErrorString(e));
   }
   return VC2_OK;
 }
 
-int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask,
-                      const double* csum_all, int64_t P, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
-                      void* f_T, float* total_f32, float* s_f32, void* stream) {
-  if (!x || !csum_all || P <= 0) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
+int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
+                      const double* csum_all, int64_t P, int64_t csum_stride, int64_t R_total, void* ws,
+                      size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
+  if (!x || !csum_all || P <= 0 || csum_stride < C) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
+  { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(D, 128))), dim3(128), 0, st,
-                                            csum_all, int(P), int(D), R_total, wsp<float>(ws, p.o_vc)));
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
+                                            csum_all, int(P), csum_stride, int(C), R_total, (double*)nullptr,
+                                            wsp<float>(ws, p.o_vc)));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
-  return launch_phase2(p, x, mask, ws, v_T, f_T, total, s, st);
+  return launch_phase2(p, x, cols, int(C), ws, v_T, f_T, total, s, st);
 }
 
-int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const uint8_t* mask, void* ws,
+int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C, void* ws,
                size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
+  { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if ((rc = launch_phase1(p, x, mask, ws, /*single_rank=*/true, st))) return rc;
+  if ((rc = launch_phase1(p, x, cols, int(C), ws, /*single_rank=*/true, st))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
-  return launch_phase2(p, x, mask, ws, v_T, f_T, total, s, st);
+  return launch_phase2(p, x, cols, int(C), ws, v_T, f_T, total, s, st);
 }
 
 int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws, size_t ws_bytes,
@@ -1055,14 +1148,14 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
-  uint8_t* mask = wsp<uint8_t>(ws, p.o_mask);
+  int* cols = wsp<int>(ws, p.o_cols);
   if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st))) return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
-  if ((rc = launch_chan_select(var_f32, D, kc, mask, st))) return rc;
-  if ((rc = launch_phase1(p, x, mask, ws, true, st))) return rc;
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, st))) return rc;
+  if ((rc = launch_phase1(p, x, cols, int(kc), ws, true, st))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* s = wsp<float>(ws, p.o_s);
-  if ((rc = launch_phase2(p, x, mask, ws, v_T, f_T, total, s, st))) return rc;
+  if ((rc = launch_phase2(p, x, cols, int(kc), ws, v_T, f_T, total, s, st))) return rc;
   float* scales = wsp<float>(ws, p.o_scales_f32);
   if ((rc = launch_scales(dtype, s, F, base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
   if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,

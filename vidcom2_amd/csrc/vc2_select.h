@@ -127,6 +127,18 @@ __device__ inline void sel_insertion_sort(const SelShared& S, int first, int las
   }
 }
 
+// Barrier between the phases of a round: a workgroup barrier for NT > 64; for a single wave the DS
+// queue already executes in order, so only the compiler must be kept from reordering LDS accesses.
+template <int NT> __device__ __forceinline__ void sel_sync() {
+  if constexpr (NT > 64) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 // ---- workgroup scan of two packed 16-bit counters ----------------------------------------
 template <int NT>
 __device__ __forceinline__ void block_scan_pair(uint32_t packed, uint32_t& excl, uint32_t& total,
@@ -156,23 +168,21 @@ __device__ __forceinline__ void block_scan_pair(uint32_t packed, uint32_t& excl,
   }
 }
 
-// std::nth_element(first, first + nth, first + n) on the (key, idx) array in LDS, by NT threads.
-// All NT threads of the workgroup must call this with identical arguments.
+// Partition rounds of __introselect on [lo, hi) by NT cooperating threads (thread ids tid0 ..
+// tid0+NT-1 of the workgroup, all of which must call this with identical arguments).  Runs until the
+// range is <= max(3, stop_len) long or the heap-select fallback fired (returns true = finished).
 template <int NT>
-__device__ void introselect_block(const SelShared& S, int n, int nth) {
-  if (n == 0 || nth >= n) return;
-  const int tid = threadIdx.x;
-  int lo = 0, hi = n;
-  int depth = 2 * (31 - __clz(n));                       // std::__lg(n) * 2
-  while (hi - lo > 3) {
+__device__ bool introselect_rounds(const SelShared& S, int& lo, int& hi, int& depth, int nth, int stop_len,
+                                   int tid) {
+  while (hi - lo > 3 && hi - lo > stop_len) {
     if (depth == 0) {
       if (tid == 0) { sel_heap_select(S, lo, nth + 1, hi); sel_swap(S, lo, nth); }
-      __syncthreads();
-      return;
+      sel_sync<NT>();
+      return true;
     }
     --depth;
     if (tid == 0) sel_median_to_first(S, lo, lo + 1, lo + (hi - lo) / 2, hi - 1);
-    __syncthreads();
+    sel_sync<NT>();
     const uint32_t pk = S.key[lo];
     const int first = lo + 1, len = hi - first;
     const int E = (len + NT - 1) / NT;
@@ -192,7 +202,7 @@ __device__ void introselect_block(const SelShared& S, int n, int nth) {
       if (k >= pk) S.la[ra++] = uint16_t(p);
       if (k <= pk) S.lb[totB - 1 - (rb++)] = uint16_t(p);
     }
-    __syncthreads();
+    sel_sync<NT>();
     // number of swapped pairs m = #{i : la[i] < lb[i]} (a prefix: la ascends, lb descends)
     int l = 0, r = min(totA, totB);
     while (l < r) {
@@ -208,11 +218,32 @@ __device__ void introselect_block(const SelShared& S, int n, int nth) {
       cut = min(a, int(S.lb[m - 1]));
     }
     for (int i = tid; i < m; i += NT) sel_swap(S, S.la[i], S.lb[i]);
-    __syncthreads();
+    sel_sync<NT>();
     if (cut <= nth) lo = cut; else hi = cut;
   }
-  if (tid == 0) sel_insertion_sort(S, lo, hi);
-  __syncthreads();
+  return false;
+}
+
+// std::nth_element(first, first + nth, first + n) on the (key, idx) array in LDS.  The first rounds
+// (long ranges) use all NT threads of the workgroup; once the range is <= kWaveTail elements wave 0
+// finishes alone, wave-synchronously (no workgroup barriers).  All NT threads must call this.
+constexpr int kWaveTail = 1024;
+
+template <int NT>
+__device__ void introselect_block(const SelShared& S, int n, int nth) {
+  if (n == 0 || nth >= n) return;
+  const int tid = threadIdx.x;
+  int lo = 0, hi = n;
+  int depth = 2 * (31 - __clz(n));                       // std::__lg(n) * 2
+  bool done = false;
+  if constexpr (NT > 64) {
+    done = introselect_rounds<NT>(S, lo, hi, depth, nth, kWaveTail, tid);
+  }
+  if (!done && tid < 64) {
+    done = introselect_rounds<64>(S, lo, hi, depth, nth, 3, tid);
+    if (!done && tid == 0) sel_insertion_sort(S, lo, hi);
+  }
+  sel_sync<NT>();
 }
 
 // torch.topk(v, k, largest=False) SET: afterwards positions [0, k) of (key, idx) hold the kept
@@ -222,7 +253,7 @@ __device__ void topk_smallest_block(const SelShared& S, int n, int k) {
   if (k <= 0 || k >= n) return;                      // k == n: everything kept
   if (int64_t(k) * 64 <= int64_t(n)) {
     if (threadIdx.x == 0) sel_heap_select(S, 0, k, n);  // partial_sort = heap_select + sort_heap
-    __syncthreads();                                    // (sort_heap only permutes the first k)
+    sel_sync<NT>();                                     // (sort_heap only permutes the first k)
   } else {
     introselect_block<NT>(S, n, k - 1);
   }

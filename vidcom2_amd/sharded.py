@@ -48,9 +48,11 @@ class HipStages:
         L = lib()
         self.ws = _ffi.workspace(F, N, D, dtype, self.device)
         self.stats = torch.empty((2, D), dtype=torch.float64, device=self.device)
-        self.csum = torch.empty(D, dtype=torch.float64, device=self.device)
+        self.csum = torch.zeros(D, dtype=torch.float64, device=self.device)   # first C entries are used
         self.var_f32 = torch.empty(D, dtype=torch.float32, device=self.device)
         self.mask = torch.empty(D, dtype=torch.uint8, device=self.device)
+        self.C = int(D * 0.5)                                   # int(x.shape[-1] * ratio), vidcom2.py:41
+        self.cols = torch.empty(D, dtype=torch.int32, device=self.device)
         self.total = torch.empty(F * N, dtype=torch.float32, device=self.device)
         self.s = torch.empty(F, dtype=torch.float32, device=self.device)
         # a rank can hold the globally dominant frame: sum of its scales <= base * (F_local + 1)
@@ -72,18 +74,19 @@ class HipStages:
         P = stats_all.shape[0]
         check(lib().vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, ptr(self.var_f32),
                                             self._st()), "vc2_chan_var_from_stats")
-        check(lib().vc2_chan_select(ptr(self.var_f32), self.D, int(self.D * 0.5), None, 0, ptr(self.mask), self._st()),
+        check(lib().vc2_chan_select(ptr(self.var_f32), self.D, self.C, ptr(self.mask), ptr(self.cols), self._st()),
               "vc2_chan_select")
 
     def phase1(self, x):
-        check(lib().vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, ptr(self.mask), ptr(self.ws),
+        check(lib().vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C, ptr(self.ws),
                                       self.ws.numel(), ptr(self.csum), self._st()), "vc2_scores_phase1")
         return self.csum
 
     def phase2(self, x, csum_all, R_total):
-        check(lib().vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, ptr(self.mask), ptr(csum_all),
-                                      csum_all.shape[0], R_total, ptr(self.ws), self.ws.numel(), None, None,
-                                      ptr(self.total), ptr(self.s), self._st()), "vc2_scores_phase2")
+        check(lib().vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C,
+                                      ptr(csum_all), csum_all.shape[0], csum_all.shape[1], R_total, ptr(self.ws),
+                                      self.ws.numel(), None, None, ptr(self.total), ptr(self.s), self._st()),
+              "vc2_scores_phase2")
         return self.s
 
     def select(self, x, s_all, f0):
