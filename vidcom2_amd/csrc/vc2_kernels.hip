@@ -246,8 +246,26 @@ constexpr int kRowWaves = 4;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+template <int DT> __device__ __forceinline__ float lds_elem(const unsigned char* rowbuf, int c) {
+  if constexpr (DT == VC2_F32) return reinterpret_cast<const float*>(rowbuf)[c];
+  else if constexpr (DT == VC2_BF16)
+    return __uint_as_float(uint32_t(reinterpret_cast<const uint16_t*>(rowbuf)[c]) << 16);
+  else return float(reinterpret_cast<const _Float16*>(rowbuf)[c]);
+}
+
+// x^ = RN_f32(v / dn) through one fp64 multiply: inv = RN_f64(1/dn); a quotient of two fp32 numbers is
+// never closer than 2^-49 (relative) to a fp32 rounding boundary, the fp64 product is within 2^-52 of
+// it, so the final fp64->fp32 rounding lands where the IEEE fp32 division does -- at a third of the
+// instructions of v_div_scale/v_rcp/v_fma*4/v_div_fmas/v_div_fixup.
+__device__ __forceinline__ float div_via_f64(float v, double inv) { return float(double(v) * inv); }
+
+// Row buffer: the row's D elements followed by one zero element (index D) that padded compact
+// positions point at, so the per-element loops need no bounds checks.
+__host__ __device__ inline size_t row_lds_bytes(int D, int ES) { return (size_t(D) * ES + 15) / 16 * 16 + 16; }
+
+// Issue the DMA of one row into `rowbuf` (VEC > 1) / copy it synchronously (scalar fallback).
 template <int DT, int VEC>
-__device__ __forceinline__ void stage_row(const void* __restrict__ x, int64_t row, int D, int CV,
+__device__ __forceinline__ void row_issue(const void* __restrict__ x, int64_t row, int D, int CV,
                                           unsigned char* rowbuf, int lane) {
   constexpr int ES = Tr<DT>::ES;
   const unsigned char* src = static_cast<const unsigned char*>(x) + row * int64_t(D) * ES;
@@ -264,27 +282,26 @@ __device__ __forceinline__ void stage_row(const void* __restrict__ x, int64_t ro
         __builtin_amdgcn_global_load_lds((glb_void_t*)(src + int64_t(cv) * 16), (lds_void_t*)(rowbuf + j * 1024),
                                          16, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+}
+// Wait until every DMA this wave has issued has landed in LDS and is visible to all its lanes.
+__device__ __forceinline__ void row_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int DT> __device__ __forceinline__ float lds_elem(const unsigned char* rowbuf, int c) {
-  if constexpr (DT == VC2_F32) return reinterpret_cast<const float*>(rowbuf)[c];
-  else if constexpr (DT == VC2_BF16)
-    return __uint_as_float(uint32_t(reinterpret_cast<const uint16_t*>(rowbuf)[c]) << 16);
-  else return float(reinterpret_cast<const _Float16*>(rowbuf)[c]);
+// compact position p = i*64 + lane of this lane -> element index inside the row buffer (D = zero pad)
+template <int NPLB>
+__device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, int C, int D, int lane,
+                                                 int (&coff)[NPLB]) {
+#pragma unroll
+  for (int i = 0; i < NPLB; ++i) {
+    const int p = i * 64 + lane;
+    coff[i] = p < C ? (cols ? cols[p] : p) : D;
+  }
 }
-
-// x^ = RN_f32(v / dn) through one fp64 multiply: inv = RN_f64(1/dn); a quotient of two fp32 numbers is
-// never closer than 2^-49 (relative) to a fp32 rounding boundary, the fp64 product is within 2^-52 of
-// it, so the final fp64->fp32 rounding lands where the IEEE fp32 division does -- at a third of the
-// instructions of v_div_scale/v_rcp/v_fma*4/v_div_fmas/v_div_fixup.
-__device__ __forceinline__ float div_via_f64(float v, double inv) { return float(double(v) * inv); }
-
-__host__ __device__ inline size_t row_lds_bytes(int D, int ES) { return (size_t(D) * ES + 15) / 16 * 16; }
 
 // sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and the
 // per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels (compact order).
@@ -295,28 +312,34 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
                                                                 int rows_per_split, float* __restrict__ den_out,
                                                                 double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const size_t rowb = row_lds_bytes(D, Tr<DT>::ES);
-  unsigned char* rows = smem;                                    // [kRowWaves][rowb]; later double sacc[C]
-  uint16_t* colsL = reinterpret_cast<uint16_t*>(smem + kRowWaves * rowb);   // [C]
+  constexpr int ES = Tr<DT>::ES;
+  const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
-  for (int p = tid; p < C; p += kRowWaves * 64) colsL[p] = uint16_t(cols ? cols[p] : p);
-  __syncthreads();
-  unsigned char* rowbuf = rows + wave * rowb;
+  unsigned char* buf0 = smem + size_t(2 * wave) * rowb;          // [kRowWaves][2][rowb]; later double sacc[C]
+  unsigned char* buf1 = buf0 + rowb;
+  if (lane < 4) {                                                // zero pad element of both buffers
+    reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+    reinterpret_cast<uint32_t*>(buf1 + rowb - 16)[lane] = 0u;
+  }
+  int coff[NPLB];
+  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
   double acc[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
-  for (int n = n0 + wave; n < n1; n += kRowWaves) {
+  int n = n0 + wave;
+  if (n < n1) row_issue<DT, VEC>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+  for (; n < n1; n += kRowWaves) {
     const int64_t row = int64_t(f) * N + n;
-    stage_row<DT, VEC>(x, row, D, CV, rowbuf, lane);
+    row_wait();
+    if (n + kRowWaves < n1) row_issue<DT, VEC>(x, row + kRowWaves, D, CV, buf1, lane);
     float xv[NPLB];
     double t = 0.0;
 #pragma unroll
     for (int i = 0; i < NPLB; ++i) {
-      const int p = i * 64 + lane;
-      xv[i] = p < C ? lds_elem<DT>(rowbuf, colsL[p]) : 0.f;
+      xv[i] = lds_elem<DT>(buf0, coff[i]);
       t = fma(double(xv[i]), double(xv[i]), t);
     }
     const double n2 = wave_sum(t);
@@ -327,15 +350,13 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     const double inv = 1.0 / double(dn);
     if (lane == 0) den_out[row] = dn;
 #pragma unroll
-    for (int i = 0; i < NPLB; ++i) {
-      const int p = i * 64 + lane;
-      if (p < C) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < NPLB; ++i) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
+    unsigned char* tbuf = buf0; buf0 = buf1; buf1 = tbuf;
   }
   // combine the 4 waves' column sums in wave order (fixed order) through LDS, then one partial per block
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  double* sacc = reinterpret_cast<double*>(rows);                // C*8 <= kRowWaves*rowb
+  double* sacc = reinterpret_cast<double*>(smem);                // C*8 <= 2*kRowWaves*rowb
   for (int w = 0; w < kRowWaves; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -389,9 +410,25 @@ __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t s
   if (vc) vc[c] = mean_T<DT>(t, R_total);
 }
 
+// RN_T of two values at once (one v_cvt_pk_* instead of two)
+template <int DT> __device__ __forceinline__ void rnT2(float a, float b, float& ra, float& rb) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  if constexpr (DT == VC2_F32) { ra = a; rb = b; }
+  else if constexpr (DT == VC2_BF16) {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    const f2_t w = __builtin_convertvector(__builtin_convertvector((f2_t){a, b}, b2_t), f2_t);
+    ra = w.x; rb = w.y;
+  } else {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const f2_t w = __builtin_convertvector(__builtin_convertvector((f2_t){a, b}, h2_t), f2_t);
+    ra = w.x; rb = w.y;
+  }
+}
+
 // sweep 3: dist_v[r] = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with the frame centre
-// (vidcom2.py:61), x^ recomputed from X and den.
-template <int DT, int VEC>
+// (vidcom2.py:61), x^ recomputed from X and den.  Column offsets and both centres of the lane's compact
+// positions live in registers for the whole workgroup; the row loop touches LDS only for the row itself.
+template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
                                                          const int* __restrict__ cols, int S, int rows_per_split,
                                                          const float* __restrict__ den,
@@ -399,38 +436,48 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
                                                          const float* __restrict__ fc,
                                                          float* __restrict__ dv_out, float* __restrict__ df_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const size_t rowb = row_lds_bytes(D, Tr<DT>::ES);
-  unsigned char* rows = smem;                                             // [kRowWaves][rowb]
-  float2* cen = reinterpret_cast<float2*>(smem + kRowWaves * rowb);       // [C] (video, frame) centre
-  uint16_t* colsL = reinterpret_cast<uint16_t*>(cen + C);                 // [C]
+  constexpr int ES = Tr<DT>::ES;
+  const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
-  for (int p = tid; p < C; p += kRowWaves * 64) {
-    colsL[p] = uint16_t(cols ? cols[p] : p);
-    cen[p] = make_float2(vc[p], fc[int64_t(f) * C + p]);
+  unsigned char* buf0 = smem + size_t(2 * wave) * rowb;          // [kRowWaves][2][rowb]
+  unsigned char* buf1 = buf0 + rowb;
+  float* dens = reinterpret_cast<float*>(smem + size_t(2 * kRowWaves) * rowb);   // [rows_per_split]
+  if (lane < 4) {
+    reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+    reinterpret_cast<uint32_t*>(buf1 + rowb - 16)[lane] = 0u;
   }
+  for (int r = n0 + tid; r < n1; r += kRowWaves * 64) dens[r - n0] = den[int64_t(f) * N + r];
+  int coff[NPLB];
+  float cv[NPLB], cf[NPLB];
+  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
+#pragma unroll
+  for (int i = 0; i < NPLB; ++i) {
+    const int p = i * 64 + lane;
+    cv[i] = p < C ? vc[p] : 0.f;
+    cf[i] = p < C ? fc[int64_t(f) * C + p] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plain loads done before any DMA is in flight
   __syncthreads();
-  unsigned char* rowbuf = rows + wave * rowb;
-  const int npl = (C + 63) >> 6;
-  for (int n = n0 + wave; n < n1; n += kRowWaves) {
+  int n = n0 + wave;
+  if (n < n1) row_issue<DT, VEC>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+  for (; n < n1; n += kRowWaves) {
     const int64_t row = int64_t(f) * N + n;
-    stage_row<DT, VEC>(x, row, D, CV, rowbuf, lane);
-    const double inv = 1.0 / double(den[row]);
+    row_wait();
+    if (n + kRowWaves < n1) row_issue<DT, VEC>(x, row + kRowWaves, D, CV, buf1, lane);
+    const double inv = 1.0 / double(dens[n - n0]);
     double pv = 0.0, pf = 0.0;
-#pragma unroll 4
-    for (int i = 0; i < npl; ++i) {
-      const int p = i * 64 + lane;
-      if (p < C) {
-        const float v = lds_elem<DT>(rowbuf, colsL[p]);
-        const float2 ce = cen[p];
-        const float xh = rnT<DT>(div_via_f64(v, inv));
-        const float a = rnT<DT>(xh - ce.x);
-        const float b = rnT<DT>(xh - ce.y);
-        pv += double(rnT<DT>(a * a));
-        pf += double(rnT<DT>(b * b));
-      }
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) {
+      const float v = lds_elem<DT>(buf0, coff[i]);
+      const float xh = rnT<DT>(div_via_f64(v, inv));
+      float a, b, aa, bb;
+      rnT2<DT>(xh - cv[i], xh - cf[i], a, b);
+      rnT2<DT>(a * a, b * b, aa, bb);
+      pv += double(aa);
+      pf += double(bb);
     }
     pv = wave_sum(pv);
     pf = wave_sum(pf);
@@ -438,7 +485,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
       dv_out[row] = rnT<DT>(float(pv));
       df_out[row] = rnT<DT>(float(pf));
     }
-    __builtin_amdgcn_wave_barrier();
+    unsigned char* tbuf = buf0; buf0 = buf1; buf1 = tbuf;
   }
 }
 
@@ -847,7 +894,7 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what)
 
 template <int DT, int VEC, int NPLB>
 int launch_norm_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
-  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(C) * 2 + 16;
+  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES);
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB>, smem, "k_norm_colsum");
   if (rc) return rc;
   hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
@@ -855,15 +902,27 @@ int launch_norm_t(const Plan& p, const void* x, const int* cols, int C, void* ws
                      wsp<double>(ws, p.o_part_col));
   return VC2_OK;
 }
-template <int DT, int VEC>
-int launch_norm_v(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
-  const int npl = int(cdiv(C, 64));
-  if (npl <= 8) return launch_norm_t<DT, VEC, 8>(p, x, cols, C, ws, st);
-  if (npl <= 16) return launch_norm_t<DT, VEC, 16>(p, x, cols, C, ws, st);
-  if (npl <= 32) return launch_norm_t<DT, VEC, 32>(p, x, cols, C, ws, st);
-  if (npl <= 64) return launch_norm_t<DT, VEC, 64>(p, x, cols, C, ws, st);
-  return fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels (C=%d)", C);
+template <int DT, int VEC, int NPLB>
+int launch_dist_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
+  // one workgroup per (frame, split): ~32 rows each, at least ~768 workgroups when the video allows
+  int64_t rps = std::max<int64_t>(16, std::min<int64_t>(64, cdiv(p.R, 768)));
+  rps = std::min<int64_t>(rps, p.N);
+  const int S2 = int(cdiv(p.N, rps));
+  rps = cdiv(p.N, S2);
+  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 16;
+  int rc = allow_big_lds(&k_dist<DT, VEC, NPLB>, smem, "k_dist");
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_dist<DT, VEC, NPLB>), dim3(unsigned(p.F * S2)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
+                     int(p.D), p.CV, C, cols, S2, int(rps), wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
+                     wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df));
+  return VC2_OK;
 }
+// compact positions per lane -> compile-time bucket (28 = 3584-d, 32 = 4096-d models)
+#define VC2_DISPATCH_NPL(npl, FN, ...)                                   \
+  ((npl) <= 8 ? FN<DT, VEC, 8>(__VA_ARGS__) : (npl) <= 16 ? FN<DT, VEC, 16>(__VA_ARGS__) \
+   : (npl) <= 28 ? FN<DT, VEC, 28>(__VA_ARGS__) : (npl) <= 32 ? FN<DT, VEC, 32>(__VA_ARGS__) \
+   : (npl) <= 64 ? FN<DT, VEC, 64>(__VA_ARGS__)                          \
+   : fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels"))
 
 // sweep 2 + centres.  single_rank: also the video centre; else only the rank's csum (for the all-gather).
 int launch_phase1(const Plan& p, const void* x, const int* cols, int C, void* ws, bool single_rank, hipStream_t st) {
@@ -872,7 +931,8 @@ int launch_phase1(const Plan& p, const void* x, const int* cols, int C, void* ws
   const int FG = int(cdiv(p.F, kCentreFL));
   { ProfScope ps_(KID_NORM_COLSUM, st);
   int rc = VC2_OK;
-  VC2_DISPATCH_VEC(p, rc = (launch_norm_v<DT, VEC>(p, x, cols, C, ws, st)));
+  const int npl = int(cdiv(C, 64));
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cols, C, ws, st));
   if (rc) return rc; }
   { ProfScope ps_(KID_CENTRES, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
@@ -885,26 +945,12 @@ int launch_phase1(const Plan& p, const void* x, const int* cols, int C, void* ws
   return check_launch("scores phase 1");
 }
 
-template <int DT, int VEC>
-int launch_dist_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
-  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(C) * (8 + 2) + 16;
-  int rc = allow_big_lds(&k_dist<DT, VEC>, smem, "k_dist");
-  if (rc) return rc;
-  // one workgroup per (frame, split); splits sized so that F*S2 covers the chip a few times over
-  const int S2 = int(std::max<int64_t>(1, std::min<int64_t>(cdiv(p.N, 4 * kRowWaves), cdiv(1024, p.F))));
-  const int rps = int(cdiv(p.N, S2));
-  const int S2e = int(cdiv(p.N, rps));
-  hipLaunchKernelGGL((k_dist<DT, VEC>), dim3(unsigned(p.F * S2e)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
-                     int(p.D), p.CV, C, cols, S2e, rps, wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
-                     wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df));
-  return VC2_OK;
-}
-
 int launch_phase2(const Plan& p, const void* x, const int* cols, int C, void* ws, void* v_T, void* f_T,
                   float* total, float* s, hipStream_t st) {
   { ProfScope ps_(KID_DIST, st);
   int rc = VC2_OK;
-  VC2_DISPATCH_VEC(p, rc = (launch_dist_t<DT, VEC>(p, x, cols, C, ws, st)));
+  const int npl = int(cdiv(C, 64));
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cols, C, ws, st));
   if (rc) return rc; }
   { ProfScope ps_(KID_EPILOGUE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
