@@ -106,6 +106,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Wave total of an fp64 value with DPP lane moves (VALU latency) instead of ds_bpermute (LDS-crossbar
+// latency): quad swaps, half-row / row mirrors, then the two gfx9 row broadcasts; the total lands in
+// lane 63 and is broadcast through an SGPR pair.  Every lane returns the same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return v + __hiloint2double(thi, tlo);
+}
+__device__ __forceinline__ double wave_sum_bcast(double v) {
+  v = dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);    // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);    // row_mirror        -> every lane holds its 16-lane row total
+  v = dpp_add<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ float wave_max_nanprop(float v) {  // NaN wins (torch max semantics)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelShared S = sel_carve(smem, D);
   const int tid = threadIdx.x;
+  dbg_stamp(1);
   for (int i = tid; i < D; i += kSelNT) {
     S.key[i] = topk_key(var_f32[i]);
     S.idx[i] = uint16_t(i);
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
     if (mask) mask[p] = on ? 1 : 0;
     if (on) { if (cols) cols[o] = p; ++o; }
   }
+  dbg_stamp(9);
 }
 
 template <int DT>
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
       xv[i] = lds_elem<DT>(buf0, coff[i]);
       t = fma(double(xv[i]), double(xv[i]), t);
     }
-    const double n2 = wave_sum(t);
+    const double n2 = wave_sum_bcast(t);
     const float norm = rnT<DT>(float(sqrt(n2)));
     // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
     float dn = rnT<DT>(fmaxf(norm, 1e-12f));
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
       pv += double(aa);
       pf += double(bb);
     }
-    pv = wave_sum(pv);
-    pf = wave_sum(pf);
+    pv = wave_sum_bcast(pv);
+    pf = wave_sum_bcast(pf);
     if (lane == 0) {
       dv_out[row] = rnT<DT>(float(pv));
       df_out[row] = rnT<DT>(float(pf));
@@ -870,7 +872,7 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, voi
 int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, hipStream_t st) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
-  const size_t smem = size_t(D) * 10 + 16 * 4 + 64;
+  const size_t smem = sel_shared_bytes(int(D));
   static bool attr_set = false;
   if (smem > 48 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chan_select),
@@ -970,7 +972,7 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 int launch_select(int dt, const float* total, const float* scales_f32, int64_t F, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   hipStream_t st) {
-  const size_t smem = size_t(N) * 10 + 16 * 4 + 64;
+  const size_t smem = sel_shared_bytes(int(N));
   ProfScope ps_(KID_SELECT, st);
   VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F)), dim3(kFrameNT), smem, st, total,
                                          scales_f32, int(F), int(N), map_mode, int(grid_h), N, cap, ks, offs,
@@ -1280,6 +1282,17 @@ int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, i
   }
   return n;
 }
+
+#ifdef VC2_DEBUG_TIMING
+int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(vc2::g_dbg_n), sizeof(int));
+  (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(vc2::g_dbg_t), sizeof(unsigned long long) * 512);
+  (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(vc2::g_dbg_v), sizeof(int) * 512);
+  if (reset) { int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(vc2::g_dbg_n), &z, sizeof(int)); }
+  return 0;
+}
+#endif
 
 int vc2_host_topk_order(const float* v, int64_t n, int64_t k, int sorted, int64_t* idx) {
   if (!v || !idx || n < 0 || k < 0 || k > n) return fail(VC2_ERR_ARG, "bad topk arguments");

@@ -23,22 +23,41 @@
 
 namespace vc2 {
 
+#ifdef VC2_DEBUG_TIMING
+__device__ unsigned long long g_dbg_t[512];
+__device__ int g_dbg_v[512];
+__device__ int g_dbg_n;
+struct DbgLds { unsigned long long t[96]; int v[96]; int n; int pad[3]; };
+__device__ __forceinline__ DbgLds* dbg_lds() { __shared__ DbgLds d; return &d; }
+__device__ __forceinline__ void dbg_stamp(int tag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    DbgLds* d = dbg_lds();
+    if (tag == 1) d->n = 0;
+    const int i = d->n;
+    if (i < 96) { d->t[i] = __builtin_readcyclecounter(); d->v[i] = tag; d->n = i + 1; }
+    if (tag == 9) { for (int j = 0; j < d->n; ++j) { g_dbg_t[j] = d->t[j]; g_dbg_v[j] = d->v[j]; } g_dbg_n = d->n; }
+  }
+}
+#else
+__device__ __forceinline__ void dbg_stamp(int) {}
+#endif
+
 struct SelShared {
   uint32_t* key;   // [n] total-order key (topk_key)
   uint16_t* idx;   // [n] original index
   uint16_t* la;    // [n] left-stop positions, ascending
   uint16_t* lb;    // [n] right-stop positions, descending
-  uint32_t* wtot;  // [16] per-wave scan totals
+  uint32_t* wtot;  // [32] per-wave scan totals / valid-pair counts
 };
 
-__device__ __forceinline__ size_t sel_shared_bytes(int n) {
-  return size_t(n) * (4 + 2 + 2 + 2) + 16 * 4 + 64;
+__host__ __device__ inline size_t sel_shared_bytes(int n) {
+  return size_t(n) * (4 + 2 + 2 + 2) + 32 * 4 + 64;
 }
 __device__ __forceinline__ SelShared sel_carve(unsigned char* smem, int n) {
   SelShared S;
   S.key = reinterpret_cast<uint32_t*>(smem);
   S.wtot = S.key + n;
-  S.idx = reinterpret_cast<uint16_t*>(S.wtot + 16);
+  S.idx = reinterpret_cast<uint16_t*>(S.wtot + 32);
   S.la = S.idx + n;
   S.lb = S.la + n;
   return S;
@@ -224,11 +243,303 @@ __device__ bool introselect_rounds(const SelShared& S, int& lo, int& hi, int& de
   return false;
 }
 
-// std::nth_element(first, first + nth, first + n) on the (key, idx) array in LDS.  The first rounds
-// (long ranges) use all NT threads of the workgroup; once the range is <= kWaveTail elements wave 0
-// finishes alone, wave-synchronously (no workgroup barriers).  All NT threads must call this.
-constexpr int kWaveTail = 1024;
+// ---- register-resident partition rounds for ONE wave --------------------------------------
+// The generic rounds above pay ~10 dependent LDS round trips per round.  For ranges of at most
+// 64*EM elements a single wave can hold the whole range in registers (slot e of lane l is position
+// first + e*64 + l), derive every rank from wave ballots (no scan through LDS), and needs only three
+// LDS round trips per round: (1) load keys + pivot candidates, (2) look up the swap partner by rank,
+// (3) read the cut.  The permutation produced is identical to the serial libstdc++ loop (see the
+// pairing argument at the top of this file).
+template <int EM>
+__device__ bool introselect_rounds_wave_reg(const SelShared& S, int& lo, int& hi, int& depth, int nth, int lane) {
+  while (hi - lo > 3) {
+    if (depth == 0) {
+      if (lane == 0) { sel_heap_select(S, lo, nth + 1, hi); sel_swap(S, lo, nth); }
+      sel_sync<64>();
+      return true;
+    }
+    --depth;
+    dbg_stamp(2000000 + (hi - lo));
+    const int first = lo + 1, len = hi - first;
+    const int E = (len + 63) >> 6;
+    const int pa = lo + 1, pb = lo + (hi - lo) / 2, pc = hi - 1;
+    // ---- trip 1: pivot candidates + this lane's elements
+    const uint32_t klo = S.key[lo], ka = S.key[pa], kb = S.key[pb], kc = S.key[pc];
+    const uint32_t ilo = S.idx[lo], ia = S.idx[pa], ib = S.idx[pb], ic = S.idx[pc];
+    uint32_t k[EM], ix[EM];
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      k[e] = 0; ix[e] = 0;
+      if (e < E) {
+        const int p = first + e * 64 + lane;
+        if (p < hi) { k[e] = S.key[p]; ix[e] = S.idx[p]; }
+      }
+    }
+    // __move_median_to_first(lo, pa, pb, pc): which candidate is the median
+    int msrc;
+    uint32_t pk, ipk;
+    if (ka < kb) {
+      if (kb < kc) { msrc = pb; pk = kb; ipk = ib; } else if (ka < kc) { msrc = pc; pk = kc; ipk = ic; }
+      else { msrc = pa; pk = ka; ipk = ia; }
+    } else if (ka < kc) { msrc = pa; pk = ka; ipk = ia; }
+    else if (kb < kc) { msrc = pc; pk = kc; ipk = ic; }
+    else { msrc = pb; pk = kb; ipk = ib; }
+    {   // iter_swap(lo, msrc): LDS by lane 0, register copy by the lane that holds msrc
+      if (lane == 0) {
+        S.key[lo] = pk; S.idx[lo] = uint16_t(ipk);
+        S.key[msrc] = klo; S.idx[msrc] = uint16_t(ilo);
+      }
+      const int d = msrc - first, e0 = d >> 6, l0 = d & 63;
+#pragma unroll
+      for (int e = 0; e < EM; ++e)
+        if (e == e0 && lane == l0) { k[e] = klo; ix[e] = ilo; }
+    }
+    // ---- pass 1: ranks from ballots, scatter stop positions (la: from the left; lb: B numbered from the left)
+    int baseA = 0, baseB = 0;
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      if (e < E) {
+        const int p = first + e * 64 + lane;
+        const bool in = p < hi;
+        const bool A = in && k[e] >= pk, B = in && k[e] <= pk;
+        const unsigned long long bA = __ballot(A), bB = __ballot(B);
+        const int rA = baseA + __builtin_amdgcn_mbcnt_hi(uint32_t(bA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bA), 0));
+        const int rB = baseB + __builtin_amdgcn_mbcnt_hi(uint32_t(bB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bB), 0));
+        if (A) S.la[rA] = uint16_t(p);
+        if (B) S.lb[rB] = uint16_t(p);
+        baseA += __popcll(bA);
+        baseB += __popcll(bB);
+      }
+    }
+    const int totA = baseA, totB = baseB;
+    sel_sync<64>();
+    // ---- pass 2 (trip 2): partner by rank, validity (la[i] < lb[i]), the swaps themselves
+    int m = 0;
+    baseA = 0; baseB = 0;
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      if (e < E) {
+        const int p = first + e * 64 + lane;
+        const bool in = p < hi;
+        const bool A = in && k[e] >= pk, B = in && k[e] <= pk;
+        const unsigned long long bA = __ballot(A), bB = __ballot(B);
+        const int rA = baseA + __builtin_amdgcn_mbcnt_hi(uint32_t(bA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bA), 0));
+        const int rBl = baseB + __builtin_amdgcn_mbcnt_hi(uint32_t(bB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bB), 0));
+        const int rB = totB - 1 - rBl;                        // B rank counted from the right
+        int dest = -1;
+        bool vA = false;
+        if (A && rA < totB) { const int q = S.lb[totB - 1 - rA]; vA = q > p; if (vA) dest = q; }
+        if (B && !vA && rB < totA) { const int q = S.la[rB]; if (q < p) dest = q; }
+        m += __popcll(__ballot(vA));
+        if (dest >= 0) { S.key[dest] = k[e]; S.idx[dest] = uint16_t(ix[e]); }
+        baseA += __popcll(bA);
+        baseB += __popcll(bB);
+      }
+    }
+    // ---- trip 3: the cut
+    int cut;
+    if (m == 0) {
+      cut = totA > 0 ? int(S.la[0]) : hi;
+    } else {
+      const int a = m < totA ? int(S.la[m]) : hi;
+      cut = min(a, int(S.lb[totB - m]));                      // lb (from the right) [m-1] = lbL[totB-1-(m-1)]
+    }
+    sel_sync<64>();
+    if (cut <= nth) lo = cut; else hi = cut;
+  }
+  return false;
+}
 
+// ---- register-resident partition rounds for a whole workgroup ------------------------------
+// For ranges of up to NT*EM elements: wave w owns a contiguous sub-range (slot e of lane l is position
+// wb + e*64 + l), in-wave ranks come from ballots, cross-wave bases from one exchange of per-wave
+// totals.  Three workgroup barriers per round.
+template <int NT, int EM>
+__device__ bool introselect_rounds_block_reg(const SelShared& S, int& lo, int& hi, int& depth, int nth,
+                                             int stop_len, int tid) {
+  constexpr int NW = NT / 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  while (hi - lo > 3 && hi - lo > stop_len) {
+    if (depth == 0) {
+      if (tid == 0) { sel_heap_select(S, lo, nth + 1, hi); sel_swap(S, lo, nth); }
+      __syncthreads();
+      return true;
+    }
+    --depth;
+    dbg_stamp(1000000 + (hi - lo));
+    const int first = lo + 1, len = hi - first;
+    const int L = (len + NW - 1) / NW;                     // positions per wave
+    const int E = (L + 63) >> 6;                           // slots per lane (<= EM by precondition)
+    const int wb = first + wave * L;
+    const int we = min(hi, wb + L);
+    const int pa = lo + 1, pb = lo + (hi - lo) / 2, pc = hi - 1;
+    // ---- trip 1
+    const uint32_t klo = S.key[lo], ka = S.key[pa], kb = S.key[pb], kc = S.key[pc];
+    const uint32_t ilo = S.idx[lo], ia = S.idx[pa], ib = S.idx[pb], ic = S.idx[pc];
+    uint32_t k[EM], ix[EM];
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      k[e] = 0; ix[e] = 0;
+      if (e < E) {
+        const int p = wb + e * 64 + lane;
+        if (p < we) { k[e] = S.key[p]; ix[e] = S.idx[p]; }
+      }
+    }
+    int msrc;
+    uint32_t pk, ipk;
+    if (ka < kb) {
+      if (kb < kc) { msrc = pb; pk = kb; ipk = ib; } else if (ka < kc) { msrc = pc; pk = kc; ipk = ic; }
+      else { msrc = pa; pk = ka; ipk = ia; }
+    } else if (ka < kc) { msrc = pa; pk = ka; ipk = ia; }
+    else if (kb < kc) { msrc = pc; pk = kc; ipk = ic; }
+    else { msrc = pb; pk = kb; ipk = ib; }
+    {
+      const int d = msrc - first, wm = d / L, off = d - wm * L, e0 = off >> 6, l0 = off & 63;
+#pragma unroll
+      for (int e = 0; e < EM; ++e)
+        if (wave == wm && e == e0 && lane == l0) { k[e] = klo; ix[e] = ilo; }
+    }
+    // ---- in-wave ranks, per-wave totals
+    int rA[EM], rB[EM];
+    int cA = 0, cB = 0;
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      rA[e] = 0; rB[e] = 0;
+      if (e < E) {
+        const int p = wb + e * 64 + lane;
+        const bool in = p < we;
+        const bool A = in && k[e] >= pk, B = in && k[e] <= pk;
+        const unsigned long long bA = __ballot(A), bB = __ballot(B);
+        rA[e] = cA + __builtin_amdgcn_mbcnt_hi(uint32_t(bA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bA), 0));
+        rB[e] = cB + __builtin_amdgcn_mbcnt_hi(uint32_t(bB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bB), 0));
+        cA += __popcll(bA);
+        cB += __popcll(bB);
+      }
+    }
+    if (lane == 0) S.wtot[wave] = uint32_t(cA) | (uint32_t(cB) << 16);
+    __syncthreads();                                        // also orders every trip-1 read before the swaps
+    if (tid == 0) {                                         // iter_swap(lo, msrc)
+      S.key[lo] = pk; S.idx[lo] = uint16_t(ipk);
+      S.key[msrc] = klo; S.idx[msrc] = uint16_t(ilo);
+    }
+    int baseA = 0, baseB = 0, totA = 0, totB = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t t = S.wtot[w];
+      if (w < wave) { baseA += int(t & 0xFFFFu); baseB += int(t >> 16); }
+      totA += int(t & 0xFFFFu);
+      totB += int(t >> 16);
+    }
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      if (e < E) {
+        const int p = wb + e * 64 + lane;
+        const bool in = p < we;
+        if (in && k[e] >= pk) S.la[baseA + rA[e]] = uint16_t(p);
+        if (in && k[e] <= pk) S.lb[baseB + rB[e]] = uint16_t(p);     // B numbered from the left
+      }
+    }
+    __syncthreads();
+    // ---- partners, validity, swaps
+    int cV = 0;
+#pragma unroll
+    for (int e = 0; e < EM; ++e) {
+      if (e < E) {
+        const int p = wb + e * 64 + lane;
+        const bool in = p < we;
+        const bool A = in && k[e] >= pk, B = in && k[e] <= pk;
+        const int ra = baseA + rA[e];
+        const int rb = totB - 1 - (baseB + rB[e]);              // B rank counted from the right
+        int dest = -1;
+        bool vA = false;
+        if (A && ra < totB) { const int q = S.lb[totB - 1 - ra]; vA = q > p; if (vA) dest = q; }
+        if (B && !vA && rb < totA) { const int q = S.la[rb]; if (q < p) dest = q; }
+        cV += __popcll(__ballot(vA));
+        if (dest >= 0) { S.key[dest] = k[e]; S.idx[dest] = uint16_t(ix[e]); }
+      }
+    }
+    if (lane == 0) S.wtot[16 + wave] = uint32_t(cV);
+    __syncthreads();
+    int m = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m += int(S.wtot[16 + w]);
+    int cut;
+    if (m == 0) {
+      cut = totA > 0 ? int(S.la[0]) : hi;
+    } else {
+      const int a = m < totA ? int(S.la[m]) : hi;
+      cut = min(a, int(S.lb[totB - m]));
+    }
+    __syncthreads();
+    if (cut <= nth) lo = cut; else hi = cut;
+  }
+  return false;
+}
+
+// Same round for longer ranges (up to 65535 elements): nothing is cached in registers, the two
+// passes stream the range from LDS 64 positions at a time (ranks still come from wave ballots).
+__device__ inline bool introselect_rounds_wave_stream(const SelShared& S, int& lo, int& hi, int& depth, int nth,
+                                                      int stop_len, int lane) {
+  while (hi - lo > 3 && hi - lo > stop_len) {
+    if (depth == 0) {
+      if (lane == 0) { sel_heap_select(S, lo, nth + 1, hi); sel_swap(S, lo, nth); }
+      sel_sync<64>();
+      return true;
+    }
+    --depth;
+    dbg_stamp(3000000 + (hi - lo));
+    const int first = lo + 1, len = hi - first;
+    const int E = (len + 63) >> 6;
+    if (lane == 0) sel_median_to_first(S, lo, lo + 1, lo + (hi - lo) / 2, hi - 1);
+    sel_sync<64>();
+    const uint32_t pk = S.key[lo];
+    int baseA = 0, baseB = 0;
+#pragma unroll 4
+    for (int e = 0; e < E; ++e) {
+      const int p = first + e * 64 + lane;
+      const bool in = p < hi;
+      const uint32_t kk = in ? S.key[p] : 0u;
+      const bool A = in && kk >= pk, B = in && kk <= pk;
+      const unsigned long long bA = __ballot(A), bB = __ballot(B);
+      const int rA = baseA + __builtin_amdgcn_mbcnt_hi(uint32_t(bA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bA), 0));
+      const int rB = baseB + __builtin_amdgcn_mbcnt_hi(uint32_t(bB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bB), 0));
+      if (A) S.la[rA] = uint16_t(p);
+      if (B) S.lb[rB] = uint16_t(p);
+      baseA += __popcll(bA);
+      baseB += __popcll(bB);
+    }
+    const int totA = baseA, totB = baseB;
+    sel_sync<64>();
+    // number of swapped pairs: la[i] < lb_right[i] is a prefix property -> count it in parallel
+    int m = 0;
+    {
+      const int np = min(totA, totB);
+      for (int i0 = 0; i0 < np; i0 += 64) {
+        const int i = i0 + lane;
+        const bool v = i < np && S.la[i] < S.lb[totB - 1 - i];
+        const unsigned long long b = __ballot(v);
+        m += __popcll(b);
+        if (b != ~0ull) break;
+      }
+    }
+    int cut;
+    if (m == 0) {
+      cut = totA > 0 ? int(S.la[0]) : hi;
+    } else {
+      const int a = m < totA ? int(S.la[m]) : hi;
+      cut = min(a, int(S.lb[totB - m]));
+    }
+    for (int i = lane; i < m; i += 64) sel_swap(S, S.la[i], S.lb[totB - 1 - i]);
+    sel_sync<64>();
+    if (cut <= nth) lo = cut; else hi = cut;
+  }
+  return false;
+}
+
+// std::nth_element(first, first + nth, first + n) on the (key, idx) array in LDS.  Long ranges
+// (> 4096) start with workgroup-parallel rounds; then wave 0 finishes alone: streaming rounds down to
+// 512 elements, register-resident rounds below.
+// All NT threads of the workgroup must call this.
 template <int NT>
 __device__ void introselect_block(const SelShared& S, int n, int nth) {
   if (n == 0 || nth >= n) return;
@@ -237,13 +548,18 @@ __device__ void introselect_block(const SelShared& S, int n, int nth) {
   int depth = 2 * (31 - __clz(n));                       // std::__lg(n) * 2
   bool done = false;
   if constexpr (NT > 64) {
-    done = introselect_rounds<NT>(S, lo, hi, depth, nth, kWaveTail, tid);
+    static_assert(NT <= 1024, "per-wave totals live in 16 slots");
+    done = introselect_rounds<NT>(S, lo, hi, depth, nth, NT * 4, tid);          // only for n > NT*4
+    if (!done) done = introselect_rounds_block_reg<NT, 4>(S, lo, hi, depth, nth, 512, tid);
   }
   if (!done && tid < 64) {
-    done = introselect_rounds<64>(S, lo, hi, depth, nth, 3, tid);
+    done = introselect_rounds_wave_stream(S, lo, hi, depth, nth, 512, tid);
+    if (!done) done = introselect_rounds_wave_reg<8>(S, lo, hi, depth, nth, tid);
+    dbg_stamp(4000000 + (hi - lo));
     if (!done && tid == 0) sel_insertion_sort(S, lo, hi);
   }
   sel_sync<NT>();
+  dbg_stamp(5000000);
 }
 
 // torch.topk(v, k, largest=False) SET: afterwards positions [0, k) of (key, idx) hold the kept
