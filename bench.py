@@ -61,6 +61,23 @@ def kernel_alg_bytes(name, F, N, D, es, K):
     }.get(name)
 
 
+def pmc_traffic(kernel, workload, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command, gfx950 FETCH_SIZE x2
+    correction applied as MI355X_MICROARCH.md prescribes).  None if no profile matches this workload."""
+    import glob
+    if world != 1:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload", "").startswith(workload + ":") and kernel in d.get("kernels", {}):
+            return d["kernels"][kernel]["hbm_bytes"]
+    return None
+
+
 def time_steps(fn, steps, dist_on):
     torch.cuda.synchronize()
     if dist_on:
@@ -109,13 +126,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get("VC2_BENCH_FORCE_DIST") == "1"   # (the override exercises the
+    #                                 sharded code path on one GPU; used by the single-GPU smoke run only)
     if args.gpus != world and rank == 0 and dist_on:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group("nccl", device_id=dev)
 
     import vidcom2_amd as vc
@@ -185,7 +206,7 @@ def main():
         ab = kernel_alg_bytes(dom, F, N, D, es, K)
         ach = ab / (sweeps[dom] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload, world),
                 "alg_bytes_per_launch": ab, "avg_us": sweeps[dom]}
 
     out = {

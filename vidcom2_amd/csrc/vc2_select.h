@@ -494,7 +494,6 @@ __device__ inline bool introselect_rounds_wave_stream(const SelShared& S, int& l
     sel_sync<64>();
     const uint32_t pk = S.key[lo];
     int baseA = 0, baseB = 0;
-#pragma unroll 4
     for (int e = 0; e < E; ++e) {
       const int p = first + e * 64 + lane;
       const bool in = p < hi;
