@@ -63,10 +63,12 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
 
 /* vidcom2.py:41-42  torch.topk(var, k, largest=False): the SET of the k selected channels, with ties
  * at the k-th value broken exactly like the CPU reference (libstdc++ introselect; SURVEY.md
- * Appendix A).  var_f32 = widened T values.  Outputs (either may be NULL): byte mask mask[D]
- * (1 = selected) and the ascending channel list cols[k] the scoring sweeps consume. */
+ * Appendix A).  var_f32 = widened T values.  Outputs (each may be NULL): byte mask mask[D]
+ * (1 = selected); the ascending channel list cols[k] the scoring sweeps consume; order[k] = the channels
+ * in torch.topk(sorted=True)'s OWN order (ascending variance, libstdc++ sort tie order -- the column
+ * order of `x[:, topk_idx]`, vidcom2.py:43) and opos[k] = position of order[p] inside cols. */
 int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
-                    void* stream);
+                    int32_t* order, int32_t* opos, void* stream);
 
 /* vidcom2.py:43  x[:, idx] column gather -> out T[R, C]; idx int64[C] on device. */
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C,

@@ -22,7 +22,7 @@ __all__ = [
     "build", "chan_var", "topk_smallest", "select_low_var_channel_idx", "select_low_var_channels",
     "compute_gaussian_scores", "gaussian_debug", "fuse", "compute_scales", "compute_ks",
     "select_outlier_indices", "map_linear_offset", "map_grid_vid", "compress_indices",
-    "vidcom2_compression", "set_num_threads", "exp_T", "gaussian_scores_sharded",
+    "vidcom2_compression", "set_num_threads", "exp_T", "gaussian_scores_sharded", "set_mode",
 ]
 
 
@@ -39,6 +39,12 @@ def _L():
         build()
         _lib = ctypes.CDLL(_LIB_PATH)
     return _lib
+
+
+def set_mode(mode: str) -> None:
+    """'exact' (default): reductions accumulated exactly; 'torch': replay torch's CPU fp32 accumulation
+    order for the L2 norm and the row sums (bit-exact to the reference in half precision)."""
+    _L().vc2o_set_mode({"exact": 0, "torch": 1}[mode])
 
 
 def set_num_threads(n: int) -> None:

@@ -130,6 +130,77 @@ void topk_smallest(const float* v, int64_t n, int64_t k, bool sorted, int64_t* i
   for (int64_t j = 0; j < k; ++j) idx_out[j] = q[Z(j)].second;
 }
 
+// ---------------------------------------------------------------- torch accumulation orders
+// Mode 1 ("torch order") replays the fp32 accumulation ORDER of the two reductions whose rounding noise
+// can flip a half-precision result (measured with the imported reference, tests/golden/make_golden.py):
+//   * L2 norm over the last dim (ReduceOpsKernel.cpp norm_kernel_tensor_iterator_impl): fp32/bf16 use
+//     8 interleaved fp32 FMA chains (element p goes to chain p % 8), chains then added 0..7, tail after;
+//     fp16 takes the generic path: one sequential fp32 chain.
+//   * sum over the last dim (SumKernel.cpp cascade_sum): 8 fp32 lanes x 4 interleaved vectors, 4 cascade
+//     levels; half types first add the two 8-element halves of each 16-element chunk.
+// Mode 0 ("exact", default) accumulates in double: the correctly rounded result.
+int g_mode = 0;
+
+inline int ceil_log2_i64(int64_t x) { int r = 0; while ((int64_t(1) << r) < x) ++r; return r; }
+
+float norm_torch_order(const float* v, int64_t n, int dt) {
+  if (dt == F16) {
+    float s = 0.f;
+    for (int64_t i = 0; i < n; ++i) s = s + v[i] * v[i];         // products of fp16 values are exact in fp32
+    return std::sqrt(s);
+  }
+  const int64_t step = (dt == F32) ? 8 : 16;                     // Vec<T>::size(); fp32 lanes = 8
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t d = 0;
+  for (; d + step <= n; d += step)
+    for (int64_t h = 0; h < step; h += 8)
+      for (int j = 0; j < 8; ++j) acc[j] = std::fmaf(v[d + h + j], v[d + h + j], acc[j]);
+  float s = acc[0];
+  for (int j = 1; j < 8; ++j) s = s + acc[j];
+  for (; d < n; ++d) s = std::fmaf(v[d], v[d], s);
+  return std::sqrt(s);
+}
+
+float sum_torch_order(const float* v, int64_t n, int dt) {
+  constexpr int W = 8, ILP = 4, LEVELS = 4;
+  const int64_t chunk = (dt == F32) ? 8 : 16;
+  const int64_t vec_size = n / chunk;
+  auto load = [&](int64_t c, float* out) {
+    const float* p = v + c * chunk;
+    if (dt == F32) { for (int j = 0; j < W; ++j) out[j] = p[j]; }
+    else { for (int j = 0; j < W; ++j) out[j] = p[j] + p[W + j]; }
+  };
+  const int64_t size_ilp = vec_size / ILP;
+  const int64_t level_power = std::max<int64_t>(4, ceil_log2_i64(size_ilp) / LEVELS);
+  const int64_t level_step = int64_t(1) << level_power, level_mask = level_step - 1;
+  float acc[LEVELS][ILP][W];
+  std::memset(acc, 0, sizeof(acc));
+  float t[W];
+  int64_t i = 0;
+  for (; i + level_step <= size_ilp;) {
+    for (int64_t j = 0; j < level_step; ++j, ++i)
+      for (int k = 0; k < ILP; ++k) { load(i * ILP + k, t); for (int l = 0; l < W; ++l) acc[0][k][l] += t[l]; }
+    for (int j = 1; j < LEVELS; ++j) {
+      for (int k = 0; k < ILP; ++k)
+        for (int l = 0; l < W; ++l) { acc[j][k][l] += acc[j - 1][k][l]; acc[j - 1][k][l] = 0.f; }
+      const int64_t mask = level_mask << (j * level_power);
+      if ((i & mask) != 0) break;
+    }
+  }
+  for (; i < size_ilp; ++i)
+    for (int k = 0; k < ILP; ++k) { load(i * ILP + k, t); for (int l = 0; l < W; ++l) acc[0][k][l] += t[l]; }
+  for (int j = 1; j < LEVELS; ++j)
+    for (int k = 0; k < ILP; ++k)
+      for (int l = 0; l < W; ++l) acc[0][k][l] += acc[j][k][l];
+  for (int64_t c = size_ilp * ILP; c < vec_size; ++c) { load(c, t); for (int l = 0; l < W; ++l) acc[0][0][l] += t[l]; }
+  for (int k = 1; k < ILP; ++k)
+    for (int l = 0; l < W; ++l) acc[0][0][l] += acc[0][k][l];
+  float fin = 0.f;
+  for (int64_t k = vec_size * chunk; k < n; ++k) fin += v[k];
+  for (int l = 0; l < W; ++l) fin += acc[0][0][l];
+  return fin;
+}
+
 // torch mean for every dtype on CPU: fp32 sum -> fp32 div by count -> cast
 // (ATen/native/ReduceOps.cpp mean_out: "cast_fp32 -> sum -> div -> cast").
 inline float mean_T(double exact_sum, int64_t count, int dt) {
@@ -140,6 +211,9 @@ inline float mean_T(double exact_sum, int64_t count, int dt) {
 }  // namespace
 
 extern "C" {
+
+// 0 = exact accumulation (default), 1 = torch's CPU accumulation order for the L2 norm and the row sums
+int vc2o_set_mode(int mode) { g_mode = mode; return 0; }
 
 // vidcom2.py:40  variances = x.var(dim=0, unbiased=False)  -> T[D]
 int vc2o_chan_var(const void* x, int64_t R, int64_t D, int dt, void* var_out) {
@@ -197,12 +271,19 @@ int vc2o_gaussian_scores_ex(const void* x, int64_t R, int64_t D, int dt, const i
   std::vector<float> nrm(Z(R));
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < R; ++r) {
-    double n2 = 0.0;
-    for (int64_t j = 0; j < C; ++j) {
-      double v = double(load_T(x, r * D + idx[j], dt));
-      n2 += v * v;
+    float norm;
+    if (g_mode == 1) {
+      std::vector<float> row(Z(C));
+      for (int64_t j = 0; j < C; ++j) row[Z(j)] = load_T(x, r * D + idx[j], dt);
+      norm = rT(norm_torch_order(row.data(), C, dt), dt);
+    } else {
+      double n2 = 0.0;
+      for (int64_t j = 0; j < C; ++j) {
+        double v = double(load_T(x, r * D + idx[j], dt));
+        n2 += v * v;
+      }
+      norm = rTd(std::sqrt(n2), dt);
     }
-    float norm = rTd(std::sqrt(n2), dt);
     float den = rT(std::max(norm, 1e-12f), dt);      // clamp_min(eps) computed in fp32 -> T
     if (std::isnan(norm)) den = norm;
     nrm[Z(r)] = norm;
@@ -237,15 +318,30 @@ int vc2o_gaussian_scores_ex(const void* x, int64_t R, int64_t D, int dt, const i
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < R; ++r) {
     const int64_t f = r / N;
-    double sv = 0.0, sf = 0.0;
-    for (int64_t j = 0; j < C; ++j) {
-      float xv = xh[Z(r * C + j)];
-      float a = rT(xv - vc[Z(j)], dt);
-      float b = rT(xv - fc[Z(f * C + j)], dt);
-      sv += double(rT(a * a, dt));
-      sf += double(rT(b * b, dt));
+    float dist[2];
+    if (g_mode == 1) {
+      std::vector<float> qa(Z(C)), qb(Z(C));
+      for (int64_t j = 0; j < C; ++j) {
+        float xv = xh[Z(r * C + j)];
+        float a = rT(xv - vc[Z(j)], dt);
+        float b = rT(xv - fc[Z(f * C + j)], dt);
+        qa[Z(j)] = rT(a * a, dt);
+        qb[Z(j)] = rT(b * b, dt);
+      }
+      dist[0] = rT(sum_torch_order(qa.data(), C, dt), dt);
+      dist[1] = rT(sum_torch_order(qb.data(), C, dt), dt);
+    } else {
+      double sv = 0.0, sf = 0.0;
+      for (int64_t j = 0; j < C; ++j) {
+        float xv = xh[Z(r * C + j)];
+        float a = rT(xv - vc[Z(j)], dt);
+        float b = rT(xv - fc[Z(f * C + j)], dt);
+        sv += double(rT(a * a, dt));
+        sf += double(rT(b * b, dt));
+      }
+      dist[0] = rTd(sv, dt);
+      dist[1] = rTd(sf, dt);
     }
-    float dist[2] = {rTd(sv, dt), rTd(sf, dt)};
     float score[2];
     for (int w = 0; w < 2; ++w) {
       float acc = 0.0f;

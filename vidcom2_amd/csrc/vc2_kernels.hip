@@ -188,7 +188,8 @@ __global__ void k_var_from_stats(const double* __restrict__ stats, const int64_t
 constexpr int kSelNT = 1024;
 
 __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
-                                                        uint8_t* __restrict__ mask, int* __restrict__ cols) {
+                                                        uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                        int* __restrict__ order, int* __restrict__ opos) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelShared S = sel_carve(smem, D);
   const int tid = threadIdx.x;
@@ -198,13 +199,30 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
     S.idx[i] = uint16_t(i);
   }
   __syncthreads();
-  topk_smallest_block<kSelNT>(S, D, k);
+  const bool partial = int64_t(k) * 64 <= int64_t(D);
+  if (k >= D && order) introselect_block<kSelNT>(S, D, D - 1);       // nth_element(n-1) still permutes
+  else topk_smallest_block<kSelNT>(S, D, k);
   __syncthreads();
+  if (order) {
+    // torch.topk(sorted=True) ORDER (vidcom2.py:42 returns it; the reference's reductions run in it)
+    if (partial) {
+      if (tid == 0) sel_sort_heap(S, 0, k);                           // partial_sort = heap_select + sort_heap
+      __syncthreads();
+      for (int p = tid; p < k; p += kSelNT) order[p] = int(S.idx[p]);
+    } else {
+      SortScratch Q = sort_carve(smem + (sel_shared_bytes(D) + 15) / 16 * 16, D);
+      introsort_block<kSelNT>(S, Q, k - 1, order);                    // std::sort(q, q + k - 1)
+      if (tid == 0) order[k - 1] = int(S.idx[k - 1]);                 // the nth_element pivot stays last
+    }
+    __syncthreads();
+  }
   // kept flags (reuse la), mask bytes, and the ascending list of kept channels (ordered compaction)
   for (int i = tid; i < D; i += kSelNT) S.la[i] = (k >= D) ? 1 : 0;
   __syncthreads();
-  if (k < D)
-    for (int i = tid; i < k; i += kSelNT) S.la[S.idx[i]] = 1;
+  if (k < D) {
+    if (order) { for (int i = tid; i < k; i += kSelNT) S.la[order[i]] = 1; }
+    else { for (int i = tid; i < k; i += kSelNT) S.la[S.idx[i]] = 1; }
+  }
   __syncthreads();
   const int E = (D + kSelNT - 1) / kSelNT;
   const int b = tid * E, e = min(D, b + E);
@@ -216,8 +234,11 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   for (int p = b; p < e; ++p) {
     const bool on = S.la[p] != 0;
     if (mask) mask[p] = on ? 1 : 0;
-    if (on) { if (cols) cols[o] = p; ++o; }
+    if (on) { if (cols) cols[o] = p; S.lb[p] = uint16_t(o); ++o; }     // lb: channel -> compact position
   }
+  __syncthreads();
+  if (order && opos)
+    for (int p = tid; p < k; p += kSelNT) opos[p] = int(S.lb[order[p]]);
   dbg_stamp(9);
 }
 
@@ -891,10 +912,11 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, voi
   return check_launch("chan_stats");
 }
 
-int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, hipStream_t st) {
+int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* order, int* opos,
+                       hipStream_t st) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
-  const size_t smem = sel_shared_bytes(int(D));
+  const size_t smem = (sel_shared_bytes(int(D)) + 15) / 16 * 16 + (order ? sort_scratch_bytes(int(D)) : 0);
   static bool attr_set = false;
   if (smem > 48 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chan_select),
@@ -903,7 +925,8 @@ int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask
     attr_set = true;
   }
   { ProfScope ps_(KID_CHAN_SELECT, st);
-  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols); }
+  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, order,
+                     opos); }
   return check_launch("chan_select");
 }
 
@@ -1077,10 +1100,11 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
   return launch_chan_stats(p, x, ws, nullptr, var_T, vf, static_cast<hipStream_t>(stream));
 }
 
-int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, void* stream) {
-  if (!var_f32 || (!mask && !cols)) return fail(VC2_ERR_ARG, "null pointer");
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, int32_t* order,
+                    int32_t* opos, void* stream) {
+  if (!var_f32 || (!mask && !cols && !order)) return fail(VC2_ERR_ARG, "null pointer");
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
-  return launch_chan_select(var_f32, D, k, mask, cols, static_cast<hipStream_t>(stream));
+  return launch_chan_select(var_f32, D, k, mask, cols, order, opos, static_cast<hipStream_t>(stream));
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -1226,7 +1250,7 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   int* cols = wsp<int>(ws, p.o_cols);
   if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st))) return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, st))) return rc;
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, nullptr, nullptr, st))) return rc;
   if ((rc = launch_phase1(p, x, cols, int(kc), ws, true, st))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* s = wsp<float>(ws, p.o_s);

@@ -476,8 +476,59 @@ __device__ bool introselect_rounds_block_reg(const SelShared& S, int& lo, int& h
   return false;
 }
 
-// Same round for longer ranges (up to 65535 elements): nothing is cached in registers, the two
-// passes stream the range from LDS 64 positions at a time (ranks still come from wave ballots).
+// One libstdc++ __unguarded_partition_pivot(lo, hi) executed by ONE wave on [lo, hi) (hi - lo > 3):
+// median-of-3 to lo, then the Hoare partition of [lo+1, hi).  Nothing is cached in registers -- the two
+// passes stream the range from LDS 64 positions at a time and ranks come from wave ballots.  The la/lb
+// scratch is addressed inside [lo, hi) only, so several waves may partition DISJOINT ranges at once.
+// Returns the cut (identical on every lane).
+__device__ inline int wave_partition(const SelShared& S, int lo, int hi, int lane) {
+  const int first = lo + 1, len = hi - first;
+  const int E = (len + 63) >> 6;
+  if (lane == 0) sel_median_to_first(S, lo, lo + 1, lo + (hi - lo) / 2, hi - 1);
+  sel_sync<64>();
+  const uint32_t pk = S.key[lo];
+  uint16_t* la = S.la + first;
+  uint16_t* lb = S.lb + first;
+  int baseA = 0, baseB = 0;
+  for (int e = 0; e < E; ++e) {
+    const int p = first + e * 64 + lane;
+    const bool in = p < hi;
+    const uint32_t kk = in ? S.key[p] : 0u;
+    const bool A = in && kk >= pk, B = in && kk <= pk;
+    const unsigned long long bA = __ballot(A), bB = __ballot(B);
+    const int rA = baseA + __builtin_amdgcn_mbcnt_hi(uint32_t(bA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bA), 0));
+    const int rB = baseB + __builtin_amdgcn_mbcnt_hi(uint32_t(bB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bB), 0));
+    if (A) la[rA] = uint16_t(p);
+    if (B) lb[rB] = uint16_t(p);                       // B numbered from the left
+    baseA += __popcll(bA);
+    baseB += __popcll(bB);
+  }
+  const int totA = baseA, totB = baseB;
+  sel_sync<64>();
+  // number of swapped pairs: la[i] < lb_right[i] is a prefix property -> count it in parallel
+  int m = 0;
+  {
+    const int np = min(totA, totB);
+    for (int i0 = 0; i0 < np; i0 += 64) {
+      const int i = i0 + lane;
+      const bool v = i < np && la[i] < lb[totB - 1 - i];
+      const unsigned long long b = __ballot(v);
+      m += __popcll(b);
+      if (b != ~0ull) break;
+    }
+  }
+  int cut;
+  if (m == 0) {
+    cut = totA > 0 ? int(la[0]) : hi;
+  } else {
+    const int a = m < totA ? int(la[m]) : hi;
+    cut = min(a, int(lb[totB - m]));
+  }
+  for (int i = lane; i < m; i += 64) sel_swap(S, la[i], lb[totB - 1 - i]);
+  sel_sync<64>();
+  return cut;
+}
+
 __device__ inline bool introselect_rounds_wave_stream(const SelShared& S, int& lo, int& hi, int& depth, int nth,
                                                       int stop_len, int lane) {
   while (hi - lo > 3 && hi - lo > stop_len) {
@@ -488,48 +539,7 @@ __device__ inline bool introselect_rounds_wave_stream(const SelShared& S, int& l
     }
     --depth;
     dbg_stamp(3000000 + (hi - lo));
-    const int first = lo + 1, len = hi - first;
-    const int E = (len + 63) >> 6;
-    if (lane == 0) sel_median_to_first(S, lo, lo + 1, lo + (hi - lo) / 2, hi - 1);
-    sel_sync<64>();
-    const uint32_t pk = S.key[lo];
-    int baseA = 0, baseB = 0;
-    for (int e = 0; e < E; ++e) {
-      const int p = first + e * 64 + lane;
-      const bool in = p < hi;
-      const uint32_t kk = in ? S.key[p] : 0u;
-      const bool A = in && kk >= pk, B = in && kk <= pk;
-      const unsigned long long bA = __ballot(A), bB = __ballot(B);
-      const int rA = baseA + __builtin_amdgcn_mbcnt_hi(uint32_t(bA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bA), 0));
-      const int rB = baseB + __builtin_amdgcn_mbcnt_hi(uint32_t(bB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bB), 0));
-      if (A) S.la[rA] = uint16_t(p);
-      if (B) S.lb[rB] = uint16_t(p);
-      baseA += __popcll(bA);
-      baseB += __popcll(bB);
-    }
-    const int totA = baseA, totB = baseB;
-    sel_sync<64>();
-    // number of swapped pairs: la[i] < lb_right[i] is a prefix property -> count it in parallel
-    int m = 0;
-    {
-      const int np = min(totA, totB);
-      for (int i0 = 0; i0 < np; i0 += 64) {
-        const int i = i0 + lane;
-        const bool v = i < np && S.la[i] < S.lb[totB - 1 - i];
-        const unsigned long long b = __ballot(v);
-        m += __popcll(b);
-        if (b != ~0ull) break;
-      }
-    }
-    int cut;
-    if (m == 0) {
-      cut = totA > 0 ? int(S.la[0]) : hi;
-    } else {
-      const int a = m < totA ? int(S.la[m]) : hi;
-      cut = min(a, int(S.lb[totB - m]));
-    }
-    for (int i = lane; i < m; i += 64) sel_swap(S, S.la[i], S.lb[totB - 1 - i]);
-    sel_sync<64>();
+    const int cut = wave_partition(S, lo, hi, lane);
     if (cut <= nth) lo = cut; else hi = cut;
   }
   return false;
@@ -572,6 +582,103 @@ __device__ void topk_smallest_block(const SelShared& S, int n, int k) {
   } else {
     introselect_block<NT>(S, n, k - 1);
   }
+}
+
+// bits/stl_heap.h __sort_heap(first, last) on a heap (serial)
+__device__ inline void sel_sort_heap(const SelShared& S, int first, int last) {
+  while (last - first > 1) {
+    --last;
+    const uint32_t vk = S.key[last];
+    const uint16_t vi = S.idx[last];
+    sel_move(S, last, first);
+    sel_adjust_heap(S, first, 0, last - first, vk, vi);
+  }
+}
+
+// ---- std::sort(first, first + n) replay (the `sorted=True` half of torch.topk, TopKImpl.h) ------------
+// __introsort_loop: every segment longer than 16 is partitioned (same __unguarded_partition_pivot as
+// above) and both halves recurse with depth_limit-1; at depth 0 a segment is heap-sorted instead.
+// Segments of one recursion level are independent, so the workgroup processes the tree level by level,
+// one wave per segment.  __final_insertion_sort then equals a STABLE sort inside every leaf segment
+// (elements never cross a cut: everything left of a cut is <= everything right of it and the insertion
+// uses a strict compare), done here by rank counting.  out_order[p] = original index at sorted position p.
+struct SortScratch {
+  uint32_t* segA;   // [kMaxSeg] packed (first | last << 13 | depth << 26)
+  uint32_t* segB;
+  int* cnt;         // [2]
+  uint8_t* bnd;     // [n] 1 = a leaf starts here
+};
+constexpr int kMaxSeg = 1024;
+__host__ __device__ inline size_t sort_scratch_bytes(int n) { return size_t(kMaxSeg) * 8 + 16 + size_t(n) + 16; }
+__device__ __forceinline__ SortScratch sort_carve(unsigned char* p, int n) {
+  SortScratch Q;
+  Q.segA = reinterpret_cast<uint32_t*>(p);
+  Q.segB = Q.segA + kMaxSeg;
+  Q.cnt = reinterpret_cast<int*>(Q.segB + kMaxSeg);
+  Q.bnd = reinterpret_cast<uint8_t*>(Q.cnt + 4);
+  (void)n;
+  return Q;
+}
+
+template <int NT>
+__device__ void introsort_block(const SelShared& S, const SortScratch& Q, int n, int* __restrict__ out_order) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NT / 64;
+  for (int p = tid; p < n; p += NT) Q.bnd[p] = (p == 0) ? 1 : 0;
+  if (tid == 0) {
+    Q.cnt[0] = 0; Q.cnt[1] = 0;
+    if (n > 16) { Q.segA[0] = uint32_t(0) | (uint32_t(n) << 13) | (uint32_t(2 * (31 - __clz(n))) << 26); Q.cnt[0] = 1; }
+  }
+  __syncthreads();
+  uint32_t* cur = Q.segA;
+  uint32_t* nxt = Q.segB;
+  int ci = 0;
+  while (true) {
+    const int ns = Q.cnt[ci];
+    if (ns == 0) break;
+    for (int si = wave; si < ns; si += NW) {
+      const uint32_t sg = cur[si];
+      const int first = int(sg & 0x1FFFu), last = int((sg >> 13) & 0x1FFFu), depth = int(sg >> 26);
+      if (depth == 0) {                                   // __partial_sort(first, last, last): heapsort
+        if (lane == 0) { sel_heap_select(S, first, last, last); sel_sort_heap(S, first, last); }
+        for (int p = first + lane; p < last; p += 64) Q.bnd[p] = 1;      // already final: one leaf per element
+        sel_sync<64>();
+      } else {
+        const int cut = wave_partition(S, first, last, lane);
+        if (lane == 0) {
+          Q.bnd[cut] = 1;
+          if (cut - first > 16) {
+            const int j = atomicAdd(&Q.cnt[ci ^ 1], 1);
+            nxt[j] = uint32_t(first) | (uint32_t(cut) << 13) | (uint32_t(depth - 1) << 26);
+          }
+          if (last - cut > 16) {
+            const int j = atomicAdd(&Q.cnt[ci ^ 1], 1);
+            nxt[j] = uint32_t(cut) | (uint32_t(last) << 13) | (uint32_t(depth - 1) << 26);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) Q.cnt[ci] = 0;
+    ci ^= 1;
+    uint32_t* t = cur; cur = nxt; nxt = t;
+    __syncthreads();
+  }
+  // stable sort inside each leaf == __final_insertion_sort
+  for (int p = tid; p < n; p += NT) {
+    int ls = p;
+    while (!Q.bnd[ls]) --ls;
+    int le = p + 1;
+    while (le < n && !Q.bnd[le]) ++le;
+    const uint32_t kp = S.key[p];
+    int r = ls;
+    for (int q = ls; q < le; ++q) {
+      const uint32_t kq = S.key[q];
+      r += (kq < kp || (kq == kp && q < p)) ? 1 : 0;
+    }
+    out_order[r] = int(S.idx[p]);
+  }
+  __syncthreads();
 }
 
 }  // namespace vc2

@@ -74,7 +74,7 @@ class HipStages:
         P = stats_all.shape[0]
         check(lib().vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, ptr(self.var_f32),
                                             self._st()), "vc2_chan_var_from_stats")
-        check(lib().vc2_chan_select(ptr(self.var_f32), self.D, self.C, ptr(self.mask), ptr(self.cols), self._st()),
+        check(lib().vc2_chan_select(ptr(self.var_f32), self.D, self.C, ptr(self.mask), ptr(self.cols), None, None, self._st()),
               "vc2_chan_select")
 
     def phase1(self, x):

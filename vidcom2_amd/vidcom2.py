@@ -163,17 +163,17 @@ def _channel_variance(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def low_var_channel_order(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
     """Indices torch.topk(var, int(D*ratio), largest=False) returns on the CPU reference, in ITS order
-    (ascending variance, libstdc++ tie order).  The D variances are computed on the device; the
-    ordering of those D scalars is replayed with the same libstdc++ algorithms on the host."""
+    (ascending variance, libstdc++ nth_element + sort tie order), replayed on the device
+    (k_chan_select: workgroup-parallel introselect + introsort)."""
     x = _prep(x, "x")
     D = x.shape[-1]
     k = int(D * ratio)
     _, var_f = _channel_variance(x)
-    host = var_f.cpu()
-    out = torch.empty(k, dtype=torch.int64)
-    check(lib().vc2_host_topk_order(ctypes.c_void_p(host.data_ptr()), D, k, 1, ctypes.c_void_p(out.data_ptr())),
-          "vc2_host_topk_order")
-    return out.to(x.device)
+    order = torch.empty(max(k, 1), dtype=torch.int32, device=x.device)
+    if k > 0:
+        check(lib().vc2_chan_select(ptr(var_f), D, k, None, None, ptr(order), None, stream_ptr(x.device)),
+              "vc2_chan_select")
+    return order[:k].to(torch.int64)
 
 
 def select_low_var_channels(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
