@@ -46,6 +46,16 @@ extern "C" {
 const char* vc2_last_error(void);
 const char* vc2_version(void);
 
+/* Accumulation semantics of the two fp32-accumulated reductions of the reference (token L2 norm,
+ * squared-distance sums) in half precision:
+ *   1 (default)  "torch order": wherever the exactly computed value lies within 128 fp32-ulps of a T rounding
+ *                boundary, torch's own CPU accumulation order (8 interleaved fp32 chains over the variance-sorted
+ *                channels / cascade sum) is replayed for that token -> bit-exact to the CPU reference;
+ *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
+ * fp32 inputs are unaffected.  Process-wide. */
+int vc2_set_mode(int mode);
+int vc2_get_mode(void);
+
 /* Workspace (bytes) needed by any entry point below for an [F*N, D] input. */
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes);
 
@@ -75,12 +85,13 @@ int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_
                     void* out, void* stream);
 
 /* vidcom2.py:45-62  compute_gaussian_scores over the C channels listed (ascending) in cols[C]
- * (cols NULL = all channels, C == D, i.e. x already holds the selected features).  Sweeps 2 and 3 of X.
+ * (cols NULL = all channels, C == D, i.e. x already holds the selected features, already in torch.topk
+ * order).  order/opos = vc2_chan_select's outputs (needed for mode 1 when cols != NULL).  Sweeps 2 and 3 of X.
  * Outputs: v_T, f_T  T[F,N] (may be NULL), total_f32 fp32-widened RN_T(v+f) [F,N] (vidcom2.py:33),
  * s_f32[F] = -mean(v, -1) widened (vidcom2.py:32). */
 int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-               int64_t C, void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32,
-               float* s_f32, void* stream);
+               int64_t C, const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes,
+               void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream);
 
 /* vidcom2.py:64-68  compute_scales(scores, base, temp) on T[F] -> scales T[F]. */
 int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws,
@@ -131,9 +142,11 @@ int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, siz
 int vc2_chan_var_from_stats(const double* stats /*[P][2][D]*/, int64_t P, int64_t R_total, int64_t D,
                             int dtype, void* var_T, float* var_f32, void* stream);
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-                      int64_t C, void* ws, size_t ws_bytes, double* csum /*[C]*/, void* stream);
+                      int64_t C, const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes,
+                      double* csum /*[C]*/, void* stream);
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-                      int64_t C, const double* csum_all /*[P][csum_stride]*/, int64_t P,
+                      int64_t C, const int32_t* order, const int32_t* opos,
+                      const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
                       void* f_T, float* total_f32, float* s_f32, void* stream);
 

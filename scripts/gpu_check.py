@@ -49,6 +49,9 @@ def run_case(F, N, D, dt, seed, dist, base):
 
 def main():
     big = "--big" in sys.argv
+    mode = "exact" if "--exact" in sys.argv else "torch"
+    O.set_mode(mode); _ffi.set_mode(mode)
+    print("mode:", mode, flush=True)
     cases = []
     for dt in (torch.float32, torch.bfloat16, torch.float16):
         for shp in [(4, 49, 64, .25), (8, 196, 1024, .25), (3, 50, 72, .3), (16, 169, 3584, .15), (32, 196, 3584, .25)]:

@@ -30,7 +30,7 @@ _SIGNATURES = {
     "vc2_chan_var": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp, _vp],
     "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
     "vc2_gather_cols": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
-    "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "vc2_compute_scales": [_vp, _i64, _dbl, _dbl, _i32, _vp, _sz, _vp, _vp],
     "vc2_select": [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _sz, _vp, _vp, _vp, _i64, _vp, _vp],
     "vc2_map_indices": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
@@ -39,14 +39,16 @@ _SIGNATURES = {
                      _vp, _vp, _vp, _vp],
     "vc2_chan_stats": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp],
     "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
-    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _sz, _vp, _vp],
-    "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp,
-                          _vp],
+    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp, _vp],
+    "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp,
+                          _vp, _vp, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
                            _vp, _vp],
     "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
     "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
     "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],
+    "vc2_set_mode": [_i32],
+    "vc2_get_mode": [],
     "vc2_profile_enable": [_i32],
     "vc2_profile_collect": [_i32, _vp, _vp, _vp],
     "vc2_last_error": [],
@@ -131,3 +133,13 @@ def profile_collect() -> dict:
     cnt = (ctypes.c_int64 * n)()
     got = lib().vc2_profile_collect(n, names, ms, cnt)
     return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(got) if cnt[i]}
+
+
+def set_mode(mode: str) -> None:
+    """'torch' (default): bit-exact to the CPU reference in half precision (replays torch's fp32 accumulation
+    order where it decides a rounding); 'exact': every reduction correctly rounded."""
+    check(lib().vc2_set_mode({"exact": 0, "torch": 1}[mode]), "vc2_set_mode")
+
+
+def get_mode() -> str:
+    return "torch" if lib().vc2_get_mode() else "exact"

@@ -326,12 +326,114 @@ __device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, i
   }
 }
 
+// ---- strict mode: torch's own fp32 accumulation order for the tokens where it matters -----------------
+// The reference's CPU kernels accumulate ||x||^2 and the squared-distance sums in fp32, in an order fixed
+// by torch's 8-lane vector code over the variance-SORTED channel order (order[p]; ReduceOpsKernel.cpp
+// norm_kernel_tensor_iterator_impl, SumKernel.cpp cascade_sum; pinned in oracle/vc2_oracle.cpp mode 1).
+// Their fp32 noise (<~1e-6 relative) changes the T-rounded result only when the exact value sits that
+// close to a T rounding boundary.  So: compute exactly (fp64), and only when the exact value is within
+// kFragileUlps fp32-ulps of a boundary replay torch's order for that token -- a few tokens per thousand.
+constexpr int kFragileUlpsNorm = 128;   // >= worst-case bound of the 8-chain FMA norm (232 * 2^-24 on the sum)
+constexpr int kFragileUlpsDist = 48;    // >= worst-case bound of the cascade sum (~42 fp32 adds per lane)
+
+template <int DT> __device__ __forceinline__ bool near_T_boundary(float y, int margin) {
+  if constexpr (DT == VC2_F32) {
+    return false;
+  } else {
+    constexpr int DROP = (DT == VC2_BF16) ? 16 : 13;            // fp32 mantissa bits the cast drops
+    const uint32_t bits = __float_as_uint(y);
+    if (DT == VC2_F16 && (bits & 0x7F800000u) < (113u << 23)) return true;   // fp16-subnormal result: be safe
+    const int low = int(bits & ((1u << DROP) - 1u));
+    const int d = low - (1 << (DROP - 1));
+    return (d < 0 ? -d : d) <= margin;
+  }
+}
+
+// sqrt(sum x^2) over the sorted channel order exactly as torch accumulates it (whole wave; same result on all lanes)
+template <int DT>
+__device__ float norm_torch_order(const unsigned char* rowbuf, const uint16_t* order, int C, int lane) {
+  float s = 0.f;
+  if constexpr (DT == VC2_F16) {                                // generic path: ONE sequential fp32 chain
+    if (lane == 0) {
+      for (int p = 0; p < C; ++p) {
+        const float v = lds_elem<DT>(rowbuf, order[p]);
+        s = s + v * v;                                          // fp16 x fp16 is exact in fp32
+      }
+    }
+    s = __shfl(s, 0, 64);
+  } else {                                                      // 8 interleaved FMA chains, then lanes 0..7, then the tail
+    constexpr int CH = (DT == VC2_F32) ? 8 : 16;
+    const int nv = (C / CH) * CH;
+    float acc = 0.f;
+    if (lane < 8)
+      for (int p = lane; p < nv; p += 8) {
+        const float v = lds_elem<DT>(rowbuf, order[p]);
+        acc = fmaf(v, v, acc);
+      }
+    s = __shfl(acc, 0, 64);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) s = s + __shfl(acc, j, 64);
+    for (int p = nv; p < C; ++p) {
+      const float v = lds_elem<DT>(rowbuf, order[p]);
+      s = fmaf(v, v, s);
+    }
+  }
+  return float(sqrt(double(s)));     // correctly rounded fp32 sqrt (53 >= 2*24+2 bits: no double rounding)
+}
+
+// sum_p RN_T(RN_T(x^_p - c_p)^2) over the sorted channel order exactly as torch's cascade_sum adds it
+// (8 lanes x 4 interleaved vectors, 4 cascade levels, halves of each 16-element chunk added first).
+template <int DT>
+__device__ float dist_torch_order(const unsigned char* rowbuf, const uint16_t* order, const uint16_t* opos,
+                                  const float* __restrict__ cen, double inv, int C, int lane) {
+  auto sq = [&](int p) -> float {
+    const float v = lds_elem<DT>(rowbuf, order[p]);
+    const float xh = rnT<DT>(div_via_f64(v, inv));
+    const float a = rnT<DT>(xh - cen[opos[p]]);
+    return rnT<DT>(a * a);
+  };
+  constexpr int CH = (DT == VC2_F32) ? 8 : 16;
+  const int l = lane & 7, k = (lane >> 3) & 3;
+  auto load = [&](int c) -> float {
+    if constexpr (DT == VC2_F32) return sq(CH * c + l);
+    else return sq(CH * c + l) + sq(CH * c + 8 + l);
+  };
+  const int vec_size = C / CH, size_ilp = vec_size / 4;
+  int lg = 0;
+  while ((1 << lg) < size_ilp) ++lg;
+  const int level_power = max(4, lg / 4);
+  const int level_step = 1 << level_power, level_mask = level_step - 1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = 0;
+  for (; i + level_step <= size_ilp;) {
+    for (int j = 0; j < level_step; ++j, ++i) a0 += load(i * 4 + k);
+    a1 += a0; a0 = 0.f;
+    if ((i & (level_mask << level_power)) == 0) {
+      a2 += a1; a1 = 0.f;
+      if ((i & (level_mask << (2 * level_power))) == 0) { a3 += a2; a2 = 0.f; }
+    }
+  }
+  for (; i < size_ilp; ++i) a0 += load(i * 4 + k);
+  a0 += a1; a0 += a2; a0 += a3;
+  for (int c = size_ilp * 4; c < vec_size; ++c) { const float t = load(c); if (k == 0) a0 += t; }
+  {
+    const float t1 = __shfl(a0, l + 8, 64), t2 = __shfl(a0, l + 16, 64), t3 = __shfl(a0, l + 24, 64);
+    a0 += t1; a0 += t2; a0 += t3;                                // meaningful on lanes 0..7
+  }
+  float fin = 0.f;
+  for (int p = vec_size * CH; p < C; ++p) fin += sq(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) fin += __shfl(a0, j, 64);
+  return fin;
+}
+
 // sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and the
 // per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels (compact order).
 // NPLB = compile-time bound on compact positions per lane (ceil(C/64) <= NPLB).
 template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
-                                                                int C, const int* __restrict__ cols, int S,
+                                                                int C, const int* __restrict__ cols,
+                                                                const int* __restrict__ order, int strict, int S,
                                                                 int rows_per_split, float* __restrict__ den_out,
                                                                 double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -346,6 +448,11 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   if (lane < 4) {                                                // zero pad element of both buffers
     reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
     reinterpret_cast<uint32_t*>(buf1 + rowb - 16)[lane] = 0u;
+  }
+  uint16_t* ordL = reinterpret_cast<uint16_t*>(smem + size_t(2 * kRowWaves) * rowb);   // [C] (strict mode only)
+  if (strict) {
+    for (int p = tid; p < C; p += kRowWaves * 64) ordL[p] = uint16_t(order ? order[p] : p);
+    __syncthreads();
   }
   int coff[NPLB];
   load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
@@ -366,7 +473,9 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
       t = fma(double(xv[i]), double(xv[i]), t);
     }
     const double n2 = wave_sum_bcast(t);
-    const float norm = rnT<DT>(float(sqrt(n2)));
+    const float nrm32 = float(sqrt(n2));
+    float norm = rnT<DT>(nrm32);
+    if (strict && (strict >= 2 || near_T_boundary<DT>(nrm32, kFragileUlpsNorm))) norm = rnT<DT>(norm_torch_order<DT>(buf0, ordL, C, lane));
     // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
     float dn = rnT<DT>(fmaxf(norm, 1e-12f));
     if (norm != norm) dn = norm;
@@ -454,8 +563,10 @@ template <int DT> __device__ __forceinline__ void rnT2(float a, float b, float& 
 // positions live in registers for the whole workgroup; the row loop touches LDS only for the row itself.
 template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
-                                                         const int* __restrict__ cols, int S, int rows_per_split,
-                                                         const float* __restrict__ den,
+                                                         const int* __restrict__ cols,
+                                                         const int* __restrict__ order,
+                                                         const int* __restrict__ opos, int strict, int S,
+                                                         int rows_per_split, const float* __restrict__ den,
                                                          const float* __restrict__ vc,
                                                          const float* __restrict__ fc,
                                                          float* __restrict__ dv_out, float* __restrict__ df_out) {
@@ -471,6 +582,14 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]
   float* dens = reinterpret_cast<float*>(smem + size_t(kRowWaves) * rowb);   // [rows_per_split]
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+  uint16_t* ordL = reinterpret_cast<uint16_t*>(dens + ((rows_per_split + 3) & ~3));   // [C] + [C] (strict mode only)
+  uint16_t* oposL = ordL + C;
+  if (strict) {
+    for (int p = tid; p < C; p += kRowWaves * 64) {
+      ordL[p] = uint16_t(order ? order[p] : p);
+      oposL[p] = uint16_t(opos ? opos[p] : p);
+    }
+  }
   for (int r = n0 + tid; r < n1; r += kRowWaves * 64) dens[r - n0] = den[int64_t(f) * N + r];
   int coff[NPLB];
   float cv[NPLB], cf[NPLB];
@@ -501,9 +620,14 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     }
     pv = wave_sum_bcast(pv);
     pf = wave_sum_bcast(pf);
+    float dvv = float(pv), dff = float(pf);
+    if (strict) {
+      if (strict >= 2 || near_T_boundary<DT>(dvv, kFragileUlpsDist)) dvv = dist_torch_order<DT>(buf0, ordL, oposL, vc, inv, C, lane);
+      if (strict >= 2 || near_T_boundary<DT>(dff, kFragileUlpsDist)) dff = dist_torch_order<DT>(buf0, ordL, oposL, fc + int64_t(f) * C, inv, C, lane);
+    }
     if (lane == 0) {
-      dv_out[row] = rnT<DT>(float(pv));
-      df_out[row] = rnT<DT>(float(pf));
+      dv_out[row] = rnT<DT>(dvv);
+      df_out[row] = rnT<DT>(dff);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // LDS reads done before the buffer is refilled
   }
@@ -798,7 +922,7 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups
   int S, rows_per_split;        // sweep-2/3 splits per frame
   // workspace offsets (bytes)
-  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
+  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
       o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_tmp_f32, total_bytes;
 };
 
@@ -830,6 +954,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_var_T = take(size_t(D) * 4);
   p->o_mask = take(size_t(D));
   p->o_cols = take(size_t(D) * 4);
+  p->o_order = take(size_t(D) * 4);
+  p->o_opos = take(size_t(D) * 4);
   p->o_den = take(size_t(p->R) * 4);
   p->o_part_col = take(size_t(F) * p->S * D * 8);
   p->o_fc = take(size_t(F) * D * 4);
@@ -939,28 +1065,51 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what)
   return VC2_OK;
 }
 
+// 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
+// result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
+int g_strict = 1;
+
+// the scored channels: ascending list (nullptr = all D), the same channels in torch.topk's order and their
+// positions in `cols` (both nullptr = identity when cols is nullptr, else strict mode is unavailable)
+struct ChanSet {
+  const int* cols;
+  const int* order;
+  const int* opos;
+  int C;
+  int strict;
+};
+inline ChanSet make_chanset(const Plan& p, const int* cols, const int* order, const int* opos, int64_t C) {
+  ChanSet cs{cols, order, opos, int(C), 0};
+  cs.strict = (g_strict && p.ES == 2 && (cols == nullptr || (order && opos))) ? g_strict : 0;   // 2 = replay always
+  return cs;
+}
+
 template <int DT, int VEC, int NPLB>
-int launch_norm_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
-  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES);
+int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+  const int* cols = cs.cols; const int C = cs.C;
+  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + (cs.strict ? size_t(C) * 2 + 16 : 0);
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB>, smem, "k_norm_colsum");
   if (rc) return rc;
   hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
-                     int(p.N), int(p.D), p.CV, C, cols, p.S, p.rows_per_split, wsp<float>(ws, p.o_den),
-                     wsp<double>(ws, p.o_part_col));
+                     int(p.N), int(p.D), p.CV, C, cols, cs.order, cs.strict, p.S, p.rows_per_split,
+                     wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col));
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
-int launch_dist_t(const Plan& p, const void* x, const int* cols, int C, void* ws, hipStream_t st) {
+int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+  const int* cols = cs.cols; const int C = cs.C;
   // one workgroup per (frame, split): ~32 rows each, at least ~768 workgroups when the video allows
   int64_t rps = std::max<int64_t>(16, std::min<int64_t>(64, cdiv(p.R, 768)));
   rps = std::min<int64_t>(rps, p.N);
   const int S2 = int(cdiv(p.N, rps));
   rps = cdiv(p.N, S2);
-  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 16;
+  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 32 +
+                      (cs.strict ? size_t(C) * 4 + 16 : 0);
   int rc = allow_big_lds(&k_dist<DT, VEC, NPLB>, smem, "k_dist");
   if (rc) return rc;
   hipLaunchKernelGGL((k_dist<DT, VEC, NPLB>), dim3(unsigned(p.F * S2)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
-                     int(p.D), p.CV, C, cols, S2, int(rps), wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
+                     int(p.D), p.CV, C, cols, cs.order, cs.opos, cs.strict, S2, int(rps), wsp<float>(ws, p.o_den),
+                     wsp<float>(ws, p.o_vc),
                      wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df));
   return VC2_OK;
 }
@@ -972,14 +1121,15 @@ int launch_dist_t(const Plan& p, const void* x, const int* cols, int C, void* ws
    : fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels"))
 
 // sweep 2 + centres.  single_rank: also the video centre; else only the rank's csum (for the all-gather).
-int launch_phase1(const Plan& p, const void* x, const int* cols, int C, void* ws, bool single_rank, hipStream_t st) {
+int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, bool single_rank, hipStream_t st) {
+  const int C = cs.C;
   double* part = wsp<double>(ws, p.o_part_col);
   double* cpart = wsp<double>(ws, p.o_csum_part);
   const int FG = int(cdiv(p.F, kCentreFL));
   { ProfScope ps_(KID_NORM_COLSUM, st);
   int rc = VC2_OK;
   const int npl = int(cdiv(C, 64));
-  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cols, C, ws, st));
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, st));
   if (rc) return rc; }
   { ProfScope ps_(KID_CENTRES, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
@@ -994,12 +1144,13 @@ int launch_phase1(const Plan& p, const void* x, const int* cols, int C, void* ws
 }
 
 // budget_base >= 0: the epilogue's last workgroup also computes the scales (single-GPU fused pass).
-int launch_phase2(const Plan& p, const void* x, const int* cols, int C, void* ws, void* v_T, void* f_T,
+int launch_phase2(const Plan& p, const void* x, const ChanSet& cs, void* ws, void* v_T, void* f_T,
                   float* total, float* s, hipStream_t st, double budget_base = -1.0) {
+  const int C = cs.C;
   { ProfScope ps_(KID_DIST, st);
   int rc = VC2_OK;
   const int npl = int(cdiv(C, 64));
-  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cols, C, ws, st));
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cs, ws, st));
   if (rc) return rc; }
   { ProfScope ps_(KID_EPILOGUE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
@@ -1049,6 +1200,13 @@ extern "C" {
 
 const char* vc2_last_error(void) { return g_err; }
 const char* vc2_version(void) { return "vidcom2_amd 0.1 (gfx950)"; }
+
+int vc2_set_mode(int mode) {
+  if (mode < 0 || mode > 3) return fail(VC2_ERR_ARG, "mode must be 0 (exact) or 1 (torch order)");   // 2, 3: debug
+  g_strict = mode;
+  return VC2_OK;
+}
+int vc2_get_mode(void) { return g_strict; }
 
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
   if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
@@ -1132,7 +1290,8 @@ static int check_cols(const int32_t* cols, int64_t C, int64_t D) {
 }
 
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      void* ws, size_t ws_bytes, double* csum, void* stream) {
+                      const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes, double* csum,
+                      void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
@@ -1140,7 +1299,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  rc = launch_phase1(p, x, cols, int(C), ws, /*single_rank=*/false, st);
+  rc = launch_phase1(p, x, make_chanset(p, cols, order, opos, C), ws, /*single_rank=*/false, st);
   if (rc) return rc;
   if (csum) {
     hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
@@ -1150,7 +1309,8 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
 }
 
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      const double* csum_all, int64_t P, int64_t csum_stride, int64_t R_total, void* ws,
+                      const int32_t* order, const int32_t* opos, const double* csum_all, int64_t P,
+                      int64_t csum_stride, int64_t R_total, void* ws,
                       size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
   if (!x || !csum_all || P <= 0 || csum_stride < C) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
@@ -1164,11 +1324,12 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
                                             wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket)));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
-  return launch_phase2(p, x, cols, int(C), ws, v_T, f_T, total, s, st);
+  return launch_phase2(p, x, make_chanset(p, cols, order, opos, C), ws, v_T, f_T, total, s, st);
 }
 
-int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C, void* ws,
-               size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
+int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
+               const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes, void* v_T, void* f_T,
+               float* total_f32, float* s_f32, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
@@ -1176,10 +1337,11 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if ((rc = launch_phase1(p, x, cols, int(C), ws, /*single_rank=*/true, st))) return rc;
+  const ChanSet cs = make_chanset(p, cols, order, opos, C);
+  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
-  return launch_phase2(p, x, cols, int(C), ws, v_T, f_T, total, s, st);
+  return launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st);
 }
 
 int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws, size_t ws_bytes,
@@ -1250,11 +1412,15 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   int* cols = wsp<int>(ws, p.o_cols);
   if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st))) return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, nullptr, nullptr, st))) return rc;
-  if ((rc = launch_phase1(p, x, cols, int(kc), ws, true, st))) return rc;
+  const bool strict = g_strict && p.ES == 2;
+  int* order = strict ? wsp<int>(ws, p.o_order) : nullptr;
+  int* opos = strict ? wsp<int>(ws, p.o_opos) : nullptr;
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, order, opos, st))) return rc;
+  const ChanSet cs = make_chanset(p, cols, order, opos, kc);
+  if ((rc = launch_phase1(p, x, cs, ws, true, st))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* s = wsp<float>(ws, p.o_s);
-  if ((rc = launch_phase2(p, x, cols, int(kc), ws, v_T, f_T, total, s, st, base_scale < 0 ? 0.0 : base_scale)))
+  if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st, base_scale < 0 ? 0.0 : base_scale)))
     return rc;
   float* scales = wsp<float>(ws, p.o_scales_f32);
   if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,

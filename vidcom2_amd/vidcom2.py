@@ -202,8 +202,8 @@ def compute_gaussian_scores(x: torch.Tensor, tpf: int) -> Tuple[torch.Tensor, to
     ws = _ffi.workspace(F, tpf, C, x.dtype, x.device)
     v = torch.empty((F, tpf), dtype=x.dtype, device=x.device)
     f = torch.empty((F, tpf), dtype=x.dtype, device=x.device)
-    check(lib().vc2_scores(ptr(x), F, tpf, C, DTYPE_CODE[x.dtype], None, C, ptr(ws), ws.numel(), ptr(v), ptr(f),
-                           None, None, stream_ptr(x.device)), "vc2_scores")
+    check(lib().vc2_scores(ptr(x), F, tpf, C, DTYPE_CODE[x.dtype], None, C, None, None, ptr(ws), ws.numel(), ptr(v),
+                           ptr(f), None, None, stream_ptr(x.device)), "vc2_scores")
     return v, f
 
 
