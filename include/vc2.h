@@ -76,9 +76,10 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
  * Appendix A).  var_f32 = widened T values.  Outputs (each may be NULL): byte mask mask[D]
  * (1 = selected); the ascending channel list cols[k] the scoring sweeps consume; order[k] = the channels
  * in torch.topk(sorted=True)'s OWN order (ascending variance, libstdc++ sort tie order -- the column
- * order of `x[:, topk_idx]`, vidcom2.py:43) and opos[k] = position of order[p] inside cols. */
+ * order of `x[:, topk_idx]`, vidcom2.py:43), opos[k] = position of order[p] inside cols, and its inverse
+ * spos[k] = position of cols[i] in that order (what the scoring sweeps need in mode 1). */
 int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
-                    int32_t* order, int32_t* opos, void* stream);
+                    int32_t* order, int32_t* opos, int32_t* spos, void* stream);
 
 /* vidcom2.py:43  x[:, idx] column gather -> out T[R, C]; idx int64[C] on device. */
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C,
@@ -86,12 +87,12 @@ int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_
 
 /* vidcom2.py:45-62  compute_gaussian_scores over the C channels listed (ascending) in cols[C]
  * (cols NULL = all channels, C == D, i.e. x already holds the selected features, already in torch.topk
- * order).  order/opos = vc2_chan_select's outputs (needed for mode 1 when cols != NULL).  Sweeps 2 and 3 of X.
+ * order).  spos = vc2_chan_select's output (needed for mode 1 when cols != NULL).  Sweeps 2 and 3 of X.
  * Outputs: v_T, f_T  T[F,N] (may be NULL), total_f32 fp32-widened RN_T(v+f) [F,N] (vidcom2.py:33),
  * s_f32[F] = -mean(v, -1) widened (vidcom2.py:32). */
 int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-               int64_t C, const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes,
-               void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream);
+               int64_t C, const int32_t* spos, void* ws, size_t ws_bytes, void* v_T, void* f_T,
+               float* total_f32, float* s_f32, void* stream);
 
 /* vidcom2.py:64-68  compute_scales(scores, base, temp) on T[F] -> scales T[F]. */
 int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int dtype, void* ws,
@@ -142,11 +143,10 @@ int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, siz
 int vc2_chan_var_from_stats(const double* stats /*[P][2][D]*/, int64_t P, int64_t R_total, int64_t D,
                             int dtype, void* var_T, float* var_f32, void* stream);
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-                      int64_t C, const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes,
-                      double* csum /*[C]*/, void* stream);
+                      int64_t C, const int32_t* spos, void* ws, size_t ws_bytes, double* csum /*[C]*/,
+                      void* stream);
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-                      int64_t C, const int32_t* order, const int32_t* opos,
-                      const double* csum_all /*[P][csum_stride]*/, int64_t P,
+                      int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
                       void* f_T, float* total_f32, float* s_f32, void* stream);
 

@@ -2,14 +2,15 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvc2hip_dbg.so"))
 dev = torch.device("cuda:0")
-for D, tie in [(3584, True), (3584, False), (1024, True)]:
+for D, tie in [(3584, True)]:
     v = torch.rand(D, device=dev)
     if tie: v = (v * 40).round() / 40
     mask = torch.empty(D, dtype=torch.uint8, device=dev); cols = torch.empty(D, dtype=torch.int32, device=dev)
+    order = torch.empty(D, dtype=torch.int32, device=dev); opos = torch.empty(D, dtype=torch.int32, device=dev); spos = torch.empty(D, dtype=torch.int32, device=dev)
     t = (ctypes.c_ulonglong * 512)(); vv = (ctypes.c_int * 512)(); n = ctypes.c_int(0)
     for rep in range(3):
         L.vc2_debug_read(t, vv, ctypes.byref(n), 1)
-        L.vc2_chan_select(ctypes.c_void_p(v.data_ptr()), ctypes.c_int64(D), ctypes.c_int64(D // 2), ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(cols.data_ptr()), ctypes.c_void_p(0))
+        L.vc2_chan_select(ctypes.c_void_p(v.data_ptr()), ctypes.c_int64(D), ctypes.c_int64(D // 2), ctypes.c_void_p(mask.data_ptr()), ctypes.c_void_p(cols.data_ptr()), ctypes.c_void_p(order.data_ptr()), ctypes.c_void_p(opos.data_ptr()), ctypes.c_void_p(spos.data_ptr()), ctypes.c_void_p(0))
         L.vc2_debug_read(t, vv, ctypes.byref(n), 0)
     print(f"D={D} ties={tie}: {n.value} stamps")
     for i in range(1, n.value):

@@ -130,15 +130,17 @@ def test_selection_kat(i):
     want_set = sorted(want.tolist())
     mask = torch.zeros(n, dtype=torch.uint8, device=dev())
     cols = torch.full((n,), -1, dtype=torch.int32, device=dev())
-    check(lib().vc2_chan_select(ptr(t), n, k, ptr(mask), ptr(cols), None, None, stream_ptr(dev())), "chan_select")
+    check(lib().vc2_chan_select(ptr(t), n, k, ptr(mask), ptr(cols), None, None, None, stream_ptr(dev())), "chan_select")
     assert mask.cpu().nonzero().flatten().tolist() == want_set
     assert cols[:k].cpu().tolist() == want_set and bool((cols[k:] == -1).all())
     if srt:     # torch.topk(sorted=True) ORDER, replayed on the device (introselect + introsort)
         order = torch.full((n,), -1, dtype=torch.int32, device=dev())
         opos = torch.full((n,), -1, dtype=torch.int32, device=dev())
-        check(lib().vc2_chan_select(ptr(t), n, k, None, ptr(cols), ptr(order), ptr(opos), stream_ptr(dev())), "chan_select")
+        spos = torch.full((n,), -1, dtype=torch.int32, device=dev())
+        check(lib().vc2_chan_select(ptr(t), n, k, None, ptr(cols), ptr(order), ptr(opos), ptr(spos), stream_ptr(dev())), "chan_select")
         assert order[:k].cpu().tolist() == want.tolist()
         assert cols[opos[:k].long()].cpu().tolist() == want.tolist()
+        assert order[spos[:k].long()].cpu().tolist() == cols[:k].cpu().tolist()
     # per-frame path: 3 identical frames with scale = k/n  ->  ks = k
     if n >= 17:
         F = 3

@@ -28,9 +28,9 @@ _SIGNATURES = {
     "vc2_workspace_bytes": [_i64, _i64, _i64, _i32, ctypes.POINTER(_sz)],
     "vc2_kept_capacity": [_i64, _i64, _dbl],
     "vc2_chan_var": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp, _vp],
-    "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp],
+    "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "vc2_gather_cols": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
-    "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
+    "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "vc2_compute_scales": [_vp, _i64, _dbl, _dbl, _i32, _vp, _sz, _vp, _vp],
     "vc2_select": [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _sz, _vp, _vp, _vp, _i64, _vp, _vp],
     "vc2_map_indices": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
@@ -39,8 +39,8 @@ _SIGNATURES = {
                      _vp, _vp, _vp, _vp],
     "vc2_chan_stats": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp],
     "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
-    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _sz, _vp, _vp],
-    "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp,
+    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp],
+    "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp,
                           _vp, _vp, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
                            _vp, _vp],

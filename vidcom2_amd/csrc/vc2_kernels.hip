@@ -125,8 +125,9 @@ template <int DT>
 __global__ __launch_bounds__(64 * kRedGL) void k_stats_reduce(const double* __restrict__ part, int G,
                                                               const void* __restrict__ x, int64_t R, int D,
                                                               double* __restrict__ stats, void* __restrict__ var_T,
-                                                              float* __restrict__ var_f32) {
+                                                              float* __restrict__ var_f32, int* __restrict__ counters) {
   __shared__ double sm[2][kRedGL][64];
+  if (counters && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;   // strict-mode queues of this pass
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s = 0.0, q = 0.0;
@@ -189,7 +190,8 @@ constexpr int kSelNT = 1024;
 
 __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
-                                                        int* __restrict__ order, int* __restrict__ opos) {
+                                                        int* __restrict__ order, int* __restrict__ opos,
+                                                        int* __restrict__ spos) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelShared S = sel_carve(smem, D);
   const int tid = threadIdx.x;
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
     if (on) { if (cols) cols[o] = p; S.lb[p] = uint16_t(o); ++o; }     // lb: channel -> compact position
   }
   __syncthreads();
-  if (order && opos)
-    for (int p = tid; p < k; p += kSelNT) opos[p] = int(S.lb[order[p]]);
+  if (order && opos)        // opos[p] = compact position of the channel at sorted position p; spos = its inverse
+    for (int p = tid; p < k; p += kSelNT) { const int cp = int(S.lb[order[p]]); opos[p] = cp; if (spos) spos[cp] = p; }
   dbg_stamp(9);
 }
 
@@ -333,6 +335,7 @@ __device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, i
 // Their fp32 noise (<~1e-6 relative) changes the T-rounded result only when the exact value sits that
 // close to a T rounding boundary.  So: compute exactly (fp64), and only when the exact value is within
 // kFragileUlps fp32-ulps of a boundary replay torch's order for that token -- a few tokens per thousand.
+constexpr int kMaxFix = 1 << 16;           // capacity of the sweep-3 strict-mode fix-up queue (entries)
 constexpr int kFragileUlpsNorm = 128;   // >= worst-case bound of the 8-chain FMA norm (232 * 2^-24 on the sum)
 constexpr int kFragileUlpsDist = 48;    // >= worst-case bound of the cascade sum (~42 fp32 adds per lane)
 
@@ -349,54 +352,57 @@ template <int DT> __device__ __forceinline__ bool near_T_boundary(float y, int m
   }
 }
 
-// sqrt(sum x^2) over the sorted channel order exactly as torch accumulates it (whole wave; same result on all lanes)
+// sqrt(sum x^2) over the sorted channel order exactly as torch accumulates it (whole wave; same result on
+// all lanes).  sv[p] = the row's selected values as fp32, ALREADY in sorted order (p = 0..C-1) in LDS.
 template <int DT>
-__device__ float norm_torch_order(const unsigned char* rowbuf, const uint16_t* order, int C, int lane) {
+__device__ float norm_torch_order(const float* sv, int C, int lane) {
   float s = 0.f;
   if constexpr (DT == VC2_F16) {                                // generic path: ONE sequential fp32 chain
     if (lane == 0) {
-      for (int p = 0; p < C; ++p) {
-        const float v = lds_elem<DT>(rowbuf, order[p]);
-        s = s + v * v;                                          // fp16 x fp16 is exact in fp32
+      int p = 0;
+      for (; p + 8 <= C; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sv[p + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = s + v[u] * v[u];        // fp16 x fp16 is exact in fp32
       }
+      for (; p < C; ++p) { const float v = sv[p]; s = s + v * v; }
     }
     s = __shfl(s, 0, 64);
   } else {                                                      // 8 interleaved FMA chains, then lanes 0..7, then the tail
     constexpr int CH = (DT == VC2_F32) ? 8 : 16;
     const int nv = (C / CH) * CH;
     float acc = 0.f;
-    if (lane < 8)
-      for (int p = lane; p < nv; p += 8) {
-        const float v = lds_elem<DT>(rowbuf, order[p]);
-        acc = fmaf(v, v, acc);
+    if (lane < 8) {
+      int p = lane;
+      for (; p + 56 < nv; p += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sv[p + 8 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(v[u], v[u], acc);
       }
+      for (; p < nv; p += 8) { const float v = sv[p]; acc = fmaf(v, v, acc); }
+    }
     s = __shfl(acc, 0, 64);
 #pragma unroll
     for (int j = 1; j < 8; ++j) s = s + __shfl(acc, j, 64);
-    for (int p = nv; p < C; ++p) {
-      const float v = lds_elem<DT>(rowbuf, order[p]);
-      s = fmaf(v, v, s);
-    }
+    for (int p = nv; p < C; ++p) { const float v = sv[p]; s = fmaf(v, v, s); }
   }
   return float(sqrt(double(s)));     // correctly rounded fp32 sqrt (53 >= 2*24+2 bits: no double rounding)
 }
 
-// sum_p RN_T(RN_T(x^_p - c_p)^2) over the sorted channel order exactly as torch's cascade_sum adds it
-// (8 lanes x 4 interleaved vectors, 4 cascade levels, halves of each 16-element chunk added first).
+// sum_p sq[p] over the sorted channel order exactly as torch's cascade_sum adds it (8 lanes x 4 interleaved
+// vectors, 4 cascade levels, halves of each 16-element chunk added first).  sq[p] = RN_T(RN_T(x^_p - c_p)^2)
+// as fp32, already in sorted order in LDS.
 template <int DT>
-__device__ float dist_torch_order(const unsigned char* rowbuf, const uint16_t* order, const uint16_t* opos,
-                                  const float* __restrict__ cen, double inv, int C, int lane) {
-  auto sq = [&](int p) -> float {
-    const float v = lds_elem<DT>(rowbuf, order[p]);
-    const float xh = rnT<DT>(div_via_f64(v, inv));
-    const float a = rnT<DT>(xh - cen[opos[p]]);
-    return rnT<DT>(a * a);
-  };
+__device__ float sum_torch_order(const float* sq, int C, int lane) {
   constexpr int CH = (DT == VC2_F32) ? 8 : 16;
   const int l = lane & 7, k = (lane >> 3) & 3;
   auto load = [&](int c) -> float {
-    if constexpr (DT == VC2_F32) return sq(CH * c + l);
-    else return sq(CH * c + l) + sq(CH * c + 8 + l);
+    if constexpr (DT == VC2_F32) return sq[CH * c + l];
+    else return sq[CH * c + l] + sq[CH * c + 8 + l];
   };
   const int vec_size = C / CH, size_ilp = vec_size / 4;
   int lg = 0;
@@ -406,7 +412,10 @@ __device__ float dist_torch_order(const unsigned char* rowbuf, const uint16_t* o
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int i = 0;
   for (; i + level_step <= size_ilp;) {
-    for (int j = 0; j < level_step; ++j, ++i) a0 += load(i * 4 + k);
+    for (int j = 0; j < level_step; j += 4, i += 4) {           // level_step >= 16
+      const float t0 = load(i * 4 + k), t1 = load((i + 1) * 4 + k), t2 = load((i + 2) * 4 + k), t3 = load((i + 3) * 4 + k);
+      a0 += t0; a0 += t1; a0 += t2; a0 += t3;
+    }
     a1 += a0; a0 = 0.f;
     if ((i & (level_mask << level_power)) == 0) {
       a2 += a1; a1 = 0.f;
@@ -421,10 +430,16 @@ __device__ float dist_torch_order(const unsigned char* rowbuf, const uint16_t* o
     a0 += t1; a0 += t2; a0 += t3;                                // meaningful on lanes 0..7
   }
   float fin = 0.f;
-  for (int p = vec_size * CH; p < C; ++p) fin += sq(p);
+  for (int p = vec_size * CH; p < C; ++p) fin += sq[p];
 #pragma unroll
   for (int j = 0; j < 8; ++j) fin += __shfl(a0, j, 64);
   return fin;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and the
@@ -433,9 +448,10 @@ __device__ float dist_torch_order(const unsigned char* rowbuf, const uint16_t* o
 template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
                                                                 int C, const int* __restrict__ cols,
-                                                                const int* __restrict__ order, int strict, int S,
-                                                                int rows_per_split, float* __restrict__ den_out,
-                                                                double* __restrict__ part) {
+                                                                int strict, int S, int rows_per_split,
+                                                                float* __restrict__ den_out, double* __restrict__ part,
+                                                                int* __restrict__ nfix_count, int* __restrict__ nfix_list,
+                                                                int nfix_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -448,11 +464,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   if (lane < 4) {                                                // zero pad element of both buffers
     reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
     reinterpret_cast<uint32_t*>(buf1 + rowb - 16)[lane] = 0u;
-  }
-  uint16_t* ordL = reinterpret_cast<uint16_t*>(smem + size_t(2 * kRowWaves) * rowb);   // [C] (strict mode only)
-  if (strict) {
-    for (int p = tid; p < C; p += kRowWaves * 64) ordL[p] = uint16_t(order ? order[p] : p);
-    __syncthreads();
   }
   int coff[NPLB];
   load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
@@ -474,8 +485,11 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     }
     const double n2 = wave_sum_bcast(t);
     const float nrm32 = float(sqrt(n2));
-    float norm = rnT<DT>(nrm32);
-    if (strict && (strict >= 2 || near_T_boundary<DT>(nrm32, kFragileUlpsNorm))) norm = rnT<DT>(norm_torch_order<DT>(buf0, ordL, C, lane));
+    const float norm = rnT<DT>(nrm32);
+    // strict mode: where the exact norm sits within a few fp32 ulps of a T rounding boundary, torch's own
+    // fp32 accumulation order decides the result -> queue the row for k_norm_fix (a few per thousand)
+    if (strict && lane == 0 && (strict >= 2 || near_T_boundary<DT>(nrm32, kFragileUlpsNorm)))
+      { const int j = atomicAdd(nfix_count, 1); if (j < nfix_cap) nfix_list[j] = int(row); }
     // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
     float dn = rnT<DT>(fmaxf(norm, 1e-12f));
     if (norm != norm) dn = norm;
@@ -502,14 +516,71 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   for (int p = tid; p < C; p += kRowWaves * 64) part[int64_t(blockIdx.x) * C + p] = sacc[p];
 }
 
+// Strict-mode fix-up of sweep 2: for every queued row replay torch's norm accumulation (the row's selected
+// values scattered to their SORTED positions, then the 8-chain / sequential fp32 sum).  Almost always the
+// T-rounded norm equals the exactly-rounded one already in den[]; when it does not, den[] is corrected and
+// the row is recorded so that k_centres can correct the column sums of its frame.  One wave per entry.
+struct NormCorr { int row; float den_old; float den_new; int pad; };
+constexpr int kMaxCorr = 4096;
+
+template <int DT, int VEC, int NPLB>
+__global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int D, int CV, int C,
+                                                 const int* __restrict__ cols, const int* __restrict__ spos,
+                                                 float* __restrict__ den, const int* __restrict__ nfix_count,
+                                                 const int* __restrict__ nfix_list, int max_entries,
+                                                 int* __restrict__ corr_count, NormCorr* __restrict__ corr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ES = Tr<DT>::ES;
+  const size_t rowb = row_lds_bytes(D, ES);
+  const int lane = threadIdx.x;
+  unsigned char* buf0 = smem;
+  const int count = min(*nfix_count, max_entries);
+  if (int(blockIdx.x) >= count) return;
+  if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+  int64_t row = nfix_list[blockIdx.x];
+  row_issue<DT, VEC>(x, row, D, CV, buf0, lane);                // first row's DMA overlaps the index loads below
+  int coff[NPLB], sp[NPLB];
+  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
+#pragma unroll
+  for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; sp[i] = p < C ? (spos ? spos[p] : p) : -1; }
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    if (e != int(blockIdx.x)) { row = nfix_list[e]; row_issue<DT, VEC>(x, row, D, CV, buf0, lane); }
+    const float dn_old = den[row];
+    row_wait();
+    float xv[NPLB];
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) xv[i] = lds_elem<DT>(buf0, coff[i]);
+    wave_lds_fence();
+    float* sv = reinterpret_cast<float*>(buf0);
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) if (sp[i] >= 0) sv[sp[i]] = xv[i];
+    wave_lds_fence();
+    const float norm = rnT<DT>(norm_torch_order<DT>(sv, C, lane));
+    float dn = rnT<DT>(fmaxf(norm, 1e-12f));
+    if (norm != norm) dn = norm;
+    if (lane == 0 && !(dn == dn_old) && !(dn != dn && dn_old != dn_old)) {
+      den[row] = dn;
+      const int j = atomicAdd(corr_count, 1);
+      if (j < kMaxCorr) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; }
+    }
+    wave_lds_fence();
+    if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+  }
+}
+
 // centres (compact channel space): frame_center[f][p] = mean_T(sum_n x^) and per-frame-group column
 // sums (fp64, fixed order).  grid = (ceil(C/64), ceil(F/16)); workgroup = 64 columns x 16 frames.
 constexpr int kCentreFL = 16;
 
+// Strict mode: rows whose norm k_norm_fix corrected (corr list, normally empty) swap their x^ contribution.
 template <int DT>
 __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __restrict__ part, int F, int S,
                                                              int N, int C, float* __restrict__ fc,
-                                                             double* __restrict__ csum_part) {
+                                                             double* __restrict__ csum_part,
+                                                             const void* __restrict__ x, int D,
+                                                             const int* __restrict__ cols,
+                                                             const int* __restrict__ corr_count,
+                                                             const NormCorr* __restrict__ corr) {
   __shared__ double sm[kCentreFL][64];
   const int cl = threadIdx.x & 63, fl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -517,6 +588,16 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
   double sf = 0.0;
   if (c < C && f < F) {
     for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
+    const int nc = corr_count ? min(*corr_count, kMaxCorr) : 0;
+    for (int e = 0; e < nc; ++e) {
+      const int row = corr[e].row;
+      if (row / N == f) {
+        const float v = ldT<DT>(x, int64_t(row) * D + (cols ? cols[c] : c));
+        const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_old)));
+        const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_new)));
+        sf += double(xn) - double(xo);
+      }
+    }
     fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
   }
   sm[fl][cl] = sf;
@@ -535,7 +616,8 @@ template <int DT>
 __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t stride, int C, int64_t R_total,
                              double* __restrict__ csum_out, float* __restrict__ vc, int* __restrict__ ticket) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && ticket) *ticket = 0;           // arrival counter of k_token_epilogue's fused budget stage
+  if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [0] arrival counter of k_token_epilogue's fused
+  //                                                            budget stage, [1] k_dist's strict-mode fix-up queue length
   if (c >= C) return;
   double t = 0.0;
   for (int p = 0; p < NP; ++p) t += parts[int64_t(p) * stride + c];
@@ -564,12 +646,12 @@ template <int DT> __device__ __forceinline__ void rnT2(float a, float b, float& 
 template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
                                                          const int* __restrict__ cols,
-                                                         const int* __restrict__ order,
-                                                         const int* __restrict__ opos, int strict, int S,
+                                                         const int* __restrict__ spos, int strict, int S,
                                                          int rows_per_split, const float* __restrict__ den,
                                                          const float* __restrict__ vc,
                                                          const float* __restrict__ fc,
-                                                         float* __restrict__ dv_out, float* __restrict__ df_out) {
+                                                         float* __restrict__ dv_out, float* __restrict__ df_out,
+                                                         int* __restrict__ fix_count, int* __restrict__ fix_list) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -582,14 +664,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]
   float* dens = reinterpret_cast<float*>(smem + size_t(kRowWaves) * rowb);   // [rows_per_split]
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-  uint16_t* ordL = reinterpret_cast<uint16_t*>(dens + ((rows_per_split + 3) & ~3));   // [C] + [C] (strict mode only)
-  uint16_t* oposL = ordL + C;
-  if (strict) {
-    for (int p = tid; p < C; p += kRowWaves * 64) {
-      ordL[p] = uint16_t(order ? order[p] : p);
-      oposL[p] = uint16_t(opos ? opos[p] : p);
-    }
-  }
   for (int r = n0 + tid; r < n1; r += kRowWaves * 64) dens[r - n0] = den[int64_t(f) * N + r];
   int coff[NPLB];
   float cv[NPLB], cf[NPLB];
@@ -620,10 +694,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     }
     pv = wave_sum_bcast(pv);
     pf = wave_sum_bcast(pf);
-    float dvv = float(pv), dff = float(pf);
-    if (strict) {
-      if (strict >= 2 || near_T_boundary<DT>(dvv, kFragileUlpsDist)) dvv = dist_torch_order<DT>(buf0, ordL, oposL, vc, inv, C, lane);
-      if (strict >= 2 || near_T_boundary<DT>(dff, kFragileUlpsDist)) dff = dist_torch_order<DT>(buf0, ordL, oposL, fc + int64_t(f) * C, inv, C, lane);
+    const float dvv = float(pv), dff = float(pf);
+    if (strict && lane == 0) {
+      // rare: the exact sum is within a few fp32 ulps of a T rounding boundary, where torch's own fp32
+      // accumulation order decides the result -> queue the (row, centre) for k_dist_fix
+      if (strict >= 2 || near_T_boundary<DT>(dvv, kFragileUlpsDist)) {
+        const int j = atomicAdd(fix_count, 1); if (j < kMaxFix) fix_list[j] = int(row) * 2;
+      }
+      if (strict >= 2 || near_T_boundary<DT>(dff, kFragileUlpsDist)) {
+        const int j = atomicAdd(fix_count, 1); if (j < kMaxFix) fix_list[j] = int(row) * 2 + 1;
+      }
     }
     if (lane == 0) {
       dv_out[row] = rnT<DT>(dvv);
@@ -709,6 +789,64 @@ __global__ __launch_bounds__(kBudNT) void k_scales(const float* __restrict__ s, 
                                                    float* __restrict__ zbuf, float* __restrict__ scales_f32,
                                                    void* __restrict__ scales_T) {
   scales_body<DT>(s, F, base, temp, zbuf, scales_f32, scales_T);
+}
+
+// Strict-mode fix-up of sweep 3: for every queued (row, centre) recompute the squares, scatter them to their
+// SORTED positions (fp32, over the row buffer once the row has been consumed) and add them in torch's
+// cascade-sum order.  One wave per entry; a handful of entries per thousand tokens.
+template <int DT, int VEC, int NPLB>
+__global__ __launch_bounds__(64) void k_dist_fix(const void* __restrict__ x, int N, int D, int CV, int C,
+                                                 const int* __restrict__ cols, const int* __restrict__ spos,
+                                                 const float* __restrict__ den, const float* __restrict__ vc,
+                                                 const float* __restrict__ fc, float* __restrict__ dv_out,
+                                                 float* __restrict__ df_out, const int* __restrict__ fix_count,
+                                                 const int* __restrict__ fix_list, int max_entries) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ES = Tr<DT>::ES;
+  const size_t rowb = row_lds_bytes(D, ES);
+  const int lane = threadIdx.x;
+  unsigned char* buf0 = smem;
+  const int count = min(*fix_count, max_entries);
+  if (int(blockIdx.x) >= count) return;
+  if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+  int coff[NPLB], sp[NPLB];
+  bool first = true;
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const int ent = fix_list[e];
+    const int64_t row = ent >> 1;
+    const int which = ent & 1;
+    row_issue<DT, VEC>(x, row, D, CV, buf0, lane);              // the DMA overlaps the loads below
+    if (first) {
+      load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
+#pragma unroll
+      for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; sp[i] = p < C ? (spos ? spos[p] : p) : -1; }
+      first = false;
+    }
+    const int f = int(row / N);
+    const float* cen = which ? fc + int64_t(f) * C : vc;
+    const double inv = 1.0 / double(den[row]);
+    float q[NPLB];
+    float cc[NPLB];
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; cc[i] = p < C ? cen[p] : 0.f; }
+    row_wait();
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) {
+      const float v = lds_elem<DT>(buf0, coff[i]);
+      const float xh = rnT<DT>(div_via_f64(v, inv));
+      const float a = rnT<DT>(xh - cc[i]);
+      q[i] = rnT<DT>(a * a);
+    }
+    wave_lds_fence();
+    float* sq = reinterpret_cast<float*>(buf0);
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) if (sp[i] >= 0) sq[sp[i]] = q[i];
+    wave_lds_fence();
+    const float r = sum_torch_order<DT>(sq, C, lane);
+    if (lane == 0) (which ? df_out : dv_out)[row] = rnT<DT>(r);
+    wave_lds_fence();
+    if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+  }
 }
 
 // per-token epilogue (vidcom2.py:62, :32-33): 5-scale Gaussian sums of both distances, total = v+f,
@@ -922,8 +1060,8 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups
   int S, rows_per_split;        // sweep-2/3 splits per frame
   // workspace offsets (bytes)
-  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_tmp_f32, total_bytes;
+  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
+      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_fixlist, o_nfixlist, o_corr, o_tmp_f32, total_bytes;
 };
 
 int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
@@ -956,6 +1094,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_cols = take(size_t(D) * 4);
   p->o_order = take(size_t(D) * 4);
   p->o_opos = take(size_t(D) * 4);
+  p->o_spos = take(size_t(D) * 4);
   p->o_den = take(size_t(p->R) * 4);
   p->o_part_col = take(size_t(F) * p->S * D * 8);
   p->o_fc = take(size_t(F) * D * 4);
@@ -971,6 +1110,9 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_scales_T = take(size_t(F) * 4);
   p->o_offs = take(size_t(F + 1) * 8);
   p->o_ticket = take(64);
+  p->o_fixlist = take(size_t(kMaxFix) * 4);
+  p->o_nfixlist = take(size_t(p->R) * 4);
+  p->o_corr = take(size_t(kMaxCorr) * sizeof(NormCorr));
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
   p->total_bytes = o;
   return VC2_OK;
@@ -986,10 +1128,10 @@ int check_launch(const char* what) {
 
 // ---- optional per-kernel timing (bench.py's roofline leg): hipEvents around every launch --------
 enum KernelId { KID_STATS = 0, KID_STATS_REDUCE, KID_CHAN_SELECT, KID_NORM_COLSUM, KID_CENTRES, KID_DIST,
-                KID_EPILOGUE, KID_SCALES, KID_KS, KID_SELECT, KID_GATHER_ROWS, KID_OTHER, KID_COUNT };
+                KID_EPILOGUE, KID_SCALES, KID_KS, KID_SELECT, KID_GATHER_ROWS, KID_OTHER, KID_CHAN_ORDER, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"k_chan_stats", "k_stats_reduce", "k_chan_select", "k_norm_colsum",
                                              "k_centres", "k_dist", "k_token_epilogue", "k_scales", "k_ks(unused)",
-                                             "k_select", "k_gather_rows", "other"};
+                                             "k_select", "k_gather_rows", "k_norm_fix", "k_chan_select(order; side stream)"};
 struct ProfRec { int id; hipEvent_t a, b; };
 bool g_prof = false;
 std::vector<ProfRec> g_prof_recs;
@@ -1026,7 +1168,7 @@ int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
 
 // sweep 1 -> (mean, M2) stats and/or var
 int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, void* var_T, float* var_f32,
-                      hipStream_t st) {
+                      hipStream_t st, bool zero_queue_counters = false) {
   double* part = wsp<double>(ws, p.o_part_stats);
   dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
   { ProfScope ps_(KID_STATS, st);
@@ -1034,12 +1176,13 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, voi
                                           p.R, int(p.D), p.CV, p.rows_per_group, part)); }
   { ProfScope ps_(KID_STATS_REDUCE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_stats_reduce<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
-                                           0, st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32)); }
+                                           0, st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32,
+                                           zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr)); }
   return check_launch("chan_stats");
 }
 
 int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* order, int* opos,
-                       hipStream_t st) {
+                       int* spos, hipStream_t st, int kid = KID_CHAN_SELECT) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = (sel_shared_bytes(int(D)) + 15) / 16 * 16 + (order ? sort_scratch_bytes(int(D)) : 0);
@@ -1050,9 +1193,9 @@ int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask
     if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(k_chan_select): %s", hipGetErrorString(e));
     attr_set = true;
   }
-  { ProfScope ps_(KID_CHAN_SELECT, st);
+  { ProfScope ps_(kid, st);
   hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, order,
-                     opos); }
+                     opos, spos); }
   return check_launch("chan_select");
 }
 
@@ -1073,26 +1216,40 @@ int g_strict = 1;
 // positions in `cols` (both nullptr = identity when cols is nullptr, else strict mode is unavailable)
 struct ChanSet {
   const int* cols;
-  const int* order;
-  const int* opos;
+  const int* spos;     // position of cols[i] in torch.topk's order (nullptr with cols == nullptr: identity)
   int C;
   int strict;
 };
-inline ChanSet make_chanset(const Plan& p, const int* cols, const int* order, const int* opos, int64_t C) {
-  ChanSet cs{cols, order, opos, int(C), 0};
-  cs.strict = (g_strict && p.ES == 2 && (cols == nullptr || (order && opos))) ? g_strict : 0;   // 2 = replay always
+inline ChanSet make_chanset(const Plan& p, const int* cols, const int* spos, int64_t C) {
+  ChanSet cs{cols, spos, int(C), 0};
+  // the replay scatters C fp32 values over one row buffer: needs C*4 <= D*sizeof(T)
+  const bool fits = size_t(C) * 4 <= size_t(p.D) * p.ES || cols == nullptr;
+  cs.strict = (g_strict && p.ES == 2 && (cols == nullptr || spos) && fits) ? g_strict : 0;   // 2 = replay always
   return cs;
 }
 
 template <int DT, int VEC, int NPLB>
 int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
   const int* cols = cs.cols; const int C = cs.C;
-  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + (cs.strict ? size_t(C) * 2 + 16 : 0);
+  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES);
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB>, smem, "k_norm_colsum");
   if (rc) return rc;
   hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
-                     int(p.N), int(p.D), p.CV, C, cols, cs.order, cs.strict, p.S, p.rows_per_split,
-                     wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col));
+                     int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.rows_per_split,
+                     wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
+                     wsp<int>(ws, p.o_nfixlist), int(p.R));
+  return VC2_OK;
+}
+template <int DT, int VEC, int NPLB>
+int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+  const size_t smem1 = row_lds_bytes(int(p.D), Tr<DT>::ES);
+  int rc1 = allow_big_lds(&k_norm_fix<DT, VEC, NPLB>, smem1, "k_norm_fix");
+  if (rc1) return rc1;
+  const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(p.R, 4096)) : 512;
+  hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
+                     cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + 2,
+                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + 3,
+                     wsp<NormCorr>(ws, p.o_corr));
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -1103,14 +1260,26 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hip
   rps = std::min<int64_t>(rps, p.N);
   const int S2 = int(cdiv(p.N, rps));
   rps = cdiv(p.N, S2);
-  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 32 +
-                      (cs.strict ? size_t(C) * 4 + 16 : 0);
+  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 32;
   int rc = allow_big_lds(&k_dist<DT, VEC, NPLB>, smem, "k_dist");
   if (rc) return rc;
   hipLaunchKernelGGL((k_dist<DT, VEC, NPLB>), dim3(unsigned(p.F * S2)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
-                     int(p.D), p.CV, C, cols, cs.order, cs.opos, cs.strict, S2, int(rps), wsp<float>(ws, p.o_den),
+                     int(p.D), p.CV, C, cols, cs.spos, cs.strict, S2, int(rps), wsp<float>(ws, p.o_den),
                      wsp<float>(ws, p.o_vc),
-                     wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df));
+                     wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df),
+                     wsp<int>(ws, p.o_ticket) + 1, wsp<int>(ws, p.o_fixlist));
+  if (cs.strict) {
+    // fix-up of the queued boundary-fragile sums (the queue length is only known on the device: launch a
+    // fixed number of single-wave workgroups, the surplus ones exit at once)
+    const size_t smem1 = row_lds_bytes(int(p.D), Tr<DT>::ES);
+    int rc1 = allow_big_lds(&k_dist_fix<DT, VEC, NPLB>, smem1, "k_dist_fix");
+    if (rc1) return rc1;
+    const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(2 * p.R, kMaxFix)) : 512;
+    hipLaunchKernelGGL((k_dist_fix<DT, VEC, NPLB>), dim3(unsigned(std::min(nfix, 4096))), dim3(64), smem1, st, x,
+                       int(p.N), int(p.D), p.CV, C, cols, cs.spos, wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
+                       wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df),
+                       wsp<int>(ws, p.o_ticket) + 1, wsp<int>(ws, p.o_fixlist), kMaxFix);
+  }
   return VC2_OK;
 }
 // compact positions per lane -> compile-time bucket (28 = 3584-d, 32 = 4096-d models)
@@ -1121,26 +1290,47 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hip
    : fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels"))
 
 // sweep 2 + centres.  single_rank: also the video centre; else only the rank's csum (for the all-gather).
-int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, bool single_rank, hipStream_t st) {
+// The two strict-mode queue counters (ticket[2], ticket[3]) must be zero on entry (zero_counters).
+// wait_before_fix: event after which cs.spos is valid (the channel sort may run on a side stream).
+int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, bool single_rank, hipStream_t st,
+                  hipEvent_t wait_before_fix = nullptr) {
   const int C = cs.C;
   double* part = wsp<double>(ws, p.o_part_col);
   double* cpart = wsp<double>(ws, p.o_csum_part);
   const int FG = int(cdiv(p.F, kCentreFL));
+  const int npl = int(cdiv(C, 64));
   { ProfScope ps_(KID_NORM_COLSUM, st);
   int rc = VC2_OK;
-  const int npl = int(cdiv(C, 64));
   VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, st));
   if (rc) return rc; }
+  if (cs.strict) {
+    if (wait_before_fix) {
+      hipError_t e = hipStreamWaitEvent(st, wait_before_fix, 0);
+      if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+    }
+    ProfScope ps_(KID_OTHER, st);
+    int rc = VC2_OK;
+    VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_fix_t, p, x, cs, ws, st));
+    if (rc) return rc;
+  }
   { ProfScope ps_(KID_CENTRES, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
                                            dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, int(p.N), C,
-                                           wsp<float>(ws, p.o_fc), cpart));
+                                           wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols,
+                                           cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
+                                           wsp<NormCorr>(ws, p.o_corr)));
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
                                            cpart, FG, int64_t(C), C, p.R,
                                            single_rank ? (double*)nullptr : wsp<double>(ws, p.o_csum),
                                            single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr,
                                            wsp<int>(ws, p.o_ticket))); }
   return check_launch("scores phase 1");
+}
+
+int zero_counters(const Plan& p, void* ws, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(wsp<int>(ws, p.o_ticket), 0, 16, st);
+  if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+  return VC2_OK;
 }
 
 // budget_base >= 0: the epilogue's last workgroup also computes the scales (single-GPU fused pass).
@@ -1189,6 +1379,23 @@ int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, con
   hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, st, static_cast<const unsigned char*>(src),
                      src_rows, D * ES, idx, K_dev, cap, static_cast<unsigned char*>(dst));
   return check_launch("gather_rows");
+}
+
+// ---- side stream for the strict-mode channel sort (fork/join with events around the caller's stream) ----
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream g_side[64];
+int get_side(SideStream** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(VC2_ERR_LAUNCH, "hipGetDevice failed");
+  SideStream& ss = g_side[dev];
+  if (!ss.s) {
+    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
+      return fail(VC2_ERR_LAUNCH, "could not create the side stream");
+  }
+  *out = &ss;
+  return VC2_OK;
 }
 
 }  // namespace
@@ -1259,10 +1466,11 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
 }
 
 int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, int32_t* order,
-                    int32_t* opos, void* stream) {
+                    int32_t* opos, int32_t* spos, void* stream) {
   if (!var_f32 || (!mask && !cols && !order)) return fail(VC2_ERR_ARG, "null pointer");
+  if ((opos || spos) && !(order && opos)) return fail(VC2_ERR_ARG, "opos/spos need order and opos");
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
-  return launch_chan_select(var_f32, D, k, mask, cols, order, opos, static_cast<hipStream_t>(stream));
+  return launch_chan_select(var_f32, D, k, mask, cols, order, opos, spos, static_cast<hipStream_t>(stream));
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -1290,8 +1498,7 @@ static int check_cols(const int32_t* cols, int64_t C, int64_t D) {
 }
 
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes, double* csum,
-                      void* stream) {
+                      const int32_t* spos, void* ws, size_t ws_bytes, double* csum, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
@@ -1299,7 +1506,8 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  rc = launch_phase1(p, x, make_chanset(p, cols, order, opos, C), ws, /*single_rank=*/false, st);
+  if ((rc = zero_counters(p, ws, st))) return rc;
+  rc = launch_phase1(p, x, make_chanset(p, cols, spos, C), ws, /*single_rank=*/false, st);
   if (rc) return rc;
   if (csum) {
     hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
@@ -1309,8 +1517,8 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
 }
 
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      const int32_t* order, const int32_t* opos, const double* csum_all, int64_t P,
-                      int64_t csum_stride, int64_t R_total, void* ws,
+                      const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
+                      int64_t R_total, void* ws,
                       size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
   if (!x || !csum_all || P <= 0 || csum_stride < C) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
@@ -1324,12 +1532,12 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
                                             wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket)));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
-  return launch_phase2(p, x, make_chanset(p, cols, order, opos, C), ws, v_T, f_T, total, s, st);
+  return launch_phase2(p, x, make_chanset(p, cols, spos, C), ws, v_T, f_T, total, s, st);
 }
 
 int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-               const int32_t* order, const int32_t* opos, void* ws, size_t ws_bytes, void* v_T, void* f_T,
-               float* total_f32, float* s_f32, void* stream) {
+               const int32_t* spos, void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32,
+               float* s_f32, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
@@ -1337,7 +1545,8 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const ChanSet cs = make_chanset(p, cols, order, opos, C);
+  const ChanSet cs = make_chanset(p, cols, spos, C);
+  if ((rc = zero_counters(p, ws, st))) return rc;
   if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
@@ -1410,14 +1619,27 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
   int* cols = wsp<int>(ws, p.o_cols);
-  if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st))) return rc;
+  if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true))) return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
   const bool strict = g_strict && p.ES == 2;
-  int* order = strict ? wsp<int>(ws, p.o_order) : nullptr;
-  int* opos = strict ? wsp<int>(ws, p.o_opos) : nullptr;
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, order, opos, st))) return rc;
-  const ChanSet cs = make_chanset(p, cols, order, opos, kc);
-  if ((rc = launch_phase1(p, x, cs, ws, true, st))) return rc;
+  int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;
+  hipEvent_t join = nullptr;
+  if (strict) {
+    // torch.topk's ORDER of the selected channels (needed only by the strict-mode fix-ups) is replayed on a side
+    // stream, concurrently with the channel-set selection and sweep 2 on the caller's stream.
+    SideStream* ss = nullptr;
+    if ((rc = get_side(&ss))) return rc;
+    if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
+      return fail(VC2_ERR_LAUNCH, "side-stream fork failed");
+    if ((rc = launch_chan_select(var_f32, D, kc, nullptr, nullptr, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos,
+                                 ss->s, KID_CHAN_ORDER)))
+      return rc;
+    if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(VC2_ERR_LAUNCH, "side-stream join failed");
+    join = ss->join;
+  }
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, nullptr, nullptr, nullptr, st))) return rc;
+  const ChanSet cs = make_chanset(p, cols, spos, kc);
+  if ((rc = launch_phase1(p, x, cs, ws, true, st, join))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* s = wsp<float>(ws, p.o_s);
   if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st, base_scale < 0 ? 0.0 : base_scale)))

@@ -635,6 +635,7 @@ __device__ void introsort_block(const SelShared& S, const SortScratch& Q, int n,
   int ci = 0;
   while (true) {
     const int ns = Q.cnt[ci];
+    dbg_stamp(6000000 + ns);
     if (ns == 0) break;
     for (int si = wave; si < ns; si += NW) {
       const uint32_t sg = cur[si];
@@ -664,21 +665,38 @@ __device__ void introsort_block(const SelShared& S, const SortScratch& Q, int n,
     uint32_t* t = cur; cur = nxt; nxt = t;
     __syncthreads();
   }
-  // stable sort inside each leaf == __final_insertion_sort
-  for (int p = tid; p < n; p += NT) {
-    int ls = p;
-    while (!Q.bnd[ls]) --ls;
-    int le = p + 1;
-    while (le < n && !Q.bnd[le]) ++le;
-    const uint32_t kp = S.key[p];
-    int r = ls;
-    for (int q = ls; q < le; ++q) {
-      const uint32_t kq = S.key[q];
-      r += (kq < kp || (kq == kp && q < p)) ? 1 : 0;
+  dbg_stamp(7000000);
+  // stable sort inside each leaf == __final_insertion_sort.  Leaf id = prefix count of the boundary flags;
+  // leaf starts are scattered by id (into la, free now), so every element finds [ls, le) in two reads.
+  {
+    const int E = (n + NT - 1) / NT;
+    const int b = tid * E, e = min(n, b + E);
+    uint32_t cnt = 0;
+    for (int p = b; p < e; ++p) cnt += Q.bnd[p];
+    uint32_t excl, tot;
+    block_scan_pair<NT>(cnt, excl, tot, S.wtot);
+    uint32_t id = excl;                                   // leaves before position b
+    for (int p = b; p < e; ++p) {
+      if (Q.bnd[p]) { S.la[id] = uint16_t(p); ++id; }
+      S.lb[p] = uint16_t(id - 1);                         // leaf id of position p
     }
-    out_order[r] = int(S.idx[p]);
+    if (tid == 0) S.la[tot] = uint16_t(n);                // sentinel end
+    __syncthreads();
+    for (int p = tid; p < n; p += NT) {
+      const int lid = S.lb[p];
+      const int ls = S.la[lid], le = S.la[lid + 1];
+      const uint32_t kp = S.key[p];
+      int r = ls;
+#pragma unroll 4
+      for (int q = ls; q < le; ++q) {
+        const uint32_t kq = S.key[q];
+        r += (kq < kp || (kq == kp && q < p)) ? 1 : 0;
+      }
+      out_order[r] = int(S.idx[p]);
+    }
   }
   __syncthreads();
+  dbg_stamp(8000000);
 }
 
 }  // namespace vc2

@@ -55,6 +55,7 @@ class HipStages:
         self.cols = torch.empty(D, dtype=torch.int32, device=self.device)
         self.order = torch.empty(D, dtype=torch.int32, device=self.device)    # channels in torch.topk order
         self.opos = torch.empty(D, dtype=torch.int32, device=self.device)
+        self.spos = torch.empty(D, dtype=torch.int32, device=self.device)     # their positions in that order
         self.total = torch.empty(F * N, dtype=torch.float32, device=self.device)
         self.s = torch.empty(F, dtype=torch.float32, device=self.device)
         # a rank can hold the globally dominant frame: sum of its scales <= base * (F_local + 1)
@@ -77,18 +78,18 @@ class HipStages:
         check(lib().vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, ptr(self.var_f32),
                                             self._st()), "vc2_chan_var_from_stats")
         check(lib().vc2_chan_select(ptr(self.var_f32), self.D, self.C, ptr(self.mask), ptr(self.cols), ptr(self.order), ptr(self.opos),
-                                    self._st()),
+                                    ptr(self.spos), self._st()),
               "vc2_chan_select")
 
     def phase1(self, x):
-        check(lib().vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C, ptr(self.order),
-                                      ptr(self.opos), ptr(self.ws), self.ws.numel(), ptr(self.csum), self._st()),
+        check(lib().vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C, ptr(self.spos),
+                                      ptr(self.ws), self.ws.numel(), ptr(self.csum), self._st()),
               "vc2_scores_phase1")
         return self.csum
 
     def phase2(self, x, csum_all, R_total):
         check(lib().vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C,
-                                      ptr(self.order), ptr(self.opos), ptr(csum_all), csum_all.shape[0], csum_all.shape[1], R_total, ptr(self.ws),
+                                      ptr(self.spos), ptr(csum_all), csum_all.shape[0], csum_all.shape[1], R_total, ptr(self.ws),
                                       self.ws.numel(), None, None, ptr(self.total), ptr(self.s), self._st()),
               "vc2_scores_phase2")
         return self.s

@@ -171,7 +171,7 @@ def low_var_channel_order(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
     _, var_f = _channel_variance(x)
     order = torch.empty(max(k, 1), dtype=torch.int32, device=x.device)
     if k > 0:
-        check(lib().vc2_chan_select(ptr(var_f), D, k, None, None, ptr(order), None, stream_ptr(x.device)),
+        check(lib().vc2_chan_select(ptr(var_f), D, k, None, None, ptr(order), None, None, stream_ptr(x.device)),
               "vc2_chan_select")
     return order[:k].to(torch.int64)
 
@@ -202,7 +202,7 @@ def compute_gaussian_scores(x: torch.Tensor, tpf: int) -> Tuple[torch.Tensor, to
     ws = _ffi.workspace(F, tpf, C, x.dtype, x.device)
     v = torch.empty((F, tpf), dtype=x.dtype, device=x.device)
     f = torch.empty((F, tpf), dtype=x.dtype, device=x.device)
-    check(lib().vc2_scores(ptr(x), F, tpf, C, DTYPE_CODE[x.dtype], None, C, None, None, ptr(ws), ws.numel(), ptr(v),
+    check(lib().vc2_scores(ptr(x), F, tpf, C, DTYPE_CODE[x.dtype], None, C, None, ptr(ws), ws.numel(), ptr(v),
                            ptr(f), None, None, stream_ptr(x.device)), "vc2_scores")
     return v, f
 
