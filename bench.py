@@ -99,6 +99,7 @@ def cpu_baseline(x_cpu, N, base, budget_s=12.0):
     import oracle
     cores = os.cpu_count() or 1
     oracle.set_num_threads(cores)
+    oracle.set_mode("torch")             # same semantics as the HIP path's default mode
     oracle.compress_indices(x_cpu[: 8 * N], N, base)   # warm (library load, page-in)
     t0 = time.perf_counter()
     reps = 0
@@ -192,12 +193,14 @@ def main():
     # ---- roofline leg: same steps again with hipEvents around every kernel --------------------------
     roof = None
     kern = {}
+    _ffi.lib().vc2_set_side_stream(0)      # per-kernel events need the kernels back to back on ONE stream
     _ffi.profile_enable(True)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     prof = _ffi.profile_collect()
     _ffi.profile_enable(False)
+    _ffi.lib().vc2_set_side_stream(1)
     for name, (tot, cnt) in prof.items():
         kern[name] = round(tot / cnt * 1e3, 2)          # us per launch
     sweeps = {n: kern[n] for n in ("k_chan_stats", "k_norm_colsum", "k_dist", "k_gather_rows") if n in kern}
@@ -225,6 +228,18 @@ def main():
         "kernels_us": kern,
     }
 
+    out["mode"] = _ffi.get_mode() + (" (bit-exact to the CPU reference: boundary-fragile tokens replay torch's fp32 "
+                                     "accumulation order)" if _ffi.get_mode() == "torch" else "")
+    # ---- side measurement: the same pass with plain correctly-rounded reductions ("exact" mode) ---------
+    if not dist_on and not args.no_extra and dtype != torch.float32:
+        _ffi.set_mode("exact")
+        for _ in range(args.warmup):
+            step()
+        e3 = time_steps(step, args.steps, False)
+        _ffi.set_mode("torch")
+        out["exact_mode"] = {"ms_per_step": round(e3 / args.steps * 1e3, 4),
+                             "tokens_per_s": round(F * N / (e3 / args.steps), 1),
+                             "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / (e3 / args.steps) / 1e9, 1)}
     # ---- side measurement: cfg2 (LLaVA-OV shape) on one GPU -----------------------------------------
     if not dist_on and not args.no_extra and args.workload == "target":
         F2, N2, D2, dt2, b2 = WORKLOADS["cfg2"]

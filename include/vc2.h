@@ -55,6 +55,10 @@ const char* vc2_version(void);
  * fp32 inputs are unaffected.  Process-wide. */
 int vc2_set_mode(int mode);
 int vc2_get_mode(void);
+/* 1 (default): in mode 1 vc2_compress replays torch.topk's channel ORDER on an internal side stream, forked from
+ * and joined to the caller's stream with events, concurrently with sweep 2.  0: everything on the caller's stream
+ * (used by bench.py's per-kernel timing leg). */
+int vc2_set_side_stream(int on);
 
 /* Workspace (bytes) needed by any entry point below for an [F*N, D] input. */
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes);

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],
     "vc2_set_mode": [_i32],
     "vc2_get_mode": [],
+    "vc2_set_side_stream": [_i32],
     "vc2_profile_enable": [_i32],
     "vc2_profile_collect": [_i32, _vp, _vp, _vp],
     "vc2_last_error": [],

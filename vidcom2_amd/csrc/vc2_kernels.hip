@@ -1211,6 +1211,7 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what)
 // 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
 // result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
 int g_strict = 1;
+int g_use_side_stream = 1;   // 0: run the channel-order replay on the caller's stream (clean per-kernel timing)
 
 // the scored channels: ascending list (nullptr = all D), the same channels in torch.topk's order and their
 // positions in `cols` (both nullptr = identity when cols is nullptr, else strict mode is unavailable)
@@ -1222,9 +1223,7 @@ struct ChanSet {
 };
 inline ChanSet make_chanset(const Plan& p, const int* cols, const int* spos, int64_t C) {
   ChanSet cs{cols, spos, int(C), 0};
-  // the replay scatters C fp32 values over one row buffer: needs C*4 <= D*sizeof(T)
-  const bool fits = size_t(C) * 4 <= size_t(p.D) * p.ES || cols == nullptr;
-  cs.strict = (g_strict && p.ES == 2 && (cols == nullptr || spos) && fits) ? g_strict : 0;   // 2 = replay always
+  cs.strict = (g_strict && p.ES == 2 && (cols == nullptr || spos)) ? g_strict : 0;   // 2 = replay always
   return cs;
 }
 
@@ -1242,7 +1241,7 @@ int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hip
 }
 template <int DT, int VEC, int NPLB>
 int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
-  const size_t smem1 = row_lds_bytes(int(p.D), Tr<DT>::ES);
+  const size_t smem1 = std::max(row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(cs.C) * 4 + 16);   // row, then C fp32
   int rc1 = allow_big_lds(&k_norm_fix<DT, VEC, NPLB>, smem1, "k_norm_fix");
   if (rc1) return rc1;
   const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(p.R, 4096)) : 512;
@@ -1271,7 +1270,7 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hip
   if (cs.strict) {
     // fix-up of the queued boundary-fragile sums (the queue length is only known on the device: launch a
     // fixed number of single-wave workgroups, the surplus ones exit at once)
-    const size_t smem1 = row_lds_bytes(int(p.D), Tr<DT>::ES);
+    const size_t smem1 = std::max(row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16);   // row, then C fp32
     int rc1 = allow_big_lds(&k_dist_fix<DT, VEC, NPLB>, smem1, "k_dist_fix");
     if (rc1) return rc1;
     const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(2 * p.R, kMaxFix)) : 512;
@@ -1414,6 +1413,7 @@ int vc2_set_mode(int mode) {
   return VC2_OK;
 }
 int vc2_get_mode(void) { return g_strict; }
+int vc2_set_side_stream(int on) { g_use_side_stream = on ? 1 : 0; return VC2_OK; }
 
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
   if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
@@ -1624,7 +1624,11 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   const bool strict = g_strict && p.ES == 2;
   int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;
   hipEvent_t join = nullptr;
-  if (strict) {
+  if (strict && !g_use_side_stream) {
+    if ((rc = launch_chan_select(var_f32, D, kc, nullptr, nullptr, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos,
+                                 st, KID_CHAN_ORDER)))
+      return rc;
+  } else if (strict) {
     // torch.topk's ORDER of the selected channels (needed only by the strict-mode fix-ups) is replayed on a side
     // stream, concurrently with the channel-set selection and sweep 2 on the caller's stream.
     SideStream* ss = nullptr;
