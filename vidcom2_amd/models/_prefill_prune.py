@@ -1,0 +1,102 @@
+"""Prefill pruning shared by the Qwen-VL hooks.
+
+What the reference's patched forwards do between "video embeddings scattered into the prompt"
+and "language model called" (models/qwen2_5_vl.py:126-185, models/qwen2_vl.py:101-147), as an
+interceptor around the model's own forward:
+
+1. `get_placeholder_mask` is watched to learn where the video placeholders sit and which
+   embeddings were scattered there (the model's own call, nothing recomputed);
+2. the call into `self.language_model` is intercepted: kept video positions are decided by
+   `choose(video_embeds)`, then `inputs_embeds`, `attention_mask` (2-D or 4-D) and
+   `position_ids` are sliced to text + kept video positions and the real language model runs.
+
+Position ids are computed by the model before the language-model call, i.e. on the *unpruned*
+sequence, which is what the reference does on purpose (qwen2_5_vl.py:89: "Pre-compute position
+ids before pruning so we can safely slice them later").
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from ._intercept import shadow
+
+
+class PruneState:
+    """Filled while the wrapped forward runs; read by tests through `model._vidcom2_last`."""
+
+    def __init__(self) -> None:
+        self.video_mask: Optional[torch.Tensor] = None       # [B, S] bool
+        self.video_embeds: Optional[torch.Tensor] = None     # [n_video_tokens, D]
+        self.kept_video: Optional[torch.Tensor] = None       # sorted indices into the video tokens
+        self.keep_token_indices: Optional[torch.Tensor] = None   # sorted positions in the sequence
+        self.pruned = False
+
+
+def _prune_attention(attn, keep: torch.Tensor):
+    if not torch.is_tensor(attn):
+        return attn
+    if attn.dim() == 2:
+        return attn[:, keep]
+    if attn.dim() == 4:
+        return attn[:, :, keep, :][:, :, :, keep]
+    return attn
+
+
+class _LanguageModelShim:
+    """Stands in for `self.language_model` during one forward; everything but the call itself
+    (attributes, sub-modules, config) is the real module's."""
+
+    def __init__(self, real, state: PruneState, choose: Callable[[torch.Tensor], Optional[torch.Tensor]]):
+        object.__setattr__(self, "_real", real)
+        object.__setattr__(self, "_state", state)
+        object.__setattr__(self, "_choose", choose)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_real"), name)
+
+    def __call__(self, *args, **kwargs):
+        st: PruneState = self._state
+        embeds = kwargs.get("inputs_embeds")
+        if st.video_mask is not None and torch.is_tensor(embeds) and embeds.shape[0] == 1:
+            kept = self._choose(st.video_embeds)
+            if kept is not None:
+                vm = st.video_mask[0].to(embeds.device)
+                video_pos = vm.nonzero(as_tuple=False).squeeze(-1)
+                keep_flags = ~vm
+                keep_flags[video_pos[kept]] = True
+                keep = keep_flags.nonzero(as_tuple=False).squeeze(-1)
+                kwargs["inputs_embeds"] = embeds[:, keep, :]
+                if torch.is_tensor(kwargs.get("input_ids")):
+                    kwargs["input_ids"] = kwargs["input_ids"][:, keep]
+                if "attention_mask" in kwargs:
+                    kwargs["attention_mask"] = _prune_attention(kwargs["attention_mask"], keep)
+                pos = kwargs.get("position_ids")
+                if torch.is_tensor(pos):
+                    kwargs["position_ids"] = pos[..., keep.to(pos.device)]
+                st.kept_video, st.keep_token_indices, st.pruned = kept, keep, True
+        return self._real(*args, **kwargs)
+
+
+def run_with_pruning(model, forward: Callable, choose: Callable[[torch.Tensor], Optional[torch.Tensor]],
+                     lm_attr: str = "language_model"):
+    """Run `forward()` with the interceptors in place.  `choose(video_embeds)` returns the sorted
+    kept indices into the video token list (or None to leave the prompt alone)."""
+    state = PruneState()
+    mask_inner = model.get_placeholder_mask
+
+    def get_placeholder_mask(*args, **kwargs):
+        out = mask_inner(*args, **kwargs)
+        feats = kwargs.get("video_features")
+        if feats is not None:
+            vmask = out[1]
+            st_mask = vmask[..., 0] if vmask.dim() == 3 else vmask
+            state.video_mask, state.video_embeds = st_mask.bool(), feats
+        return out
+
+    shim = _LanguageModelShim(getattr(model, lm_attr), state, choose)
+    with shadow(model, get_placeholder_mask=get_placeholder_mask, **{lm_attr: shim}):
+        out = forward()
+    model.__dict__["_vidcom2_last"] = state
+    return out

@@ -1,0 +1,84 @@
+"""LLaVA-OneVision / LLaVA-Video hook (reference: token_compressor/vidcom2/models/llava.py:52-379).
+
+Install exactly like the reference (README.md:76-83, lmms_eval/models/llava_onevision.py:157-163):
+
+    model.prepare_inputs_labels_for_multimodal = types.MethodType(
+        cus_prepare_inputs_labels_for_multimodal, model)
+
+The reference's function is a copy of `LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal`
+with two inserted calls, both in the per-video branch of the "spatial*" merge types:
+
+* `mm_newline_position == "grid"` (LLaVA-Video; llava.py:114-127): the video's pooled features
+  `[F, 169, D]` are flattened, `add_token_per_grid` builds the newline-augmented `[F*13*14, D]`
+  stream, and `vidcom2_compression(flattened, "llava_vid", img_feat=stream)` replaces the stream
+  by its kept rows;
+* `mm_newline_position == "one_token"` with an "unpad" merge type (LLaVA-OneVision;
+  llava.py:153-161): `image_feature.flatten(0, 1)` is replaced by
+  `vidcom2_compression(image_feature.flatten(0, 1))` (model "llava_ov", 196 tokens per frame).
+
+This wrapper runs the installed class's own method and intercepts exactly those two points:
+`self.add_token_per_grid` (grid) and, for one_token, the tensor `self.get_2dPool` hands to the
+branch, whose `flatten(0, 1)` yields the compressed rows.  Other configurations ("frame",
+"no_token", "flat" merge, non-video inputs) pass through untouched, as in the reference.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..vidcom2 import vidcom2_compression
+from ._intercept import original_method, retention_ratio, shadow
+
+__all__ = ["cus_prepare_inputs_labels_for_multimodal"]
+
+
+class _CompressOnFlatten(torch.Tensor):
+    """Pooled video features `[F, N, D]` whose `.flatten(0, 1)` is the compressed token list."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl   # every op returns plain tensors
+
+    def flatten(self, *args, **kwargs):
+        plain = self.as_subclass(torch.Tensor)
+        flat = plain.flatten(*args, **kwargs)
+        if args == (0, 1) and not kwargs and plain.dim() == 3:
+            return vidcom2_compression(flat, base_scale=retention_ratio())
+        return flat
+
+
+def cus_prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values,
+                                             labels, images, modalities=["image"], image_sizes=None):
+    original = original_method(self, "prepare_inputs_labels_for_multimodal",
+                               cus_prepare_inputs_labels_for_multimodal)
+    cfg = self.config
+    merge_type = getattr(cfg, "mm_patch_merge_type", "flat")
+    newline = getattr(cfg, "mm_newline_position", "one_token")
+    per_sample = type(images) is list or (torch.is_tensor(images) and images.ndim == 5)
+
+    patches = {}
+    if per_sample and merge_type.startswith("spatial"):
+        if newline == "grid":
+            grid_inner = self.add_token_per_grid
+            faster = bool(getattr(cfg, "add_faster_video", False))
+            calls = [0]
+
+            def add_token_per_grid(image_feature):
+                out = grid_inner(image_feature)
+                calls[0] += 1
+                if faster and calls[0] % 2 == 0:
+                    # second call per video builds the "faster" stream, which the reference leaves
+                    # uncompressed (llava.py:130-131)
+                    return out
+                flat = image_feature.reshape(-1, image_feature.shape[-1])
+                return vidcom2_compression(flat, "llava_vid", base_scale=retention_ratio(), img_feat=out)
+
+            patches["add_token_per_grid"] = add_token_per_grid
+        elif newline == "one_token" and "unpad" in merge_type:
+            pool_inner = self.get_2dPool
+
+            def get_2dPool(image_feature, *args, **kwargs):
+                return pool_inner(image_feature, *args, **kwargs).as_subclass(_CompressOnFlatten)
+
+            patches["get_2dPool"] = get_2dPool
+
+    with shadow(self, **patches):
+        return original(input_ids, position_ids, attention_mask, past_key_values, labels, images,
+                        modalities, image_sizes)
