@@ -162,6 +162,13 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
                        size_t ws_bytes, int64_t* ks, int64_t* idx_out, int64_t cap, int64_t* K_out,
                        const void* gather_src, void* out_rows, void* stream);
 
+/* _multi_scale_gaussian(x, center, alphas) as a standalone call -- vidcom2.py:59-62 (the fused pass
+ * never materialises x; this entry serves callers of the helper itself).  x: T[F*N, C] as given,
+ * centre: T[n_centres, C] with n_centres == 1 (video centre) or F (one per frame), alphas: n_alphas
+ * host doubles (<= 16).  out: T[F*N] = sum_a exp(-||x - c||^2 / (2 a)), every op rounded to T. */
+int vc2_multi_scale_gaussian(const void* x, int64_t F, int64_t N, int64_t C, int dtype, const void* centre,
+                             int64_t n_centres, const double* alphas, int n_alphas, void* out_T, void* stream);
+
 /* ---- small device utilities used by tests / bench ----------------------------------- */
 /* exp over every T bit pattern as the path computes it: out[i] = RN_T(exp(in[i])) (KAT). */
 int vc2_kat_exp(const void* in_T, int64_t n, int dtype, void* out_T, void* stream);

@@ -23,6 +23,7 @@ __all__ = [
     "compute_gaussian_scores", "gaussian_debug", "fuse", "compute_scales", "compute_ks",
     "select_outlier_indices", "map_linear_offset", "map_grid_vid", "compress_indices",
     "vidcom2_compression", "set_num_threads", "exp_T", "gaussian_scores_sharded", "set_mode",
+    "multi_scale_gaussian",
 ]
 
 
@@ -133,6 +134,20 @@ def compute_gaussian_scores(sel: torch.Tensor, tpf: int) -> Tuple[torch.Tensor, 
     sel = _prep(sel)
     o = gaussian_debug(sel, torch.arange(sel.shape[1]), tpf)
     return o["v"], o["f"]
+
+
+def multi_scale_gaussian(x: torch.Tensor, center: torch.Tensor, alphas) -> torch.Tensor:
+    """vidcom2.py:59-62 standalone.  x: [F, N, C]; center: [1, 1, C] or [F, 1, C]; returns [F, N]."""
+    if x.dim() != 3 or center.dim() != 3 or center.shape[1] != 1 or center.shape[2] != x.shape[2] \
+            or center.shape[0] not in (1, x.shape[0]):
+        raise RuntimeError("multi_scale_gaussian: x [F,N,C] and center [1|F,1,C] expected")
+    F, N, C = x.shape
+    xx, cc = _prep(x.reshape(F * N, C)), _prep(center.reshape(-1, C).to(x.dtype))
+    two_a = (ctypes.c_float * len(alphas))(*[float(2 * a) for a in alphas])
+    out = torch.empty(F, N, dtype=x.dtype)
+    _chk(_L().vc2o_multi_scale_gaussian(_p(xx), _i64(F * N), _i64(C), _DT[x.dtype], _p(cc), _i64(cc.shape[0]),
+                                        _i64(N), two_a, ctypes.c_int(len(alphas)), _p(out)), "multi_scale_gaussian")
+    return out
 
 
 def fuse(v: torch.Tensor, f: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -363,6 +363,43 @@ int vc2o_gaussian_scores_ex(const void* x, int64_t R, int64_t D, int dt, const i
   return 0;
 }
 
+// _multi_scale_gaussian(x, center, alphas) as a standalone call (vidcom2.py:59-62).  x: T[R, C]
+// (rows of N per frame), centre: T[n_centres, C] with n_centres == 1 (video centre) or R / N (one per
+// frame); two_a[i] = fp32(2 * alpha_i).  out: T[R].
+int vc2o_multi_scale_gaussian(const void* x, int64_t R, int64_t C, int dt, const void* centre,
+                              int64_t n_centres, int64_t N, const float* two_a, int na, void* out) {
+  if (!x || !centre || !out || !two_a || R < 0 || C <= 0 || N <= 0 || na <= 0) return -1;
+  if (n_centres != 1 && n_centres * N != R) return -2;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < R; ++r) {
+    const int64_t cb = (n_centres == 1 ? 0 : r / N) * C;
+    float dist;
+    if (g_mode == 1) {
+      std::vector<float> q(Z(C));
+      for (int64_t j = 0; j < C; ++j) {
+        float a = rT(load_T(x, r * C + j, dt) - load_T(centre, cb + j, dt), dt);
+        q[Z(j)] = rT(a * a, dt);
+      }
+      dist = rT(sum_torch_order(q.data(), C, dt), dt);
+    } else {
+      double sv = 0.0;
+      for (int64_t j = 0; j < C; ++j) {
+        float a = rT(load_T(x, r * C + j, dt) - load_T(centre, cb + j, dt), dt);
+        sv += double(rT(a * a, dt));
+      }
+      dist = rTd(sv, dt);
+    }
+    float acc = 0.0f;
+    for (int a = 0; a < na; ++a) {
+      float arg = rT((-dist) / two_a[a], dt);
+      float e = rTd(std::exp(double(arg)), dt);
+      acc = (a == 0) ? e : rT(acc + e, dt);          // Python sum(): 0 + t1 is exact
+    }
+    store_T(out, r, dt, acc);
+  }
+  return 0;
+}
+
 int vc2o_gaussian_scores(const void* x, int64_t R, int64_t D, int dt, const int64_t* idx,
                          int64_t C, int64_t tpf, void* v_out, void* f_out, void* norm_out,
                          void* vc_out, void* fc_out, void* dv_out, void* df_out) {

@@ -249,3 +249,14 @@ def qwen_inputs(c):
     else:
         mask = None
     return ids, feats, pos, mask
+
+
+def msg_inputs(c):
+    """x [F, N, C] and center ([1, 1, C] | [F, 1, C]) of a `msg_cases.json` case; scaled so that the
+    squared distances are O(1) and the Gaussians do not all underflow."""
+    F, N, C = c["F"], c["N"], c["C"]
+    s = np.float32(0.7 / np.sqrt(C))
+    x = synth.to_torch(synth.make_fp32(F, N, C, c["seed"], "iid") * s, DT[c["dt"]])
+    nc = 1 if c["kind"] == "video" else F
+    cen = synth.to_torch(synth.make_fp32(nc, 1, C, c["seed"] + 50, "iid") * s, DT[c["dt"]])
+    return x, cen

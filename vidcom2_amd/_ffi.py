@@ -44,6 +44,7 @@ _SIGNATURES = {
                           _vp, _vp, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
                            _vp, _vp],
+    "vc2_multi_scale_gaussian": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, ctypes.POINTER(ctypes.c_double), _i32, _vp, _vp],
     "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
     "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
     "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],

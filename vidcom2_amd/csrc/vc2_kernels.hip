@@ -864,6 +864,50 @@ __device__ __forceinline__ float gauss_sum(float dist) {
   return acc;
 }
 
+// _multi_scale_gaussian(x, center, alphas) as a standalone call (vidcom2.py:59-62): x T[R, C] is taken
+// as given (already normalised / channel-selected by the caller), centre T[1 | R/N, C].  One wave per
+// row: RN_T(RN_T(x - c)^2) per element, the row sum exact (fp64) or -- `strict` -- in torch's cascade
+// order over the columns as they are stored, then the Gaussian sum over the caller's scales.
+constexpr int kMsgWaves = 4;
+constexpr int kMaxAlphas = 16;
+struct MsgAlphas { float two_a[kMaxAlphas]; int n; };
+
+template <int DT>
+__global__ __launch_bounds__(kMsgWaves * 64) void k_multi_scale_gaussian(const void* __restrict__ x, int64_t R,
+                                                                         int C, const void* __restrict__ centre,
+                                                                         int per_frame, int N, MsgAlphas al,
+                                                                         int strict, void* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* sq = reinterpret_cast<float*>(smem) + size_t(wave) * C;      // strict only
+  for (int64_t r = int64_t(blockIdx.x) * kMsgWaves + wave; r < R; r += int64_t(gridDim.x) * kMsgWaves) {
+    const int64_t cb = per_frame ? (r / N) * C : 0;
+    double acc = 0.0;
+    for (int p = lane; p < C; p += 64) {
+      const float a = rnT<DT>(ldT<DT>(x, r * C + p) - ldT<DT>(centre, cb + p));
+      const float q = rnT<DT>(a * a);
+      if (strict) sq[p] = q; else acc += double(q);
+    }
+    float dist;
+    if (strict) {
+      wave_lds_fence();
+      dist = rnT<DT>(sum_torch_order<DT>(sq, C, lane));
+      wave_lds_fence();
+    } else {
+      dist = rnT<DT>(float(wave_sum(acc)));
+    }
+    if (lane == 0) {
+      float g = 0.f;
+      for (int a = 0; a < al.n; ++a) {
+        const float arg = rnT<DT>((-dist) / al.two_a[a]);
+        const float e = rnT<DT>(float(exp(double(arg))));
+        g = (a == 0) ? e : rnT<DT>(g + e);
+      }
+      stT<DT>(out, r, g);
+    }
+  }
+}
+
 // When `ticket` is given (single-GPU fused pass) the LAST workgroup to finish also runs the budget stage
 // (compute_scales over all F frame scores), saving a kernel boundary.  Hand-off per the CDNA guide G16:
 // s_out stores -> agent-scope release -> relaxed ticket; the last arriver does one agent-scope acquire.
@@ -1682,6 +1726,33 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
   if (out_rows && gather_src)
     rc = launch_gather_rows(gather_src, F_local * N, D, p.ES, idx_out, K_out, cap, out_rows, st);
   return rc;
+}
+
+int vc2_multi_scale_gaussian(const void* x, int64_t F, int64_t N, int64_t C, int dtype, const void* centre,
+                             int64_t n_centres, const double* alphas, int n_alphas, void* out_T, void* stream) {
+  if (!x || !centre || !alphas || !out_T) return fail(VC2_ERR_ARG, "null pointer");
+  if (dtype < 0 || dtype > 2) return fail(VC2_ERR_ARG, "unknown dtype code %d", dtype);
+  if (F < 0 || N <= 0 || C <= 0) return fail(VC2_ERR_SHAPE, "bad shape F=%lld N=%lld C=%lld", (long long)F,
+                                              (long long)N, (long long)C);
+  if (n_centres != 1 && n_centres != F) return fail(VC2_ERR_SHAPE, "centre must have 1 or F rows");
+  if (n_alphas < 1 || n_alphas > kMaxAlphas) return fail(VC2_ERR_UNSUPPORTED, "1..%d scales", kMaxAlphas);
+  if (C > 8192) return fail(VC2_ERR_UNSUPPORTED, "C <= 8192");
+  if (F == 0) return VC2_OK;
+  MsgAlphas al;
+  al.n = n_alphas;
+  for (int i = 0; i < n_alphas; ++i) al.two_a[i] = float(2.0 * alphas[i]);   // python: -d / (2 * a), scalar -> fp32
+  const int64_t R = F * N;
+  const unsigned grid = unsigned(std::min<int64_t>(cdiv(R, kMsgWaves), 65535 * 16));
+  const size_t smem = g_strict ? size_t(kMsgWaves) * size_t(C) * 4 : 0;
+  VC2_DISPATCH_DT(dtype, {
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_multi_scale_gaussian<DT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
+    hipLaunchKernelGGL((k_multi_scale_gaussian<DT>), dim3(grid), dim3(kMsgWaves * 64), smem,
+                       static_cast<hipStream_t>(stream), x, R, int(C), centre, n_centres == 1 ? 0 : 1, int(N), al,
+                       g_strict ? 1 : 0, out_T);
+  });
+  return check_launch("multi_scale_gaussian");
 }
 
 int vc2_kat_exp(const void* in_T, int64_t n, int dtype, void* out_T, void* stream) {

@@ -208,9 +208,24 @@ def compute_gaussian_scores(x: torch.Tensor, tpf: int) -> Tuple[torch.Tensor, to
 
 
 def _multi_scale_gaussian(x: torch.Tensor, center: torch.Tensor, alphas: List[float]) -> torch.Tensor:
-    """Reference: vidcom2.py:59-62 (helper, importable from the module).  Not on the fused path --
-    compute_gaussian_scores fuses both centres into sweep 3; this standalone form is not built yet."""
-    raise NotImplementedError("_multi_scale_gaussian is fused into compute_gaussian_scores in vidcom2_amd")
+    """Reference: vidcom2.py:59-62.  x T[F, N, C], center T[1, 1, C] or T[F, 1, C] (the two shapes
+    compute_gaussian_scores uses, vidcom2.py:51-52) -> T[F, N].  The fused pass never calls this (it
+    does not materialise x); it exists for callers of the helper itself."""
+    if x.dim() != 3 or center.dim() != 3 or center.shape[1] != 1 or center.shape[2] != x.shape[2] \
+            or center.shape[0] not in (1, x.shape[0]):
+        raise RuntimeError(f"_multi_scale_gaussian: x [F, N, C] with center [1, 1, C] or [F, 1, C] expected, got "
+                           f"{tuple(x.shape)} and {tuple(center.shape)}")
+    alphas = [float(a) for a in alphas]
+    if not alphas:
+        return 0                     # Python's sum() over no terms, exactly like the reference
+    F, N, C = x.shape
+    xx = _prep(x, "x")
+    cc = _prep(center.to(x.dtype), "center")
+    out = torch.empty(F, N, dtype=x.dtype, device=x.device)
+    arr = (ctypes.c_double * len(alphas))(*alphas)
+    check(lib().vc2_multi_scale_gaussian(ptr(xx), F, N, C, DTYPE_CODE[x.dtype], ptr(cc), cc.shape[0], arr,
+                                         len(alphas), ptr(out), stream_ptr(x.device)), "_multi_scale_gaussian")
+    return out
 
 
 def compute_scales(scores: torch.Tensor, base: float, temp: float = 0.01) -> torch.Tensor:
