@@ -208,6 +208,43 @@ inline float mean_T(double exact_sum, int64_t count, int dt) {
   return rT(s / float(count), dt);
 }
 
+
+// Column sum of a contiguous fp32 [rows, C] block as torch's outer reduction adds it
+// (ATen/native/cpu/SumKernel.cpp: vectorized_outer_sum -> multi_row_sum for full groups of 32 columns,
+// row_sum -- four row-interleaved chains -- for the columns after the last full group; which path the
+// tail columns take depends on how torch splits the columns over threads, the single-call rule is used).
+// `v` points at element (first row, column), `stride` = C.  Used for the half-precision centre means,
+// where ReduceOps.cpp mean_out sums an fp32 copy, divides by the count in fp32 and casts.
+float cascade_rows(const float* v, int64_t stride, int64_t step_rows, int64_t n) {   // multi_row_sum, 1 column
+  const int64_t level_power = std::max<int64_t>(4, ceil_log2_i64(n) / 4);
+  const int64_t level_step = int64_t(1) << level_power, level_mask = level_step - 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int64_t i = 0;
+  for (; i + level_step <= n;) {
+    for (int64_t j = 0; j < level_step; ++j, ++i) acc[0] += v[i * step_rows * stride];
+    for (int j = 1; j < 4; ++j) {
+      acc[j] += acc[j - 1];
+      acc[j - 1] = 0.f;
+      const int64_t mask = level_mask << (j * level_power);
+      if ((i & mask) != 0) break;
+    }
+  }
+  for (; i < n; ++i) acc[0] += v[i * step_rows * stride];
+  for (int j = 1; j < 4; ++j) acc[0] += acc[j];
+  return acc[0];
+}
+float col_sum_torch_order(const float* base, int64_t C, int64_t j, int64_t rows) {
+  const int64_t group = (C >= 8) ? 32 : 4;
+  const float* v = base + j;
+  if (j < (C / group) * group) return cascade_rows(v, C, 1, rows);
+  const int64_t size_ilp = rows / 4;                         // row_sum: rows as a (-1, 4) array
+  float part[4];
+  for (int k = 0; k < 4; ++k) part[k] = cascade_rows(v + k * C, C, 4, size_ilp);
+  for (int64_t i = size_ilp * 4; i < rows; ++i) part[0] += v[i * C];
+  for (int k = 1; k < 4; ++k) part[0] += part[k];
+  return part[0];
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,11 +335,17 @@ int vc2o_gaussian_scores_ex(const void* x, int64_t R, int64_t D, int dt, const i
     for (int64_t n = 0; n < N; ++n)
       for (int64_t j = 0; j < C; ++j)
         fsum[Z(f * C + j)] += double(xh[Z((f * N + n) * C + j)]);
+  // torch mode, half precision: the fp32 sum inside mean() is order dependent (mean_out casts to fp32,
+  // sums with the outer-reduction cascade, divides, casts back); replayed for the unsharded pass.  The
+  // frame-sharded pass only has per-rank sums of the video centre and keeps the exact sum there.
+  const bool replay = g_mode == 1 && dt != F32;
+#pragma omp parallel for schedule(static)
   for (int64_t j = 0; j < C; ++j) {
     double t = 0.0;
     for (int64_t f = 0; f < F; ++f) {
       t += fsum[Z(f * C + j)];
-      fc[Z(f * C + j)] = mean_T(fsum[Z(f * C + j)], N, dt);
+      fc[Z(f * C + j)] = replay ? rT(col_sum_torch_order(xh.data() + Z(f * N * C), C, j, N) / float(N), dt)
+                                : mean_T(fsum[Z(f * C + j)], N, dt);
     }
     if (csum_out) csum_out[j] = t;
     if (csum_in) {
@@ -310,7 +353,7 @@ int vc2o_gaussian_scores_ex(const void* x, int64_t R, int64_t D, int dt, const i
       for (int64_t p = 0; p < P; ++p) t += csum_in[p * C + j];
       vc[Z(j)] = mean_T(t, R_total, dt);
     } else {
-      vc[Z(j)] = mean_T(t, R, dt);
+      vc[Z(j)] = replay ? rT(col_sum_torch_order(xh.data(), C, j, R) / float(R), dt) : mean_T(t, R, dt);
     }
   }
   // _multi_scale_gaussian (vidcom2.py:59-62), alphas = 2^-3..2^1

@@ -20,7 +20,7 @@ CASES = load_core_cases()
 FP32_TOL = 1e-5          # north_star: "similarity scores within 1e-5 fp32"
 # The one fixture whose reference result hinges on the fp32 accumulation order of the video-centre MEAN (not
 # yet replayed; DESIGN.md "Numerics contract"): a single fp16 centre value flips, and with it a few v-scores.
-KNOWN_RESIDUE = {("cfg2", "f16", "iid", 2)}
+KNOWN_RESIDUE = set()
 
 
 @pytest.fixture(autouse=True)

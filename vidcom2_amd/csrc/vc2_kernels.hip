@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * kRedGL) void k_stats_reduce(const double* __re
                                                               double* __restrict__ stats, void* __restrict__ var_T,
                                                               float* __restrict__ var_f32, int* __restrict__ counters) {
   __shared__ double sm[2][kRedGL][64];
-  if (counters && blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;   // strict-mode queues of this pass
+  if (counters && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // strict-mode queues of this pass
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s = 0.0, q = 0.0;
@@ -352,6 +352,27 @@ template <int DT> __device__ __forceinline__ bool near_T_boundary(float y, int m
   }
 }
 
+// Centre means (vidcom2.py:51-52): for half precision torch's mean_out sums an fp32 copy with the outer-
+// reduction cascade, divides by the count in fp32 and casts.  The cascade result sits within a few fp32 ulps
+// of the exact sum (measured < 2 ulp std at 25088 rows), so only means this close to a T rounding boundary
+// are replayed (k_centre_fix).
+constexpr int kFragileUlpsMean = 16;
+
+template <int DT> __device__ __forceinline__ bool mean_near_T_boundary(float q) {
+  if constexpr (DT == VC2_F32) {
+    return false;
+  } else if constexpr (DT == VC2_BF16) {
+    return near_T_boundary<DT>(q, kFragileUlpsMean);
+  } else {
+    const float a = fabsf(q);
+    if (a < 6.103515625e-05f) {                  // fp16-subnormal result: values on the 2^-24 grid
+      const float t = a * 16777216.f;            // exact scaling
+      return fabsf((t - floorf(t)) - 0.5f) <= 0.00390625f;   // 2^-8 of a grid step >> 16 fp32 ulps of q
+    }
+    return near_T_boundary<DT>(q, kFragileUlpsMean);
+  }
+}
+
 // sqrt(sum x^2) over the sorted channel order exactly as torch accumulates it (whole wave; same result on
 // all lanes).  sv[p] = the row's selected values as fp32, ALREADY in sorted order (p = 0..C-1) in LDS.
 template <int DT>
@@ -568,6 +589,8 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   }
 }
 
+struct CFixEntry { int f; int c; };      // f < 0: the video centre
+
 // centres (compact channel space): frame_center[f][p] = mean_T(sum_n x^) and per-frame-group column
 // sums (fp64, fixed order).  grid = (ceil(C/64), ceil(F/16)); workgroup = 64 columns x 16 frames.
 constexpr int kCentreFL = 16;
@@ -580,7 +603,9 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
                                                              const void* __restrict__ x, int D,
                                                              const int* __restrict__ cols,
                                                              const int* __restrict__ corr_count,
-                                                             const NormCorr* __restrict__ corr) {
+                                                             const NormCorr* __restrict__ corr, int strict,
+                                                             int* __restrict__ cfix_count,
+                                                             CFixEntry* __restrict__ cfix_list, int cfix_cap) {
   __shared__ double sm[kCentreFL][64];
   const int cl = threadIdx.x & 63, fl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -599,6 +624,10 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
       }
     }
     fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
+    if (strict == 1 && cfix_count && mean_near_T_boundary<DT>(float(sf) / float(N))) {
+      const int j = atomicAdd(cfix_count, 1);
+      if (j < cfix_cap) { cfix_list[j].f = f; cfix_list[j].c = c; }
+    }
   }
   sm[fl][cl] = sf;
   __syncthreads();
@@ -614,7 +643,9 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
 // csum_out[c] = sum_p parts[p*stride + c] (fp64) and/or vc[c] = mean_T(that, R_total)  (vidcom2.py:51)
 template <int DT>
 __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t stride, int C, int64_t R_total,
-                             double* __restrict__ csum_out, float* __restrict__ vc, int* __restrict__ ticket) {
+                             double* __restrict__ csum_out, float* __restrict__ vc, int* __restrict__ ticket,
+                             int strict = 0, int* __restrict__ cfix_count = nullptr,
+                             CFixEntry* __restrict__ cfix_list = nullptr, int cfix_cap = 0) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [0] arrival counter of k_token_epilogue's fused
   //                                                            budget stage, [1] k_dist's strict-mode fix-up queue length
@@ -622,7 +653,124 @@ __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t s
   double t = 0.0;
   for (int p = 0; p < NP; ++p) t += parts[int64_t(p) * stride + c];
   if (csum_out) csum_out[c] = t;
-  if (vc) vc[c] = mean_T<DT>(t, R_total);
+  if (vc) {
+    vc[c] = mean_T<DT>(t, R_total);
+    if (strict == 1 && cfix_count && mean_near_T_boundary<DT>(float(t) / float(R_total))) {
+      const int j = atomicAdd(cfix_count, 1);
+      if (j < cfix_cap) { cfix_list[j].f = -1; cfix_list[j].c = c; }
+    }
+  }
+}
+
+// ---- strict mode, half precision: replay torch's fp32 outer-sum cascade for the queued centre means ------
+// SumKernel.cpp multi_row_sum over n elements: blocks of 16 added sequentially (acc0), block sums added into
+// acc1, acc1 dumped into acc2 every 256 elements, acc2 into acc3 every 4096; finally
+// ((tail + acc1) + acc2) + acc3.  (level_power = max(4, ceil_log2(n) / 4) is 4 for n <= 2^19.)
+// Every block / group sum is an independent sequential chain, so the workgroup computes them level by level.
+constexpr int kCFixNT = 1024;
+constexpr int kCFixL0 = 8192;      // level-0 block sums in LDS per super-chunk (a multiple of 256)
+
+template <int DT>
+__device__ __forceinline__ float xhat_at(const void* __restrict__ x, int64_t row, int D, int col,
+                                         const float* __restrict__ den) {
+  return rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), 1.0 / double(den[row])));
+}
+
+// elements e = 0..n-1 live at rows r0 + e * rs.  Whole workgroup; the result is valid on thread 0.
+template <int DT>
+__device__ float block_cascade(const void* __restrict__ x, int D, int col, const float* __restrict__ den,
+                               int64_t r0, int rs, int64_t n, float* L0, float* L1, float* L2) {
+  const int tid = threadIdx.x;
+  const int64_t nb = n >> 4;                                  // complete level-0 blocks
+  float acc3 = 0.f, acc2 = 0.f, acc1 = 0.f;
+  for (int64_t b0 = 0; b0 < nb; b0 += kCFixL0) {
+    const int nbc = int(min<int64_t>(kCFixL0, nb - b0));
+    for (int b = tid; b < nbc; b += kCFixNT) {
+      const int64_t e0 = (b0 + b) << 4;
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, r0 + (e0 + u) * rs, D, col, den);
+      float a = v[0];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) a += v[u];
+      L0[b] = a;
+    }
+    __syncthreads();
+    const int n1 = nbc >> 4;                                  // complete level-1 groups of this chunk
+    for (int g = tid; g < n1; g += kCFixNT) {
+      float a = L0[16 * g];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) a += L0[16 * g + u];
+      L1[g] = a;
+    }
+    __syncthreads();
+    const int n2 = n1 >> 4;                                   // complete level-2 groups
+    for (int h = tid; h < n2; h += kCFixNT) {
+      float a = L1[16 * h];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) a += L1[16 * h + u];
+      L2[h] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int h = 0; h < n2; ++h) acc3 += L2[h];
+      if (b0 + nbc == nb) {                                   // last chunk: the open groups
+        for (int g = 16 * n2; g < n1; ++g) acc2 += L1[g];
+        for (int b = 16 * n1; b < nbc; ++b) acc1 += L0[b];
+      }
+    }
+    __syncthreads();
+  }
+  float r = 0.f;
+  if (tid == 0) {
+    for (int64_t e = nb << 4; e < n; ++e) r += xhat_at<DT>(x, r0 + e * rs, D, col, den);
+    r += acc1; r += acc2; r += acc3;
+  }
+  return r;
+}
+
+// grid-stride over the queue (all != 0: over every (centre, column) pair instead -- debug mode 2).
+template <int DT>
+__global__ __launch_bounds__(kCFixNT) void k_centre_fix(const void* __restrict__ x, int F, int N, int D, int C,
+                                                        const int* __restrict__ cols,
+                                                        const int* __restrict__ spos,
+                                                        const float* __restrict__ den,
+                                                        const int* __restrict__ count,
+                                                        const CFixEntry* __restrict__ list, int cap, int all,
+                                                        int do_vid, float* __restrict__ fc,
+                                                        float* __restrict__ vc) {
+  __shared__ float L0[kCFixL0];
+  __shared__ float L1[kCFixL0 / 16];
+  __shared__ float L2[kCFixL0 / 256];
+  const int total = all ? (F + (do_vid ? 1 : 0)) * C : min(*count, cap);
+  for (int e = blockIdx.x; e < total; e += gridDim.x) {
+    int f, c;
+    if (all) { f = e / C - (do_vid ? 1 : 0); c = e % C; } else { f = list[e].f; c = list[e].c; }
+    const int64_t r0 = f < 0 ? 0 : int64_t(f) * N;
+    const int64_t rows = f < 0 ? int64_t(F) * N : N;
+    if (rows > (int64_t(1) << 19)) continue;                  // level_power 5: not replayed (exact mean kept)
+    const int col = cols ? cols[c] : c;
+    const int sp = spos ? spos[c] : c;                        // column position in torch's (sorted) layout
+    const int group = C >= 8 ? 32 : 4;
+    float s;
+    if (sp < (C / group) * group) {
+      s = block_cascade<DT>(x, D, col, den, r0, 1, rows, L0, L1, L2);
+    } else {                                                  // row_sum: four row-interleaved chains
+      const int64_t q4 = rows >> 2;
+      float part[4];
+      for (int k = 0; k < 4; ++k) part[k] = block_cascade<DT>(x, D, col, den, r0 + k, 4, q4, L0, L1, L2);
+      s = part[0];
+      if (threadIdx.x == 0) {
+        for (int64_t i = q4 << 2; i < rows; ++i) s += xhat_at<DT>(x, r0 + i, D, col, den);
+        s += part[1]; s += part[2]; s += part[3];
+      }
+    }
+    if (threadIdx.x == 0) {
+      const float q = s / float(rows);
+      if (f < 0) vc[c] = rnT<DT>(q); else fc[int64_t(f) * C + c] = rnT<DT>(q);
+    }
+    __syncthreads();
+  }
 }
 
 // RN_T of two values at once (one v_cvt_pk_* instead of two)
@@ -1105,7 +1253,8 @@ struct Plan {
   int S, rows_per_split;        // sweep-2/3 splits per frame
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_fixlist, o_nfixlist, o_corr, o_tmp_f32, total_bytes;
+      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_fixlist, o_nfixlist, o_corr, o_cfixlist, o_tmp_f32, total_bytes;
+  int cfix_cap;
 };
 
 int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
@@ -1157,6 +1306,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_fixlist = take(size_t(kMaxFix) * 4);
   p->o_nfixlist = take(size_t(p->R) * 4);
   p->o_corr = take(size_t(kMaxCorr) * sizeof(NormCorr));
+  p->cfix_cap = int(std::min<int64_t>(std::max<int64_t>(4096, F * D / 32), int64_t(1) << 22));
+  p->o_cfixlist = take(size_t(p->cfix_cap) * sizeof(CFixEntry));
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
   p->total_bytes = o;
   return VC2_OK;
@@ -1357,21 +1508,36 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
     if (rc) return rc;
   }
   { ProfScope ps_(KID_CENTRES, st);
+  const bool replay = cs.strict && p.dt != VC2_F32;           // half-precision centre means in torch's order
+  int* cfix_count = replay ? wsp<int>(ws, p.o_ticket) + 4 : (int*)nullptr;
+  CFixEntry* cfix_list = wsp<CFixEntry>(ws, p.o_cfixlist);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
                                            dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, int(p.N), C,
                                            wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols,
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
-                                           wsp<NormCorr>(ws, p.o_corr)));
+                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, cfix_count, cfix_list,
+                                           p.cfix_cap));
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
                                            cpart, FG, int64_t(C), C, p.R,
                                            single_rank ? (double*)nullptr : wsp<double>(ws, p.o_csum),
                                            single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr,
-                                           wsp<int>(ws, p.o_ticket))); }
+                                           wsp<int>(ws, p.o_ticket), cs.strict, cfix_count, cfix_list,
+                                           p.cfix_cap));
+  if (replay) {
+    const int all = cs.strict >= 2 ? 1 : 0;
+    const int64_t pairs = (p.F + (single_rank ? 1 : 0)) * int64_t(C);
+    const unsigned grid = unsigned(all ? std::min<int64_t>(pairs, 4096) : 256);
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centre_fix<DT>), dim3(grid), dim3(kCFixNT), 0, st, x, int(p.F),
+                                             int(p.N), int(p.D), C, cs.cols, cs.spos,
+                                             wsp<float>(ws, p.o_den), cfix_count, cfix_list, p.cfix_cap, all,
+                                             single_rank ? 1 : 0, wsp<float>(ws, p.o_fc),
+                                             wsp<float>(ws, p.o_vc)));
+  } }
   return check_launch("scores phase 1");
 }
 
 int zero_counters(const Plan& p, void* ws, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(wsp<int>(ws, p.o_ticket), 0, 16, st);
+  hipError_t e = hipMemsetAsync(wsp<int>(ws, p.o_ticket), 0, 32, st);
   if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
   return VC2_OK;
 }
