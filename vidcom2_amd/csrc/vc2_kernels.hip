@@ -589,7 +589,8 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   }
 }
 
-struct CFixEntry { int f; int c; };      // f < 0: the video centre
+struct CFixEntry { int f; int c; };      // queued (frame, compact column) pair
+constexpr int kCFixMaxVid = 256;        // queued video-centre columns per pass (expected: a handful)
 
 // centres (compact channel space): frame_center[f][p] = mean_T(sum_n x^) and per-frame-group column
 // sums (fp64, fixed order).  grid = (ceil(C/64), ceil(F/16)); workgroup = 64 columns x 16 frames.
@@ -644,20 +645,21 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
 template <int DT>
 __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t stride, int C, int64_t R_total,
                              double* __restrict__ csum_out, float* __restrict__ vc, int* __restrict__ ticket,
-                             int strict = 0, int* __restrict__ cfix_count = nullptr,
-                             CFixEntry* __restrict__ cfix_list = nullptr, int cfix_cap = 0) {
+                             int strict = 0, int* __restrict__ vfix_count = nullptr,
+                             int* __restrict__ vfix_list = nullptr, int* __restrict__ vticket = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [0] arrival counter of k_token_epilogue's fused
   //                                                            budget stage, [1] k_dist's strict-mode fix-up queue length
+  if (vticket && c < kCFixMaxVid) vticket[c] = 0;           // per-entry arrival counters of k_centre_fix
   if (c >= C) return;
   double t = 0.0;
   for (int p = 0; p < NP; ++p) t += parts[int64_t(p) * stride + c];
   if (csum_out) csum_out[c] = t;
   if (vc) {
     vc[c] = mean_T<DT>(t, R_total);
-    if (strict == 1 && cfix_count && mean_near_T_boundary<DT>(float(t) / float(R_total))) {
-      const int j = atomicAdd(cfix_count, 1);
-      if (j < cfix_cap) { cfix_list[j].f = -1; cfix_list[j].c = c; }
+    if (strict == 1 && vfix_count && mean_near_T_boundary<DT>(float(t) / float(R_total))) {
+      const int j = atomicAdd(vfix_count, 1);
+      if (j < kCFixMaxVid) vfix_list[j] = c;
     }
   }
 }
@@ -666,110 +668,165 @@ __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t s
 // SumKernel.cpp multi_row_sum over n elements: blocks of 16 added sequentially (acc0), block sums added into
 // acc1, acc1 dumped into acc2 every 256 elements, acc2 into acc3 every 4096; finally
 // ((tail + acc1) + acc2) + acc3.  (level_power = max(4, ceil_log2(n) / 4) is 4 for n <= 2^19.)
-// Every block / group sum is an independent sequential chain, so the workgroup computes them level by level.
-constexpr int kCFixNT = 1024;
-constexpr int kCFixL0 = 8192;      // level-0 block sums in LDS per super-chunk (a multiple of 256)
+// Every block / group sum is an independent sequential chain.  Work item = one level-1 group (16 blocks = 256
+// rows) of one queued column, done by one wave: 16 lanes each add one block's 16 values in order, then the 16
+// block sums are added in order.  A frame-centre entry (N rows, usually one group) is finished by its wave
+// alone; the ~100 groups of a video-centre entry are spread over the grid (the 25088 strided 2-byte loads of
+// one column would take one CU ~40 us) and the last wave to arrive -- agent-scope release / acquire on a
+// per-entry ticket, CDNA guide G16 -- combines them.
+constexpr int kCFixWaves = 4;
+constexpr int kCFixSolo = 512;       // level-1 groups a single wave may hold (rows <= 131072)
 
 template <int DT>
 __device__ __forceinline__ float xhat_at(const void* __restrict__ x, int64_t row, int D, int col,
                                          const float* __restrict__ den) {
-  return rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), 1.0 / double(den[row])));
+  // one quotient per row here, so the IEEE fp32 division itself (same value as div_via_f64, see there)
+  return rnT<DT>(ldT<DT>(x, row * D + col) / den[row]);
 }
 
-// elements e = 0..n-1 live at rows r0 + e * rs.  Whole workgroup; the result is valid on thread 0.
+// sum of the level-0 sums of blocks [first_block, first_block + nbl), nbl <= 16, elements at rows r0 + e*rs
 template <int DT>
-__device__ float block_cascade(const void* __restrict__ x, int D, int col, const float* __restrict__ den,
-                               int64_t r0, int rs, int64_t n, float* L0, float* L1, float* L2) {
-  const int tid = threadIdx.x;
-  const int64_t nb = n >> 4;                                  // complete level-0 blocks
-  float acc3 = 0.f, acc2 = 0.f, acc1 = 0.f;
-  for (int64_t b0 = 0; b0 < nb; b0 += kCFixL0) {
-    const int nbc = int(min<int64_t>(kCFixL0, nb - b0));
-    for (int b = tid; b < nbc; b += kCFixNT) {
-      const int64_t e0 = (b0 + b) << 4;
-      float v[16];
+__device__ float wave_l1_group(const void* __restrict__ x, int D, int col, const float* __restrict__ den,
+                               int64_t r0, int rs, int64_t first_block, int nbl, int lane) {
+  float a = 0.f;
+  if (lane < nbl) {
+    const int64_t e0 = (first_block + lane) << 4;
+    float v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, r0 + (e0 + u) * rs, D, col, den);
-      float a = v[0];
+    for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, r0 + (e0 + u) * rs, D, col, den);
+    a = v[0];
 #pragma unroll
-      for (int u = 1; u < 16; ++u) a += v[u];
-      L0[b] = a;
-    }
-    __syncthreads();
-    const int n1 = nbc >> 4;                                  // complete level-1 groups of this chunk
-    for (int g = tid; g < n1; g += kCFixNT) {
-      float a = L0[16 * g];
-#pragma unroll
-      for (int u = 1; u < 16; ++u) a += L0[16 * g + u];
-      L1[g] = a;
-    }
-    __syncthreads();
-    const int n2 = n1 >> 4;                                   // complete level-2 groups
-    for (int h = tid; h < n2; h += kCFixNT) {
-      float a = L1[16 * h];
-#pragma unroll
-      for (int u = 1; u < 16; ++u) a += L1[16 * h + u];
-      L2[h] = a;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int h = 0; h < n2; ++h) acc3 += L2[h];
-      if (b0 + nbc == nb) {                                   // last chunk: the open groups
-        for (int g = 16 * n2; g < n1; ++g) acc2 += L1[g];
-        for (int b = 16 * n1; b < nbc; ++b) acc1 += L0[b];
-      }
-    }
-    __syncthreads();
+    for (int u = 1; u < 16; ++u) a += v[u];
   }
+  float s = __shfl(a, 0, 64);
+  for (int u = 1; u < nbl; ++u) s += __shfl(a, u, 64);
+  return s;
+}
+
+// ((tail + acc1) + acc2) + acc3 from the level-1 values l1[0 .. ceil(nb/16)) (same result on every lane)
+template <int DT>
+__device__ float wave_cascade_final(const float* l1, int64_t nb, const void* __restrict__ x, int D, int col,
+                                    const float* __restrict__ den, int64_t r0, int rs, int64_t n, int lane) {
+  const int n1c = int(nb >> 4);                               // complete level-1 groups
+  const int n2 = n1c >> 4;                                    // complete level-2 groups
+  float acc3 = 0.f;
+  for (int h0 = 0; h0 < n2; h0 += 64) {
+    const int h = h0 + lane;
+    float a = 0.f;
+    if (h < n2) {
+      a = l1[16 * h];
+      for (int u = 1; u < 16; ++u) a += l1[16 * h + u];
+    }
+    const int cnt = min(64, n2 - h0);
+    for (int u = 0; u < cnt; ++u) acc3 += __shfl(a, u, 64);
+  }
+  float acc2 = 0.f;
+  for (int g = 16 * n2; g < n1c; ++g) acc2 += l1[g];
+  const float acc1 = (nb & 15) ? l1[n1c] : 0.f;
   float r = 0.f;
-  if (tid == 0) {
-    for (int64_t e = nb << 4; e < n; ++e) r += xhat_at<DT>(x, r0 + e * rs, D, col, den);
-    r += acc1; r += acc2; r += acc3;
-  }
+  for (int64_t e = nb << 4; e < n; ++e) r += xhat_at<DT>(x, r0 + e * rs, D, col, den);
+  r += acc1; r += acc2; r += acc3;
   return r;
 }
 
-// grid-stride over the queue (all != 0: over every (centre, column) pair instead -- debug mode 2).
+// one chain (n elements at rows r0 + e*rs) by ONE wave; needs ceil((n/16)/16) <= kCFixSolo
 template <int DT>
-__global__ __launch_bounds__(kCFixNT) void k_centre_fix(const void* __restrict__ x, int F, int N, int D, int C,
-                                                        const int* __restrict__ cols,
-                                                        const int* __restrict__ spos,
-                                                        const float* __restrict__ den,
-                                                        const int* __restrict__ count,
-                                                        const CFixEntry* __restrict__ list, int cap, int all,
-                                                        int do_vid, float* __restrict__ fc,
-                                                        float* __restrict__ vc) {
-  __shared__ float L0[kCFixL0];
-  __shared__ float L1[kCFixL0 / 16];
-  __shared__ float L2[kCFixL0 / 256];
-  const int total = all ? (F + (do_vid ? 1 : 0)) * C : min(*count, cap);
-  for (int e = blockIdx.x; e < total; e += gridDim.x) {
-    int f, c;
-    if (all) { f = e / C - (do_vid ? 1 : 0); c = e % C; } else { f = list[e].f; c = list[e].c; }
-    const int64_t r0 = f < 0 ? 0 : int64_t(f) * N;
-    const int64_t rows = f < 0 ? int64_t(F) * N : N;
-    if (rows > (int64_t(1) << 19)) continue;                  // level_power 5: not replayed (exact mean kept)
-    const int col = cols ? cols[c] : c;
-    const int sp = spos ? spos[c] : c;                        // column position in torch's (sorted) layout
-    const int group = C >= 8 ? 32 : 4;
-    float s;
-    if (sp < (C / group) * group) {
-      s = block_cascade<DT>(x, D, col, den, r0, 1, rows, L0, L1, L2);
-    } else {                                                  // row_sum: four row-interleaved chains
-      const int64_t q4 = rows >> 2;
-      float part[4];
-      for (int k = 0; k < 4; ++k) part[k] = block_cascade<DT>(x, D, col, den, r0 + k, 4, q4, L0, L1, L2);
-      s = part[0];
-      if (threadIdx.x == 0) {
-        for (int64_t i = q4 << 2; i < rows; ++i) s += xhat_at<DT>(x, r0 + i, D, col, den);
-        s += part[1]; s += part[2]; s += part[3];
-      }
+__device__ float wave_cascade_solo(float* l1s, const void* __restrict__ x, int D, int col,
+                                   const float* __restrict__ den, int64_t r0, int rs, int64_t n, int lane) {
+  const int64_t nb = n >> 4;
+  const int G = int((nb + 15) >> 4);
+  for (int g = 0; g < G; ++g) {
+    const float v = wave_l1_group<DT>(x, D, col, den, r0, rs, int64_t(g) << 4, int(min<int64_t>(16, nb - (int64_t(g) << 4))), lane);
+    if (lane == 0) l1s[g] = v;
+  }
+  wave_lds_fence();
+  const float r = wave_cascade_final<DT>(l1s, nb, x, D, col, den, r0, rs, n, lane);
+  wave_lds_fence();
+  return r;
+}
+
+// a whole column sum in torch's order by one wave: simple cascade, or row_sum's four interleaved chains
+template <int DT>
+__device__ float wave_column_solo(float* l1s, bool simple, const void* __restrict__ x, int D, int col,
+                                  const float* __restrict__ den, int64_t r0, int64_t rows, int lane) {
+  if (simple) return wave_cascade_solo<DT>(l1s, x, D, col, den, r0, 1, rows, lane);
+  const int64_t q4 = rows >> 2;
+  float part[4];
+  for (int k = 0; k < 4; ++k) part[k] = wave_cascade_solo<DT>(l1s, x, D, col, den, r0 + k, 4, q4, lane);
+  float s = part[0];
+  for (int64_t i = q4 << 2; i < rows; ++i) s += xhat_at<DT>(x, r0 + i, D, col, den);
+  s += part[1]; s += part[2]; s += part[3];
+  return s;
+}
+
+// counts[0] / flist: queued frame-centre entries; counts[1] / vlist: queued video-centre columns.
+// all != 0 (debug mode 2): every (frame, column) pair and every video column instead of the queues.
+template <int DT>
+__global__ __launch_bounds__(kCFixWaves * 64) void k_centre_fix(const void* __restrict__ x, int F, int N, int D,
+                                                                int C, const int* __restrict__ cols,
+                                                                const int* __restrict__ spos,
+                                                                const float* __restrict__ den,
+                                                                const int* __restrict__ counts,
+                                                                const CFixEntry* __restrict__ flist, int fcap,
+                                                                const int* __restrict__ vlist, int all, int do_vid,
+                                                                float* __restrict__ vscratch, int vstride,
+                                                                int* __restrict__ vticket,
+                                                                float* __restrict__ fc, float* __restrict__ vc) {
+  __shared__ float l1s_all[kCFixWaves][kCFixSolo];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* l1s = l1s_all[wave];
+  const int64_t R = int64_t(F) * N;
+  const int group = C >= 8 ? 32 : 4;
+  const int simple_end = (C / group) * group;
+  const int nf = all ? F * C : min(counts[0], fcap);
+  int nv = !do_vid ? 0 : (all ? C : min(counts[1], kCFixMaxVid));
+  if (R > (int64_t(1) << 19)) nv = 0;                         // level_power 5: not replayed (exact mean kept)
+  const int64_t nbv = R >> 4;
+  const int G1v = int((nbv + 15) >> 4);
+  const bool multi = !all && G1v > 1;
+  const int64_t items = int64_t(nf) + (multi ? int64_t(nv) * G1v : int64_t(nv));
+  const int64_t nw = int64_t(gridDim.x) * kCFixWaves;
+  for (int64_t it = int64_t(blockIdx.x) * kCFixWaves + wave; it < items; it += nw) {
+    if (it < nf) {                                            // ---- frame-centre entry, one wave
+      int f, c;
+      if (all) { f = int(it / C); c = int(it % C); } else { f = flist[it].f; c = flist[it].c; }
+      const int col = cols ? cols[c] : c, sp = spos ? spos[c] : c;
+      if (((N >> 4) + 15) >> 4 > kCFixSolo) continue;
+      const float s = wave_column_solo<DT>(l1s, sp < simple_end, x, D, col, den, int64_t(f) * N, N, lane);
+      if (lane == 0) fc[int64_t(f) * C + c] = rnT<DT>(s / float(N));
+      continue;
     }
-    if (threadIdx.x == 0) {
-      const float q = s / float(rows);
-      if (f < 0) vc[c] = rnT<DT>(q); else fc[int64_t(f) * C + c] = rnT<DT>(q);
+    const int64_t j = it - nf;
+    const int v = multi ? int(j / G1v) : int(j);
+    const int g = multi ? int(j % G1v) : 0;
+    const int c = all ? v : vlist[v];
+    const int col = cols ? cols[c] : c, sp = spos ? spos[c] : c;
+    const bool simple = sp < simple_end;
+    if (!multi || !simple) {                                  // ---- video-centre column, one wave
+      if (g != 0) continue;
+      if ((simple ? G1v : int((((R >> 2) >> 4) + 15) >> 4)) > kCFixSolo) continue;
+      const float s = wave_column_solo<DT>(l1s, simple, x, D, col, den, 0, R, lane);
+      if (lane == 0) vc[c] = rnT<DT>(s / float(R));
+      continue;
     }
-    __syncthreads();
+    // ---- one level-1 group of a video-centre column; the last wave to finish combines
+    const float l1 = wave_l1_group<DT>(x, D, col, den, 0, 1, int64_t(g) << 4,
+                                       int(min<int64_t>(16, nbv - (int64_t(g) << 4))), lane);
+    int last = 0;
+    if (lane == 0) {
+      vscratch[int64_t(v) * vstride + g] = l1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int t0 = __hip_atomic_fetch_add(vticket + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t0 == G1v - 1) ? 1 : 0;
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    last = __shfl(last, 0, 64);
+    if (last) {
+      const float* l1p = vscratch + int64_t(v) * vstride;
+      const float s = wave_cascade_final<DT>(l1p, nbv, x, D, col, den, 0, 1, R, lane);
+      if (lane == 0) vc[c] = rnT<DT>(s / float(R));
+    }
   }
 }
 
@@ -1253,8 +1310,8 @@ struct Plan {
   int S, rows_per_split;        // sweep-2/3 splits per frame
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_fixlist, o_nfixlist, o_corr, o_cfixlist, o_tmp_f32, total_bytes;
-  int cfix_cap;
+      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_fixlist, o_nfixlist, o_corr, o_cfixlist, o_vfixlist, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
+  int cfix_cap, vstride;
 };
 
 int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
@@ -1308,6 +1365,10 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_corr = take(size_t(kMaxCorr) * sizeof(NormCorr));
   p->cfix_cap = int(std::min<int64_t>(std::max<int64_t>(4096, F * D / 32), int64_t(1) << 22));
   p->o_cfixlist = take(size_t(p->cfix_cap) * sizeof(CFixEntry));
+  p->o_vfixlist = take(size_t(kCFixMaxVid) * 4);
+  p->vstride = int(cdiv(cdiv(std::min<int64_t>(p->R, int64_t(1) << 19), 16), 16) + 1);
+  p->o_vscratch = take(size_t(kCFixMaxVid) * p->vstride * 4);
+  p->o_vticket = take(size_t(kCFixMaxVid) * 4);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
   p->total_bytes = o;
   return VC2_OK;
@@ -1517,21 +1578,23 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
                                            wsp<NormCorr>(ws, p.o_corr), cs.strict, cfix_count, cfix_list,
                                            p.cfix_cap));
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
-                                           cpart, FG, int64_t(C), C, p.R,
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(std::max(C, kCFixMaxVid), 128))),
+                                           dim3(128), 0, st, cpart, FG, int64_t(C), C, p.R,
                                            single_rank ? (double*)nullptr : wsp<double>(ws, p.o_csum),
                                            single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr,
-                                           wsp<int>(ws, p.o_ticket), cs.strict, cfix_count, cfix_list,
-                                           p.cfix_cap));
+                                           wsp<int>(ws, p.o_ticket), cs.strict,
+                                           replay ? cfix_count + 1 : (int*)nullptr, wsp<int>(ws, p.o_vfixlist),
+                                           replay ? wsp<int>(ws, p.o_vticket) : (int*)nullptr));
   if (replay) {
     const int all = cs.strict >= 2 ? 1 : 0;
     const int64_t pairs = (p.F + (single_rank ? 1 : 0)) * int64_t(C);
-    const unsigned grid = unsigned(all ? std::min<int64_t>(pairs, 4096) : 256);
-    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centre_fix<DT>), dim3(grid), dim3(kCFixNT), 0, st, x, int(p.F),
-                                             int(p.N), int(p.D), C, cs.cols, cs.spos,
-                                             wsp<float>(ws, p.o_den), cfix_count, cfix_list, p.cfix_cap, all,
-                                             single_rank ? 1 : 0, wsp<float>(ws, p.o_fc),
-                                             wsp<float>(ws, p.o_vc)));
+    const unsigned grid = unsigned(all ? std::min<int64_t>(cdiv(pairs, kCFixWaves), 8192) : 512);
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centre_fix<DT>), dim3(grid), dim3(kCFixWaves * 64), 0, st, x,
+                                             int(p.F), int(p.N), int(p.D), C, cs.cols, cs.spos,
+                                             wsp<float>(ws, p.o_den), cfix_count, cfix_list, p.cfix_cap,
+                                             wsp<int>(ws, p.o_vfixlist), all, single_rank ? 1 : 0,
+                                             wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
+                                             wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_vc)));
   } }
   return check_launch("scores phase 1");
 }
