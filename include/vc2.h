@@ -46,11 +46,12 @@ extern "C" {
 const char* vc2_last_error(void);
 const char* vc2_version(void);
 
-/* Accumulation semantics of the two fp32-accumulated reductions of the reference (token L2 norm,
- * squared-distance sums) in half precision:
- *   1 (default)  "torch order": wherever the exactly computed value lies within 128 fp32-ulps of a T rounding
- *                boundary, torch's own CPU accumulation order (8 interleaved fp32 chains over the variance-sorted
- *                channels / cascade sum) is replayed for that token -> bit-exact to the CPU reference;
+/* Accumulation semantics of the reference's fp32-accumulated reductions in half precision (token L2 norm,
+ * squared-distance row sums, centre means):
+ *   1 (default)  "torch order": wherever the exactly computed value lies within a few fp32-ulps (128 / 48 / 16)
+ *                of a T rounding boundary, torch's own CPU accumulation order (8 interleaved fp32 chains over the
+ *                variance-sorted channels / cascade sum / outer-sum cascade over the rows) is replayed for that
+ *                token or centre element -> bit-exact to the CPU reference;
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
  * fp32 inputs are unaffected.  Process-wide. */
 int vc2_set_mode(int mode);
