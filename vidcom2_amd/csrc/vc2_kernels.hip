@@ -1113,19 +1113,12 @@ __global__ __launch_bounds__(kMsgWaves * 64) void k_multi_scale_gaussian(const v
   }
 }
 
-// When `ticket` is given (single-GPU fused pass) the LAST workgroup to finish also runs the budget stage
-// (compute_scales over all F frame scores), saving a kernel boundary.  Hand-off per the CDNA guide G16:
-// s_out stores -> agent-scope release -> relaxed ticket; the last arriver does one agent-scope acquire.
-// The ticket word is zeroed by k_vid_centre earlier in the same pass (ordered by kernel boundaries).
 template <int DT>
 __global__ __launch_bounds__(256) void k_token_epilogue(const float* __restrict__ dv,
                                                         const float* __restrict__ df, int N,
                                                         void* __restrict__ v_T, void* __restrict__ f_T,
-                                                        float* __restrict__ total, float* __restrict__ s_out,
-                                                        int F, int* __restrict__ ticket, float base, float temp,
-                                                        float* __restrict__ zbuf, float* __restrict__ scales_f32) {
+                                                        float* __restrict__ total, float* __restrict__ s_out) {
   __shared__ double sm[4];
-  __shared__ int is_last;
   const int f = blockIdx.x;
   double acc = 0.0;
   for (int n = threadIdx.x; n < N; n += 256) {
@@ -1140,20 +1133,7 @@ __global__ __launch_bounds__(256) void k_token_epilogue(const float* __restrict_
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const double t = sm[0] + sm[1] + sm[2] + sm[3];
-    s_out[f] = -mean_T<DT>(t, N);
-    if (ticket) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int t0 = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = (t0 == F - 1) ? 1 : 0;
-      if (t0 == F - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-  }
-  if (!ticket) return;
-  __syncthreads();
-  if (is_last) scales_body<DT>(s_out, F, base, temp, zbuf, scales_f32, nullptr);
+  if (threadIdx.x == 0) s_out[f] = -mean_T<DT>(sm[0] + sm[1] + sm[2] + sm[3], N);
 }
 
 // k_f = clamp_min(long(round(RN_T(scale_f * tpf))), 1)   (vidcom2.py:72)
@@ -1384,10 +1364,12 @@ int check_launch(const char* what) {
 
 // ---- optional per-kernel timing (bench.py's roofline leg): hipEvents around every launch --------
 enum KernelId { KID_STATS = 0, KID_STATS_REDUCE, KID_CHAN_SELECT, KID_NORM_COLSUM, KID_CENTRES, KID_DIST,
-                KID_EPILOGUE, KID_SCALES, KID_KS, KID_SELECT, KID_GATHER_ROWS, KID_OTHER, KID_CHAN_ORDER, KID_COUNT };
+                KID_EPILOGUE, KID_SCALES, KID_KS, KID_SELECT, KID_GATHER_ROWS, KID_OTHER, KID_CHAN_ORDER, KID_DIST_FIX,
+                KID_CENTRE_FIX, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"k_chan_stats", "k_stats_reduce", "k_chan_select", "k_norm_colsum",
                                              "k_centres", "k_dist", "k_token_epilogue", "k_scales", "k_ks(unused)",
-                                             "k_select", "k_gather_rows", "k_norm_fix", "k_chan_select(order; side stream)"};
+                                             "k_select", "k_gather_rows", "k_norm_fix", "k_chan_select(order; side stream)",
+                                             "k_dist_fix", "k_centre_fix"};
 struct ProfRec { int id; hipEvent_t a, b; };
 bool g_prof = false;
 std::vector<ProfRec> g_prof_recs;
@@ -1518,12 +1500,14 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hip
   const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 32;
   int rc = allow_big_lds(&k_dist<DT, VEC, NPLB>, smem, "k_dist");
   if (rc) return rc;
+  { ProfScope ps_(KID_DIST, st);
   hipLaunchKernelGGL((k_dist<DT, VEC, NPLB>), dim3(unsigned(p.F * S2)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
                      int(p.D), p.CV, C, cols, cs.spos, cs.strict, S2, int(rps), wsp<float>(ws, p.o_den),
                      wsp<float>(ws, p.o_vc),
                      wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df),
-                     wsp<int>(ws, p.o_ticket) + 1, wsp<int>(ws, p.o_fixlist));
+                     wsp<int>(ws, p.o_ticket) + 1, wsp<int>(ws, p.o_fixlist)); }
   if (cs.strict) {
+    ProfScope ps_(KID_DIST_FIX, st);
     // fix-up of the queued boundary-fragile sums (the queue length is only known on the device: launch a
     // fixed number of single-wave workgroups, the surplus ones exit at once)
     const size_t smem1 = std::max(row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16);   // row, then C fp32
@@ -1585,7 +1569,11 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            wsp<int>(ws, p.o_ticket), cs.strict,
                                            replay ? cfix_count + 1 : (int*)nullptr, wsp<int>(ws, p.o_vfixlist),
                                            replay ? wsp<int>(ws, p.o_vticket) : (int*)nullptr));
-  if (replay) {
+  }
+  if (cs.strict && p.dt != VC2_F32) {
+    ProfScope ps_(KID_CENTRE_FIX, st);
+    int* cfix_count = wsp<int>(ws, p.o_ticket) + 4;
+    CFixEntry* cfix_list = wsp<CFixEntry>(ws, p.o_cfixlist);
     const int all = cs.strict >= 2 ? 1 : 0;
     const int64_t pairs = (p.F + (single_rank ? 1 : 0)) * int64_t(C);
     const unsigned grid = unsigned(all ? std::min<int64_t>(cdiv(pairs, kCFixWaves), 8192) : 512);
@@ -1595,7 +1583,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                              wsp<int>(ws, p.o_vfixlist), all, single_rank ? 1 : 0,
                                              wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
                                              wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_vc)));
-  } }
+  }
   return check_launch("scores phase 1");
 }
 
@@ -1605,22 +1593,17 @@ int zero_counters(const Plan& p, void* ws, hipStream_t st) {
   return VC2_OK;
 }
 
-// budget_base >= 0: the epilogue's last workgroup also computes the scales (single-GPU fused pass).
 int launch_phase2(const Plan& p, const void* x, const ChanSet& cs, void* ws, void* v_T, void* f_T,
-                  float* total, float* s, hipStream_t st, double budget_base = -1.0) {
+                  float* total, float* s, hipStream_t st) {
   const int C = cs.C;
-  { ProfScope ps_(KID_DIST, st);
-  int rc = VC2_OK;
+  { int rc = VC2_OK;
   const int npl = int(cdiv(C, 64));
   VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cs, ws, st));
   if (rc) return rc; }
   { ProfScope ps_(KID_EPILOGUE, st);
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
                                            wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df), int(p.N), v_T, f_T,
-                                           total, s, int(p.F),
-                                           budget_base >= 0 ? wsp<int>(ws, p.o_ticket) : (int*)nullptr,
-                                           float(budget_base), 0.01f, wsp<float>(ws, p.o_zbuf),
-                                           wsp<float>(ws, p.o_scales_f32))); }
+                                           total, s)); }
   return check_launch("scores phase 2");
 }
 
@@ -1919,9 +1902,13 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   if ((rc = launch_phase1(p, x, cs, ws, true, st, join))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* s = wsp<float>(ws, p.o_s);
-  if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st, base_scale < 0 ? 0.0 : base_scale)))
-    return rc;
   float* scales = wsp<float>(ws, p.o_scales_f32);
+  if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st))) return rc;
+  // budgets in their own small kernel: fusing them into the epilogue's last workgroup (agent-scope release /
+  // acquire ticket) measured 2 us SLOWER than this kernel boundary -- the release fences write back L2
+  if ((rc = launch_scales(dtype, s, F, base_scale < 0 ? 0.0 : base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales,
+                          nullptr, st)))
+    return rc;
   if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
                           cap, K_out, st)))
     return rc;
