@@ -177,12 +177,17 @@ class Recorder(torch.nn.Module):
 
 
 def make_qwen_vl_model(family: str, D: int, dtype, device, seed: int):
-    """`family` in {"qwen2_5_vl", "qwen2_vl"} -> (model, recorder)."""
+    """`family` in {"qwen2_5_vl", "qwen2_vl", "qwen3_vl"} -> (model, recorder)."""
     if family == "qwen2_5_vl":
         from transformers.models.qwen2_5_vl import Qwen2_5_VLConfig as Cfg
         from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLModel as Model
         vision = dict(depth=1, hidden_size=32, intermediate_size=32, num_heads=2, out_hidden_size=D,
                       fullatt_block_indexes=[0], spatial_merge_size=2)
+    elif family == "qwen3_vl":
+        from transformers.models.qwen3_vl import Qwen3VLConfig as Cfg
+        from transformers.models.qwen3_vl.modeling_qwen3_vl import Qwen3VLModel as Model
+        vision = dict(depth=1, hidden_size=32, intermediate_size=32, num_heads=2, out_hidden_size=D,
+                      spatial_merge_size=2, deepstack_visual_indexes=[0], num_position_embeddings=16)
     else:
         from transformers.models.qwen2_vl import Qwen2VLConfig as Cfg
         from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLModel as Model
@@ -203,14 +208,27 @@ def make_qwen_vl_model(family: str, D: int, dtype, device, seed: int):
     return model, rec
 
 
-def set_video_features(model, feats_per_video):
-    """Make the model's video tower deliver `feats_per_video` (list of [n_i, D])."""
-    out = SimpleNamespace(pooler_output=tuple(feats_per_video))
+def set_video_features(model, feats_per_video, deepstack=None):
+    """Make the model's video tower deliver `feats_per_video` (list of [n_i, D]) and, for Qwen3-VL, the
+    per-layer deepstack features (list of [sum n_i, D])."""
+    out = SimpleNamespace(pooler_output=tuple(feats_per_video), deepstack_features=deepstack)
     model.__dict__["get_video_features"] = lambda *a, **k: out
 
 
-def qwen_prompt(n_prefix: int, video_lens, n_between: int, n_suffix: int, seed: int) -> torch.Tensor:
+def set_image_features(model, feats_per_image, deepstack=None):
+    out = SimpleNamespace(pooler_output=tuple(feats_per_image), deepstack_features=deepstack)
+    model.__dict__["get_image_features"] = lambda *a, **k: out
+
+
+def deepstack_feats(n: int, D: int, dtype, seed: int, layers: int = 2):
+    """Synthetic per-layer deepstack features [n, D] (stream ids 44+)."""
+    return [synth.to_torch(synth.gauss(seed, 44 + l, 0, n * D).reshape(n, D), dtype) for l in range(layers)]
+
+
+def qwen_prompt(n_prefix: int, video_lens, n_between: int, n_suffix: int, seed: int, n_image: int = 0) -> torch.Tensor:
     parts = [text_ids(n_prefix, seed)]
+    if n_image:
+        parts += [torch.full((n_image,), IMAGE_ID, dtype=torch.int64), text_ids(2, seed + 300)]
     for i, n in enumerate(video_lens):
         if i:
             parts.append(text_ids(n_between, seed + 100 + i))
@@ -239,7 +257,7 @@ def qwen_inputs(c):
         n = (h * w) // 4
         feats.append(video_feats(t, n, c["D"], dtype, c["seed"] + i).reshape(t * n, c["D"]))
         lens.append(t * n)
-    ids = qwen_prompt(c["prefix"], lens, c["between"], c["suffix"], c["seed"])
+    ids = qwen_prompt(c["prefix"], lens, c["between"], c["suffix"], c["seed"], c.get("n_image", 0))
     L = ids.shape[1]
     pos = torch.arange(L).view(1, 1, L).expand(3, 1, L).contiguous()
     if c["mask"] == "2d":

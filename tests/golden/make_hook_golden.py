@@ -63,6 +63,14 @@ QWEN25_CASES = [
 ]
 
 
+QWEN3_CASES = [
+    dict(name="video_only_bf16", D=128, dt="bf16", seed=31, r="0.25", grids=[[8, 12, 12]], prefix=11, between=0,
+         suffix=6, mask="2d", n_image=0),
+    dict(name="image_and_two_videos_f32", D=64, dt="f32", seed=32, r="0.4", grids=[[4, 8, 8], [6, 12, 8]], prefix=5,
+         between=3, suffix=4, mask="4d", n_image=9),
+]
+
+
 def run_llava():
     from llava.model.llava_arch import LlavaMetaForCausalLM
     from token_compressor.vidcom2.models.llava import cus_prepare_inputs_labels_for_multimodal as ref_hook
@@ -143,8 +151,64 @@ def run_qwen25():
     return out
 
 
+def run_qwen3():
+    import transformers.models.qwen3_vl.modeling_qwen3_vl as hf
+    if not hasattr(hf, "is_torchdynamo_compiling"):
+        hf.is_torchdynamo_compiling = lambda: False
+    from token_compressor.vidcom2.models.qwen3_vl import Qwen3VLModel_forward as ref_forward
+
+    out = []
+    for c in QWEN3_CASES:
+        os.environ["R_RATIO"], os.environ["COMPRESSOR"] = c["r"], "vidcom2"
+        dtype = S.DT[c["dt"]]
+        ids, feats, pos, mask = S.qwen_inputs(c)
+        n_vid = sum(f.shape[0] for f in feats)
+        table = S.embed_table(c["D"], dtype, c["seed"])
+        deep_v = S.deepstack_feats(n_vid, c["D"], dtype, c["seed"])
+        img = S.video_feats(1, c["n_image"], c["D"], dtype, c["seed"] + 9)[0] if c["n_image"] else None
+        deep_i = S.deepstack_feats(c["n_image"], c["D"], dtype, c["seed"] + 9) if c["n_image"] else None
+        seen = {}
+
+        class Self:
+            config = SimpleNamespace(video_token_id=S.VIDEO_ID, image_token_id=S.IMAGE_ID)
+            visual = SimpleNamespace(spatial_merge_size=2)
+            rope_deltas = None
+
+            def get_input_embeddings(self):
+                return lambda i: table[i]
+
+            def get_video_features(self, pv, grid):
+                return tuple(feats), deep_v
+
+            def get_image_features(self, pv, grid):
+                return (img,), deep_i
+
+            def get_placeholder_mask(self, input_ids, inputs_embeds, image_features=None, video_features=None):
+                im = (input_ids == S.IMAGE_ID).unsqueeze(-1).expand_as(inputs_embeds)
+                vm = (input_ids == S.VIDEO_ID).unsqueeze(-1).expand_as(inputs_embeds)
+                return im, vm
+
+            def language_model(self, **kw):
+                seen.update(kw)
+                return SimpleNamespace(last_hidden_state=kw["inputs_embeds"], past_key_values=None)
+
+        ref_forward(Self(), input_ids=ids, attention_mask=mask, position_ids=pos,
+                    pixel_values=torch.zeros(1, 4) if c["n_image"] else None,
+                    image_grid_thw=torch.tensor([[1, 6, 6]]) if c["n_image"] else None,
+                    pixel_values_videos=torch.zeros(1, 4), video_grid_thw=torch.tensor(c["grids"]))
+        keep = seen["position_ids"][0, 0].tolist()
+        out.append(dict(c, seq_len=ids.shape[1], keep_token_indices=keep, embeds_sha=sha(seen["inputs_embeds"]),
+                        mask_sha=None if mask is None else sha(seen["attention_mask"]),
+                        mask_shape=None if mask is None else list(seen["attention_mask"].shape),
+                        vpm_sha=sha(seen["visual_pos_masks"].to(torch.uint8)),
+                        deep_shapes=[list(d.shape) for d in seen["deepstack_visual_embeds"]],
+                        deep_sha=[sha(d) for d in seen["deepstack_visual_embeds"]]))
+        print("qwen3_vl", c["name"], ids.shape[1], "->", len(keep), out[-1]["deep_shapes"])
+    return out
+
+
 def main():
-    cases = dict(llava=run_llava(), qwen2_5_vl=run_qwen25())
+    cases = dict(llava=run_llava(), qwen2_5_vl=run_qwen25(), qwen3_vl=run_qwen3())
     with open(os.path.join(HERE, "hook_cases.json"), "w") as f:
         json.dump(cases, f, indent=1)
     print("wrote hook_cases.json")

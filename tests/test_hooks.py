@@ -379,8 +379,60 @@ def test_install_binds_by_family(monkeypatch):
     assert install(q25) and q25.forward.__func__ is Qwen2_5_VLModel_forward
     q2, _ = S.make_qwen_vl_model("qwen2_vl", 64, torch.float32, "cpu", 1)
     assert install(q2) and q2.forward.__func__ is Qwen2VLModel_forward
+    from vidcom2_amd.models.qwen3_vl import Qwen3VLModel_forward
+    q3, _ = S.make_qwen_vl_model("qwen3_vl", 64, torch.float32, "cpu", 1)
+    assert install(q3) and q3.forward.__func__ is Qwen3VLModel_forward
     wrapper = type("FakeForConditionalGeneration", (), {})()
     wrapper.model = S.make_qwen_vl_model("qwen2_5_vl", 64, torch.float32, "cpu", 1)[0]
     assert install(wrapper) and wrapper.model.forward.__func__ is Qwen2_5_VLModel_forward
     with pytest.raises(TypeError):
         install(object.__new__(type("Other", (), {})))
+
+
+# ------------------------------------------------------------------------------------------
+# Qwen3-VL (installed transformers' real Qwen3VLModel; deepstack features pruned with the prompt)
+# ------------------------------------------------------------------------------------------
+def _run_qwen3(c, device):
+    from vidcom2_amd.models.qwen3_vl import Qwen3VLModel_forward as hook
+    os.environ["R_RATIO"], os.environ["COMPRESSOR"] = c["r"], "vidcom2"
+    dtype = S.DT[c["dt"]]
+    ids, feats, pos, mask = S.qwen_inputs(c)
+    n_vid = sum(f.shape[0] for f in feats)
+    model, rec = S.make_qwen_vl_model("qwen3_vl", c["D"], dtype, device, c["seed"])
+    S.set_video_features(model, [f.to(device) for f in feats],
+                         [d.to(device) for d in S.deepstack_feats(n_vid, c["D"], dtype, c["seed"])])
+    kwargs = dict(input_ids=ids.to(device), attention_mask=None if mask is None else mask.to(device),
+                  position_ids=pos.to(device), pixel_values_videos=torch.zeros(1, 4, device=device),
+                  video_grid_thw=torch.tensor(c["grids"], device=device))
+    if c["n_image"]:
+        img = S.video_feats(1, c["n_image"], c["D"], dtype, c["seed"] + 9)[0].to(device)
+        S.set_image_features(model, [img], [d.to(device) for d in
+                                            S.deepstack_feats(c["n_image"], c["D"], dtype, c["seed"] + 9)])
+        kwargs.update(pixel_values=torch.zeros(1, 4, device=device),
+                      image_grid_thw=torch.tensor([[1, 6, 6]], device=device))
+    model.forward = types.MethodType(hook, model)
+    model(**kwargs)
+    return rec.calls[-1]
+
+
+def _check_qwen3(c, seen):
+    assert seen["position_ids"][0, 0].tolist() == c["keep_token_indices"]
+    assert sha(seen["inputs_embeds"]) == c["embeds_sha"]
+    if c["mask_sha"] is not None:
+        assert sha(seen["attention_mask"]) == c["mask_sha"]
+    assert sha(seen["visual_pos_masks"].to(torch.uint8)) == c["vpm_sha"]
+    assert [list(d.shape) for d in seen["deepstack_visual_embeds"]] == c["deep_shapes"]
+    assert [sha(d) for d in seen["deepstack_visual_embeds"]] == c["deep_sha"]
+    assert int(seen["visual_pos_masks"].sum()) == c["deep_shapes"][0][0]
+
+
+@pytest.mark.parametrize("c", CASES["qwen3_vl"], ids=lambda c: c["name"])
+def test_qwen3_hook_logic_cpu(c, monkeypatch):
+    _use_oracle(monkeypatch)
+    _check_qwen3(c, _run_qwen3(c, "cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CASES["qwen3_vl"], ids=lambda c: c["name"])
+def test_qwen3_hook_gpu(c):
+    _check_qwen3(c, _run_qwen3(c, "cuda"))

@@ -3,6 +3,7 @@
     from vidcom2_amd.models.llava import cus_prepare_inputs_labels_for_multimodal
     from vidcom2_amd.models.qwen2_5_vl import Qwen2_5_VLModel_forward
     from vidcom2_amd.models.qwen2_vl import Qwen2VL_ViT_forward, Qwen2VLGeneration_forward
+    from vidcom2_amd.models.qwen3_vl import Qwen3VLModel_forward
 
 Same names, same installation (`types.MethodType(hook, model)`), same env knobs (`COMPRESSOR`,
 `R_RATIO`); implemented as wrappers around the installed model's own methods, see `_intercept.py`.
@@ -22,7 +23,7 @@ def install(model, force: bool = False) -> bool:
     (or `force`), with `types.MethodType`.  Returns whether a hook was bound.
 
     LLaVA-OneVision / LLaVA-Video : `model.prepare_inputs_labels_for_multimodal`
-    Qwen2.5-VL / Qwen2-VL         : `forward` of the inner `*Model` (`model.model` of a
+    Qwen2.5-VL / Qwen2-VL / Qwen3-VL : `forward` of the inner `*Model` (`model.model` of a
                                     `*ForConditionalGeneration`)
     """
     if not (force or compressor_enabled()):
@@ -34,7 +35,9 @@ def install(model, force: bool = False) -> bool:
         return True
     inner = model.model if any(n.endswith("ForConditionalGeneration") for n in names) else model
     inner_names = {k.__name__ for k in type(inner).__mro__}
-    if any(n.startswith("Qwen2_5_VL") for n in inner_names):
+    if any(n.startswith("Qwen3VL") for n in inner_names):
+        from .qwen3_vl import Qwen3VLModel_forward as hook
+    elif any(n.startswith("Qwen2_5_VL") for n in inner_names):
         from .qwen2_5_vl import Qwen2_5_VLModel_forward as hook
     elif any(n.startswith("Qwen2VL") for n in inner_names):
         from .qwen2_vl import Qwen2VLModel_forward as hook

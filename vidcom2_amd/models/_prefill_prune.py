@@ -71,10 +71,21 @@ class _LanguageModelShim:
                 if torch.is_tensor(kwargs.get("input_ids")):
                     kwargs["input_ids"] = kwargs["input_ids"][:, keep]
                 if "attention_mask" in kwargs:
-                    kwargs["attention_mask"] = _prune_attention(kwargs["attention_mask"], keep)
+                    am = kwargs["attention_mask"]
+                    kwargs["attention_mask"] = ({k: _prune_attention(v, keep) for k, v in am.items()}
+                                                if isinstance(am, dict) else _prune_attention(am, keep))
                 pos = kwargs.get("position_ids")
                 if torch.is_tensor(pos):
                     kwargs["position_ids"] = pos[..., keep.to(pos.device)]
+                # Qwen3-VL deepstack: per-layer features of the visual tokens, row i <-> i-th True of the mask
+                # (models/qwen3_vl.py:141-149, 200-226 of the reference)
+                vpm = kwargs.get("visual_pos_masks")
+                if torch.is_tensor(vpm):
+                    rows = keep_flags[vpm[0].to(keep_flags.device)]
+                    deep = kwargs.get("deepstack_visual_embeds")
+                    if deep is not None:
+                        kwargs["deepstack_visual_embeds"] = [d[rows.to(d.device)] for d in deep]
+                    kwargs["visual_pos_masks"] = vpm[:, keep.to(vpm.device)]
                 st.kept_video, st.keep_token_indices, st.pruned = kept, keep, True
         return self._real(*args, **kwargs)
 
