@@ -6,13 +6,17 @@
 //   sweep 1  k_chan_stats      per-channel sum / sum-of-squares (fp64)        vidcom2.py:40
 //            k_stats_reduce    fixed-order partial reduce -> var (T)
 //            k_chan_select     lowest-variance half, CPU-reference ties       vidcom2.py:41-42
+//                              (+ torch.topk's sorted ORDER on a side stream in "torch order" mode)
 //   sweep 2  k_norm_colsum     token L2 norms, x^ = x/||x||, per-frame sums   vidcom2.py:47-52
-//            k_centres         frame / video centres (T)
+//            k_centres, k_vid_centre   frame / video centres (T)
 //   sweep 3  k_dist            squared distances to both centres              vidcom2.py:61
 //            k_token_epilogue  5-scale Gaussian sums, v+f, per-frame mean     vidcom2.py:62,32-33
-//            k_budget          softmax budgets, ks, offsets                   vidcom2.py:64-68,72
-//            k_select          per-frame bottom-k (libstdc++ ties) + mapping  vidcom2.py:74-77,99-115
+//            k_scales          softmax budgets                                vidcom2.py:64-68
+//            k_select          ks, per-frame bottom-k (libstdc++ ties) + map  vidcom2.py:72-77,99-115
 //            k_gather_rows     kept rows                                      vidcom2.py:91,96
+//   "torch order" mode only: k_norm_fix, k_centre_fix, k_dist_fix replay torch's fp32 accumulation order for
+//   the few values whose exact result lies next to a T rounding boundary (DESIGN.md "Numerics contract").
+//   standalone helper: k_multi_scale_gaussian                                 vidcom2.py:59-62
 //
 // HBM-bound: no dense contraction exists in the reference, so no MFMA.  All global
 // loads are 16 B/lane coalesced along D; reductions are fixed-order (no float atomics) so results
@@ -648,8 +652,7 @@ __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t s
                              int strict = 0, int* __restrict__ vfix_count = nullptr,
                              int* __restrict__ vfix_list = nullptr, int* __restrict__ vticket = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [0] arrival counter of k_token_epilogue's fused
-  //                                                            budget stage, [1] k_dist's strict-mode fix-up queue length
+  if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [1] k_dist's strict-mode fix-up queue length ([0] spare)
   if (vticket && c < kCFixMaxVid) vticket[c] = 0;           // per-entry arrival counters of k_centre_fix
   if (c >= C) return;
   double t = 0.0;
