@@ -81,14 +81,14 @@ def pmc_traffic(kernel, workload, world):
 def time_steps(fn, steps, dist_on):
     torch.cuda.synchronize()
     if dist_on:
-        torch.distributed.barrier()
+        torch.distributed.barrier(device_ids=[torch.cuda.current_device()])
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
     if dist_on:
-        torch.distributed.barrier()
+        torch.distributed.barrier(device_ids=[torch.cuda.current_device()])
         torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 side measurement")
+    ap.add_argument("--no-side-stream", action="store_true", help="A/B: keep the channel-order replay on the main stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,12 +139,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        # lazy communicator creation on purpose: with `device_id=` (eager init) every pass that uses the library's
+        # side stream measured ~45 us slower on this stack (323 vs 278 us), with it the numbers match a plain process
+        torch.distributed.init_process_group("nccl")
 
     import vidcom2_amd as vc
     from vidcom2_amd import _ffi, synth
 
     F, N, D, dtype, base = WORKLOADS[args.workload]
+    side = 0 if args.no_side_stream else 1
+    _ffi.lib().vc2_set_side_stream(side)
     es = 4 if dtype == torch.float32 else 2
     F_total = F * world
 
@@ -200,7 +205,7 @@ def main():
     torch.cuda.synchronize()
     prof = _ffi.profile_collect()
     _ffi.profile_enable(False)
-    _ffi.lib().vc2_set_side_stream(1)
+    _ffi.lib().vc2_set_side_stream(side)
     for name, (tot, cnt) in prof.items():
         kern[name] = round(tot / cnt * 1e3, 2)          # us per launch
     sweeps = {n: kern[n] for n in ("k_chan_stats", "k_norm_colsum", "k_dist", "k_gather_rows") if n in kern}

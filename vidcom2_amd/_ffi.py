@@ -29,6 +29,7 @@ _SIGNATURES = {
     "vc2_kept_capacity": [_i64, _i64, _dbl],
     "vc2_chan_var": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp, _vp],
     "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vc2_chan_select_overlapped": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "vc2_gather_cols": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
     "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "vc2_compute_scales": [_vp, _i64, _dbl, _dbl, _i32, _vp, _sz, _vp, _vp],

@@ -1640,7 +1640,7 @@ int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, con
 }
 
 // ---- side stream for the strict-mode channel sort (fork/join with events around the caller's stream) ----
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; };
 SideStream g_side[64];
 int get_side(SideStream** out) {
   int dev = 0;
@@ -1732,6 +1732,37 @@ int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, i
   return launch_chan_select(var_f32, D, k, mask, cols, order, opos, spos, static_cast<hipStream_t>(stream));
 }
 
+int vc2_chan_select_overlapped(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
+                               int32_t* order, int32_t* opos, int32_t* spos, void* stream) {
+  if (!var_f32 || !cols) return fail(VC2_ERR_ARG, "null pointer");
+  if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool want_order = g_strict != 0 && order && opos && spos;
+  int rc;
+  if (want_order && g_use_side_stream && !g_prof) {
+    SideStream* ss = nullptr;
+    if ((rc = get_side(&ss))) return rc;
+    if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
+      return fail(VC2_ERR_LAUNCH, "side-stream fork failed");
+    if ((rc = launch_chan_select(var_f32, D, k, nullptr, nullptr, order, opos, spos, ss->s, KID_CHAN_ORDER))) return rc;
+    if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(VC2_ERR_LAUNCH, "side-stream join failed");
+    ss->pending = true;                                       // consumed by the next vc2_scores_phase1 / vc2_scores
+  } else if (want_order) {
+    if ((rc = launch_chan_select(var_f32, D, k, nullptr, nullptr, order, opos, spos, st, KID_CHAN_ORDER))) return rc;
+  }
+  return launch_chan_select(var_f32, D, k, mask, cols, nullptr, nullptr, nullptr, st);
+}
+
+// the join event of a pending vc2_chan_select_overlapped on this device (or nullptr); clears the flag
+static hipEvent_t take_pending_join() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& ss = g_side[dev];
+  if (!ss.s || !ss.pending) return nullptr;
+  ss.pending = false;
+  return ss.join;
+}
+
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
                     void* stream) {
   if (!x || !idx || !out) return fail(VC2_ERR_ARG, "null pointer");
@@ -1766,7 +1797,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  rc = launch_phase1(p, x, make_chanset(p, cols, spos, C), ws, /*single_rank=*/false, st);
+  rc = launch_phase1(p, x, make_chanset(p, cols, spos, C), ws, /*single_rank=*/false, st, take_pending_join());
   if (rc) return rc;
   if (csum) {
     hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
@@ -1806,7 +1837,7 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st))) return rc;
+  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st, take_pending_join()))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st);

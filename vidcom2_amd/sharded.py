@@ -65,40 +65,50 @@ class HipStages:
         self.kout = torch.zeros(2, dtype=torch.int64, device=self.device)
         self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
 
+        # device pointers of the fixed buffers, resolved once: the per-pass host work is five C calls plus
+        # three collectives, and that host time bounds the pass when it exceeds the ~0.3 ms of GPU work
+        self._L = L
+        self._p = {n: ptr(getattr(self, n)) for n in ("ws", "stats", "csum", "var_f32", "mask", "cols", "order", "opos",
+                                                     "spos", "total", "s", "idx", "ks", "kout", "rows")}
+        self._ws_n = self.ws.numel()
+
     def _st(self):
         return stream_ptr(self.device)
 
     def chan_stats(self, x):
-        check(lib().vc2_chan_stats(ptr(x), self.F * self.N, self.D, self.code, ptr(self.ws), self.ws.numel(),
-                                   ptr(self.stats), self._st()), "vc2_chan_stats")
+        p = self._p
+        check(self._L.vc2_chan_stats(ptr(x), self.F * self.N, self.D, self.code, p["ws"], self._ws_n, p["stats"],
+                                     self._st()), "vc2_chan_stats")
         return self.stats
 
     def select_channels(self, stats_all, R_total):
+        p, st = self._p, self._st()
         P = stats_all.shape[0]
-        check(lib().vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, ptr(self.var_f32),
-                                            self._st()), "vc2_chan_var_from_stats")
-        check(lib().vc2_chan_select(ptr(self.var_f32), self.D, self.C, ptr(self.mask), ptr(self.cols), ptr(self.order), ptr(self.opos),
-                                    ptr(self.spos), self._st()),
-              "vc2_chan_select")
+        check(self._L.vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, p["var_f32"], st),
+              "vc2_chan_var_from_stats")
+        # cols on this stream; torch.topk's channel ORDER (needed only by the fix-up kernels of phase 1) on the
+        # library's side stream, joined inside vc2_scores_phase1
+        check(self._L.vc2_chan_select_overlapped(p["var_f32"], self.D, self.C, p["mask"], p["cols"], p["order"],
+                                                 p["opos"], p["spos"], st), "vc2_chan_select_overlapped")
 
     def phase1(self, x):
-        check(lib().vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C, ptr(self.spos),
-                                      ptr(self.ws), self.ws.numel(), ptr(self.csum), self._st()),
-              "vc2_scores_phase1")
+        p = self._p
+        check(self._L.vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
+                                        p["ws"], self._ws_n, p["csum"], self._st()), "vc2_scores_phase1")
         return self.csum
 
     def phase2(self, x, csum_all, R_total):
-        check(lib().vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, ptr(self.cols), self.C,
-                                      ptr(self.spos), ptr(csum_all), csum_all.shape[0], csum_all.shape[1], R_total, ptr(self.ws),
-                                      self.ws.numel(), None, None, ptr(self.total), ptr(self.s), self._st()),
-              "vc2_scores_phase2")
+        p = self._p
+        check(self._L.vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
+                                        ptr(csum_all), csum_all.shape[0], csum_all.shape[1], R_total, p["ws"],
+                                        self._ws_n, None, None, p["total"], p["s"], self._st()), "vc2_scores_phase2")
         return self.s
 
     def select(self, x, s_all, f0):
-        check(lib().vc2_select_sharded(ptr(self.total), ptr(s_all), s_all.numel(), f0, self.F, self.N, self.D,
-                                       float(self.base), self.code, ptr(self.ws), self.ws.numel(), ptr(self.ks),
-                                       ptr(self.idx), self.cap, ptr(self.kout),
-                                       ptr(x if self.rows is not None else None), ptr(self.rows), self._st()),
+        p = self._p
+        check(self._L.vc2_select_sharded(p["total"], ptr(s_all), s_all.numel(), f0, self.F, self.N, self.D,
+                                         float(self.base), self.code, p["ws"], self._ws_n, p["ks"], p["idx"], self.cap,
+                                         p["kout"], ptr(x if self.rows is not None else None), p["rows"], self._st()),
               "vc2_select_sharded")
 
     def result(self, f0):
@@ -109,15 +119,15 @@ class HipStages:
         return ShardResult(self.rows[:K] if self.rows is not None else None, li, li + f0 * self.N, self.ks, int(K))
 
 
-def _all_gather(t: torch.Tensor, group, world: int) -> torch.Tensor:
-    """[world, *t.shape] stacked in rank order (one all-gather; RCCL on GPU tensors, gloo on CPU)."""
-    flat = t.contiguous().reshape(-1)
-    out = torch.empty(world * flat.numel(), dtype=t.dtype, device=t.device)
+def _all_gather(t: torch.Tensor, group, world: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[world, *t.shape] stacked in rank order (one all-gather; RCCL on GPU tensors, gloo on CPU).  `out` is a
+    preallocated [world, *t.shape] buffer (the hot path passes one; tests may not)."""
     if world == 1:
-        out.copy_(flat)
-    else:
-        dist.all_gather_into_tensor(out, flat, group=group)
-    return out.reshape((world,) + tuple(t.shape))
+        return t.unsqueeze(0)
+    if out is None:
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
+    return out
 
 
 class ShardedCompressor:
@@ -134,13 +144,23 @@ class ShardedCompressor:
         self.stages = stages if stages is not None else HipStages(self.F, self.N, self.D, dtype, device, base_scale,
                                                                   gather)
 
+        self._gbuf = {}
+
+    def _gather(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t.unsqueeze(0)
+        buf = self._gbuf.get(key)
+        if buf is None or buf.shape[1:] != t.shape or buf.dtype != t.dtype or buf.device != t.device:
+            buf = self._gbuf[key] = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        return _all_gather(t, self.group, self.world, buf)
+
     def enqueue(self, x_local: torch.Tensor) -> None:
-        st, W = self.stages, self.world
+        st = self.stages
         R_total = self.F_total * self.N
-        stats_all = _all_gather(st.chan_stats(x_local), self.group, W)          # exchange 1: [W, 2, D] fp64
+        stats_all = self._gather("stats", st.chan_stats(x_local))               # exchange 1: [W, 2, D] fp64
         st.select_channels(stats_all, R_total)
-        csum_all = _all_gather(st.phase1(x_local), self.group, W)               # exchange 2: [W, D] fp64
-        s_all = _all_gather(st.phase2(x_local, csum_all, R_total), self.group, W)   # exchange 3: [W, F_local]
+        csum_all = self._gather("csum", st.phase1(x_local))                     # exchange 2: [W, D] fp64
+        s_all = self._gather("s", st.phase2(x_local, csum_all, R_total))        # exchange 3: [W, F_local]
         st.select(x_local, s_all.reshape(-1), self.f0)
 
     def finish(self) -> ShardResult:
