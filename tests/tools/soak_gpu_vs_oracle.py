@@ -1,6 +1,6 @@
 """GPU-box soak: HIP path (flag-and-fix replay) vs the oracle (replays everything) on fresh seeds, torch mode."""
 import sys, time, itertools, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle as O
 from vidcom2_amd import synth, _ffi

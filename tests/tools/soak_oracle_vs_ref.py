@@ -1,7 +1,8 @@
 """Container-only soak: reference (imported from /root/reference) vs oracle (torch mode) on fresh seeds.
 Prints every case whose kept indices / budgets / half-precision scores differ.  Not a test (needs the reference)."""
 import sys, time, itertools
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/reference")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, "/root/reference")
 import torch
 from token_compressor.vidcom2 import vidcom2 as R
 import oracle as O
