@@ -1,5 +1,5 @@
 """Stage-by-stage comparison of the HIP path with the CPU oracle (development aid; the pytest
-suite in tests/ is the real gate).  Run on a GPU box:  python scripts/gpu_check.py [--big]"""
+suite in tests/ is the real gate).  Run on a GPU box:  python tests/tools/gpu_check.py [--big]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
