@@ -848,6 +848,27 @@ template <int DT> __device__ __forceinline__ void rnT2(float a, float b, float& 
   }
 }
 
+// the same on a register pair
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <int DT> __device__ __forceinline__ f2_t rnT2v(f2_t v) {
+  if constexpr (DT == VC2_F32) {
+    return v;
+  } else if constexpr (DT == VC2_BF16) {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(__builtin_convertvector(v, b2_t), f2_t);
+  } else {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(__builtin_convertvector(v, h2_t), f2_t);
+  }
+}
+
+// (a, b) -> (a*a, b*b) in ONE packed instruction (the compiler scalarises the vector multiply here)
+__device__ __forceinline__ f2_t pk_square(f2_t v) {
+  f2_t r;
+  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 // sweep 3: dist_v[r] = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with the frame centre
 // (vidcom2.py:61), x^ recomputed from X and den.  Column offsets and both centres of the lane's compact
 // positions live in registers for the whole workgroup; the row loop touches LDS only for the row itself.
@@ -890,15 +911,23 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     row_wait();
     const double inv = 1.0 / double(dens[n - n0]);
     double pv = 0.0, pf = 0.0;
+    // two compact positions per step: one packed conversion rounds both x^, the two subtract / square pairs
+    // are packed fp32 ops on (video, frame) register pairs -- the kernel is VALU-bound, every
+    // instruction counts.  The fp64 accumulation order (i, then i + 1) is the same as element by element.
+    static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
 #pragma unroll
-    for (int i = 0; i < NPLB; ++i) {
-      const float v = lds_elem<DT>(buf0, coff[i]);
-      const float xh = rnT<DT>(div_via_f64(v, inv));
-      float a, b, aa, bb;
-      rnT2<DT>(xh - cv[i], xh - cf[i], a, b);
-      rnT2<DT>(a * a, b * b, aa, bb);
-      pv += double(aa);
-      pf += double(bb);
+    for (int i = 0; i < NPLB; i += 2) {
+      const float v0 = lds_elem<DT>(buf0, coff[i]), v1 = lds_elem<DT>(buf0, coff[i + 1]);
+      float xh0, xh1;
+      rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
+      const f2_t d0 = (f2_t){xh0, xh0} - (f2_t){cv[i], cf[i]};
+      const f2_t d1 = (f2_t){xh1, xh1} - (f2_t){cv[i + 1], cf[i + 1]};
+      const f2_t r0 = rnT2v<DT>(d0), r1 = rnT2v<DT>(d1);
+      const f2_t q0 = rnT2v<DT>(pk_square(r0)), q1 = rnT2v<DT>(pk_square(r1));
+      pv += double(q0.x);
+      pf += double(q0.y);
+      pv += double(q1.x);
+      pf += double(q1.y);
     }
     pv = wave_sum_bcast(pv);
     pf = wave_sum_bcast(pf);
