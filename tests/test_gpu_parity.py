@@ -2,6 +2,7 @@
 inputs and (b) the golden vectors captured from the reference.  Bar: kept indices, budgets, channel
 selection bit-exact; half-precision scores bit-exact vs the oracle; fp32 scores within 1e-5."""
 import ctypes
+import os
 import hashlib
 
 import numpy as np
@@ -275,3 +276,22 @@ def test_full_size_properties(shape):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_integration_md_ctypes_stub_runs():
+    """The ctypes stub printed in INTEGRATION.md §2 is executed as written (only the library path is filled in)
+    and must reproduce the package's own result."""
+    import re
+    from vidcom2_amd import vidcom2 as V
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes, torch\n(.*?)```", text, re.S)
+    assert block, "INTEGRATION.md lost its ctypes stub"
+    src = "import ctypes, torch\n" + block.group(1)
+    src = src.replace('".../vidcom2_amd/_lib/libvc2hip.so"', repr(_ffi.LIB_PATH))
+    ns = {}
+    exec(compile(src, "INTEGRATION.md", "exec"), ns)
+    x = make_input(8, 196, 1024, "bf16", 3, "drift").cuda()
+    rows, idx, ks = ns["compress"](x, 196, 0.25)
+    ref = V.compress(x, 196, 0.25)
+    assert torch.equal(idx, ref.global_idx) and torch.equal(ks, ref.ks) and torch.equal(rows, ref.rows)
