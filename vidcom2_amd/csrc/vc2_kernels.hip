@@ -524,21 +524,21 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     for (int i = 0; i < NPLB; ++i) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
     unsigned char* tbuf = buf0; buf0 = buf1; buf1 = tbuf;
   }
-  // combine the 4 waves' column sums in wave order (fixed order) through LDS, then one partial per block
+  // combine the 4 waves' column sums in wave order (fixed order): every wave parks its sums in LDS (the row
+  // buffers are free now), then each thread adds the 4 values of its columns -- two barriers instead of a
+  // serial hand-over per wave
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  double* sacc = reinterpret_cast<double*>(smem);                // C*8 <= 2*kRowWaves*rowb
-  for (int w = 0; w < kRowWaves; ++w) {
-    if (wave == w) {
+  double* sacc = reinterpret_cast<double*>(smem);                // [kRowWaves][NPLB * 64] doubles
 #pragma unroll
-      for (int i = 0; i < NPLB; ++i) {
-        const int p = i * 64 + lane;
-        if (p < C) sacc[p] = (w == 0 ? 0.0 : sacc[p]) + acc[i];
-      }
-    }
-    __syncthreads();
+  for (int i = 0; i < NPLB; ++i) sacc[(wave * NPLB + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  for (int p = tid; p < C; p += kRowWaves * 64) {
+    double t = sacc[p];
+#pragma unroll
+    for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
+    part[int64_t(blockIdx.x) * C + p] = t;
   }
-  for (int p = tid; p < C; p += kRowWaves * 64) part[int64_t(blockIdx.x) * C + p] = sacc[p];
 }
 
 // Strict-mode fix-up of sweep 2: for every queued row replay torch's norm accumulation (the row's selected
@@ -1500,7 +1500,8 @@ inline ChanSet make_chanset(const Plan& p, const int* cols, const int* spos, int
 template <int DT, int VEC, int NPLB>
 int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
   const int* cols = cs.cols; const int C = cs.C;
-  const size_t smem = 2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES);
+  const size_t smem = std::max<size_t>(2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES),
+                                      size_t(kRowWaves) * NPLB * 64 * 8);          // row buffers, then the combine
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB>, smem, "k_norm_colsum");
   if (rc) return rc;
   hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
