@@ -295,3 +295,29 @@ def test_integration_md_ctypes_stub_runs():
     rows, idx, ks = ns["compress"](x, 196, 0.25)
     ref = V.compress(x, 196, 0.25)
     assert torch.equal(idx, ref.global_idx) and torch.equal(ks, ref.ks) and torch.equal(rows, ref.rows)
+
+
+def test_pass_is_hip_graph_capturable():
+    """The whole pass only enqueues (no host sync, no allocation): it can be captured into a hipGraph -- side-stream
+    fork/join included -- and replayed (serving loops)."""
+    x = make_input(32, 196, 1024, "bf16", 5, "drift").cuda()
+    plan = vc.vidcom2.CompressPlan(32, 196, 1024, torch.bfloat16, x.device, 0.25)
+    plan.enqueue(x)
+    ref = plan.finish()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.enqueue(x)                                   # warm-up on the capture stream (lazy side-stream creation)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        plan.enqueue(x)
+    plan.idx.zero_()
+    g.replay()
+    got = plan.finish()
+    assert torch.equal(got.global_idx, ref.global_idx) and torch.equal(got.ks, ref.ks) and torch.equal(got.rows, ref.rows)
+    x2 = make_input(32, 196, 1024, "bf16", 6, "drift").cuda()
+    x.copy_(x2)                                           # same buffers, new contents
+    g.replay()
+    got2 = plan.finish()
+    want2 = vc.vidcom2.compress(x2, 196, 0.25)
+    assert torch.equal(got2.global_idx, want2.global_idx) and torch.equal(got2.rows, want2.rows)
