@@ -321,3 +321,12 @@ def test_pass_is_hip_graph_capturable():
     got2 = plan.finish()
     want2 = vc.vidcom2.compress(x2, 196, 0.25)
     assert torch.equal(got2.global_idx, want2.global_idx) and torch.equal(got2.rows, want2.rows)
+
+
+@pytest.mark.parametrize("F", [1024, 1100])
+def test_many_frames_budget_paths(F):
+    """F <= 1024: every k_select wave derives the budgets itself; above: the separate k_scales kernel."""
+    x = make_input(F, 16, 64, "bf16", 11, "drift")
+    got = vc.vidcom2.compress(x.cuda(), 16, 0.25)
+    ref = O.compress_indices(x, 16, 0.25)
+    assert torch.equal(got.ks.cpu(), ref["ks"]) and torch.equal(got.global_idx.cpu(), ref["global_idx"])

@@ -1189,23 +1189,80 @@ __global__ void k_widen(const void* __restrict__ in, int64_t n, float* __restric
 // sum of the budgets of all earlier frames, replays torch.topk's selection on its N scores in LDS,
 // and writes the kept token indices ascending, already mapped (linear / grid_vid / local).
 constexpr int kFrameNT = 64;
+constexpr int kFusedScalesMaxF = 1024;      // up to this many frames every k_select wave derives the budgets itself
+
+// compute_scales (vidcom2.py:64-68) by ONE wave, every op in T exactly like scales_body; each lane ends up with
+// the scale of the frames i = lane, lane + 64, ... it asks for through `want` (returns scale of frame `i`).
+// The three reductions are recomputed from the F frame scores (L2-resident, F <= 1024) instead of staged.
+template <int DT> struct WaveScales {
+  float mx, zmax, pmean, base, temp;
+  double esum;
+  __device__ __forceinline__ float z_of(float sv) const { return rnT<DT>(rnT<DT>(sv - mx) / temp); }
+  __device__ __forceinline__ float p_of(float sv) const {
+    const double e = double(float(exp(double(z_of(sv) - zmax))));
+    return rnT<DT>(float(e / esum));
+  }
+  __device__ __forceinline__ float scale_of(float sv) const {
+    float t = rnT<DT>(1.0f + p_of(sv));
+    t = rnT<DT>(t - pmean);
+    t = rnT<DT>(base * t);
+    return t > 1.0f ? 1.0f : t;
+  }
+  __device__ void init(const float* __restrict__ s, int F, float base_, float temp_, int lane) {
+    base = base_; temp = temp_;
+    float m = -INFINITY;
+    bool first = true;
+    for (int i = lane; i < F; i += 64) {
+      const float v = s[i];
+      m = first ? v : ((m != m) ? m : ((v != v) ? v : fmaxf(m, v)));
+      first = false;
+    }
+    mx = wave_max_nanprop(m);
+    float zm = -INFINITY;
+    for (int i = lane; i < F; i += 64) {
+      const float z = z_of(s[i]);
+      zm = (zm != zm) ? zm : ((z != z) ? z : fmaxf(zm, z));
+    }
+    zmax = wave_max_nanprop(zm);
+    double es = 0.0;
+    for (int i = lane; i < F; i += 64) es += double(float(exp(double(z_of(s[i]) - zmax))));
+    esum = wave_sum(es);
+    double ps = 0.0;
+    for (int i = lane; i < F; i += 64) ps += double(p_of(s[i]));
+    pmean = mean_T<DT>(wave_sum(ps), F);
+  }
+};
+
 
 template <int DT>
 __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total,
                                                      const float* __restrict__ scales_f32, int F, int N,
                                                      int map_mode, int grid_h, int64_t stride, int64_t cap,
                                                      int64_t* __restrict__ ks, int64_t* __restrict__ offs,
-                                                     int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out) {
+                                                     int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out,
+                                                     const float* __restrict__ frame_scores, float base,
+                                                     float temp, float* __restrict__ scales_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelShared S = sel_carve(smem, N);
   const int f = blockIdx.x, tid = threadIdx.x;
   const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
-  // budgets: offs[f] = sum_{f' < f} (k_f' + extra)
+  // budgets: offs[f] = sum_{f' < f} (k_f' + extra).  With frame_scores the wave computes the scales itself
+  // (saves the k_scales kernel boundary, ~5 us); otherwise it reads them.
   int64_t before = 0;
-  for (int i = tid; i < f; i += kFrameNT) before += budget_k<DT>(scales_f32[i], N) + extra;
+  int k;
+  if (frame_scores) {
+    WaveScales<DT> ws;
+    ws.init(frame_scores, F, base, temp, tid);
+    for (int i = tid; i < f; i += kFrameNT) before += budget_k<DT>(ws.scale_of(frame_scores[i]), N) + extra;
+    const float sc = ws.scale_of(frame_scores[f]);
+    k = budget_k<DT>(sc, N);
+    if (tid == 0 && scales_out) scales_out[f] = sc;
+  } else {
+    for (int i = tid; i < f; i += kFrameNT) before += budget_k<DT>(scales_f32[i], N) + extra;
+    k = budget_k<DT>(scales_f32[f], N);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
-  const int k = budget_k<DT>(scales_f32[f], N);
   const int64_t o0 = before;
   if (tid == 0) {
     ks[f] = k;
@@ -1650,12 +1707,13 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 
 int launch_select(int dt, const float* total, const float* scales_f32, int64_t F, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
-                  hipStream_t st) {
+                  hipStream_t st, const float* frame_scores = nullptr, double base = 0.0, double temp = 0.01,
+                  float* scales_out = nullptr) {
   const size_t smem = sel_shared_bytes(int(N));
   ProfScope ps_(KID_SELECT, st);
   VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F)), dim3(kFrameNT), smem, st, total,
                                          scales_f32, int(F), int(N), map_mode, int(grid_h), N, cap, ks, offs,
-                                         idx_out, K_out));
+                                         idx_out, K_out, frame_scores, float(base), float(temp), scales_out));
   return check_launch("select");
 }
 
@@ -1968,14 +2026,20 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   float* s = wsp<float>(ws, p.o_s);
   float* scales = wsp<float>(ws, p.o_scales_f32);
   if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st))) return rc;
-  // budgets in their own small kernel: fusing them into the epilogue's last workgroup (agent-scope release /
-  // acquire ticket) measured 2 us SLOWER than this kernel boundary -- the release fences write back L2
-  if ((rc = launch_scales(dtype, s, F, base_scale < 0 ? 0.0 : base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales,
-                          nullptr, st)))
-    return rc;
-  if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
-                          cap, K_out, st)))
-    return rc;
+  // budgets: every k_select wave derives them from the F frame scores itself (F <= 1024; saves the k_scales kernel
+  // boundary).  Fusing them into the epilogue's last workgroup through an agent-scope ticket measured SLOWER than
+  // a separate kernel -- the release fences write back L2.
+  const double bs = base_scale < 0 ? 0.0 : base_scale;
+  if (F <= kFusedScalesMaxF) {
+    if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
+                            cap, K_out, st, s, bs, 0.01, scales)))
+      return rc;
+  } else {
+    if ((rc = launch_scales(dtype, s, F, bs, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
+    if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
+                            cap, K_out, st)))
+      return rc;
+  }
   if (out_rows && gather_src)
     rc = launch_gather_rows(gather_src, gather_rows, D, p.ES, idx_out, K_out, cap, out_rows, st);
   return rc;
