@@ -257,6 +257,24 @@ def main():
                        "tokens_per_s": round(F2 * N2 / (e2 / args.steps), 1),
                        "pass_alg_GBs": round(alg_bytes_pass(F2, N2, D2, 2, b2) / (e2 / args.steps) / 1e9, 1)}
 
+    # ---- side measurement: two clips in flight, one stream each (serving / batched eval) --------------
+    # The single-workgroup selection replays leave the GPU mostly idle; a second clip on its own stream fills it.
+    if not dist_on and not args.no_extra and args.workload == "target":
+        # (the current stream plus ONE new one: each brings an internal side stream, and four streams is what the
+        # default four hardware queues run without multiplexing)
+        streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+        plans = [plan, vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base)]
+
+        def two():
+            for st, pl in zip(streams, plans):
+                with torch.cuda.stream(st):
+                    pl.enqueue(x)
+        for _ in range(args.warmup):
+            two()
+        e4 = time_steps(two, args.steps, False)
+        out["two_clips_in_flight"] = {"ms_per_round": round(e4 / args.steps * 1e3, 4),
+                                      "tokens_per_s": round(2 * F * N / (e4 / args.steps), 1)}
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -88,7 +88,7 @@ int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, i
 
 /* vc2_chan_select for the scoring entry points, with the ORDER replay off the critical path:
  * `cols` (and `mask`) are produced on `stream`; in "torch order" mode order/opos/spos are produced on an internal
- * side stream forked from `stream`, and the next vc2_scores_phase1 / vc2_scores call on this device waits for them
+ * side stream forked from `stream` (one per caller stream), and the next vc2_scores_phase1 / vc2_scores call on that stream waits for them
  * (event join) right before its first fix-up kernel.  In "exact" mode the order outputs are not needed by the
  * scoring entry points and are not computed.  Use plain vc2_chan_select when the order is consumed elsewhere. */
 int vc2_chan_select_overlapped(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,

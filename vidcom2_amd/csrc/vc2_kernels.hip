@@ -1728,19 +1728,35 @@ int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, con
 }
 
 // ---- side stream for the strict-mode channel sort (fork/join with events around the caller's stream) ----
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; };
-SideStream g_side[64];
-int get_side(SideStream** out) {
+// One side stream (+ fork / join events) per CALLER stream, so that passes enqueued on different streams -- several
+// clips in flight, one stream each -- replay their channel orders concurrently instead of queueing on one stream.
+// Up to kSideSlots caller streams per device are remembered (the least recently created slot is recycled).
+struct SideStream { hipStream_t owner = nullptr; bool used = false; hipStream_t s = nullptr;
+                    hipEvent_t fork = nullptr, join = nullptr; bool pending = false; };
+constexpr int kSideSlots = 8;
+SideStream g_side[64][kSideSlots];
+int g_side_next[64];
+SideStream* find_side(int dev, hipStream_t owner) {
+  for (int i = 0; i < kSideSlots; ++i)
+    if (g_side[dev][i].used && g_side[dev][i].owner == owner) return &g_side[dev][i];
+  return nullptr;
+}
+int get_side(hipStream_t owner, SideStream** out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(VC2_ERR_LAUNCH, "hipGetDevice failed");
-  SideStream& ss = g_side[dev];
-  if (!ss.s) {
-    if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess)
-      return fail(VC2_ERR_LAUNCH, "could not create the side stream");
+  SideStream* ss = find_side(dev, owner);
+  if (!ss) {
+    ss = &g_side[dev][g_side_next[dev]];
+    g_side_next[dev] = (g_side_next[dev] + 1) % kSideSlots;
+    if (!ss->s) {
+      if (hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ss->join, hipEventDisableTiming) != hipSuccess)
+        return fail(VC2_ERR_LAUNCH, "could not create the side stream");
+    }
+    ss->owner = owner; ss->used = true; ss->pending = false;
   }
-  *out = &ss;
+  *out = ss;
   return VC2_OK;
 }
 
@@ -1829,7 +1845,7 @@ int vc2_chan_select_overlapped(const float* var_f32, int64_t D, int64_t k, uint8
   int rc;
   if (want_order && g_use_side_stream && !g_prof) {
     SideStream* ss = nullptr;
-    if ((rc = get_side(&ss))) return rc;
+    if ((rc = get_side(st, &ss))) return rc;
     if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
       return fail(VC2_ERR_LAUNCH, "side-stream fork failed");
     if ((rc = launch_chan_select(var_f32, D, k, nullptr, nullptr, order, opos, spos, ss->s, KID_CHAN_ORDER))) return rc;
@@ -1841,14 +1857,14 @@ int vc2_chan_select_overlapped(const float* var_f32, int64_t D, int64_t k, uint8
   return launch_chan_select(var_f32, D, k, mask, cols, nullptr, nullptr, nullptr, st);
 }
 
-// the join event of a pending vc2_chan_select_overlapped on this device (or nullptr); clears the flag
-static hipEvent_t take_pending_join() {
+// the join event of a pending vc2_chan_select_overlapped issued on `st` (or nullptr); clears the flag
+static hipEvent_t take_pending_join(hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& ss = g_side[dev];
-  if (!ss.s || !ss.pending) return nullptr;
-  ss.pending = false;
-  return ss.join;
+  SideStream* ss = find_side(dev, st);
+  if (!ss || !ss->pending) return nullptr;
+  ss->pending = false;
+  return ss->join;
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -1885,7 +1901,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  rc = launch_phase1(p, x, make_chanset(p, cols, spos, C), ws, /*single_rank=*/false, st, take_pending_join());
+  rc = launch_phase1(p, x, make_chanset(p, cols, spos, C), ws, /*single_rank=*/false, st, take_pending_join(st));
   if (rc) return rc;
   if (csum) {
     hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
@@ -1925,7 +1941,7 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st, take_pending_join()))) return rc;
+  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st, take_pending_join(st)))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st);
@@ -2010,7 +2026,7 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
     // torch.topk's ORDER of the selected channels (needed only by the strict-mode fix-ups) is replayed on a side
     // stream, concurrently with the channel-set selection and sweep 2 on the caller's stream.
     SideStream* ss = nullptr;
-    if ((rc = get_side(&ss))) return rc;
+    if ((rc = get_side(st, &ss))) return rc;
     if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
       return fail(VC2_ERR_LAUNCH, "side-stream fork failed");
     if ((rc = launch_chan_select(var_f32, D, kc, nullptr, nullptr, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos,
