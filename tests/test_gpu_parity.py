@@ -330,3 +330,23 @@ def test_many_frames_budget_paths(F):
     got = vc.vidcom2.compress(x.cuda(), 16, 0.25)
     ref = O.compress_indices(x, 16, 0.25)
     assert torch.equal(got.ks.cpu(), ref["ks"]) and torch.equal(got.global_idx.cpu(), ref["global_idx"])
+
+
+def test_two_clips_in_flight_on_two_streams():
+    """Every caller stream gets its own internal side stream: two passes enqueued back to back on two streams run
+    concurrently and still produce what they produce alone."""
+    xs = [make_input(32, 196, 1024, "bf16", s, "drift").cuda() for s in (21, 22)]
+    want = [vc.vidcom2.compress(x, 196, 0.25) for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    plans = [vc.vidcom2.CompressPlan(32, 196, 1024, torch.bfloat16, xs[0].device, 0.25) for _ in xs]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for st, pl, x in zip(streams, plans, xs):
+            with torch.cuda.stream(st):
+                pl.enqueue(x)
+    got = []
+    for st, pl in zip(streams, plans):
+        with torch.cuda.stream(st):
+            got.append(pl.finish())
+    for g, w in zip(got, want):
+        assert torch.equal(g.global_idx, w.global_idx) and torch.equal(g.ks, w.ks) and torch.equal(g.rows, w.rows)
