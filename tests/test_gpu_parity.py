@@ -350,3 +350,17 @@ def test_two_clips_in_flight_on_two_streams():
             got.append(pl.finish())
     for g, w in zip(got, want):
         assert torch.equal(g.global_idx, w.global_idx) and torch.equal(g.ks, w.ks) and torch.equal(g.rows, w.rows)
+
+
+def test_compress_batch_matches_sequential():
+    shapes = [(16, 196, 1024), (8, 196, 1024), (16, 196, 1024), (4, 196, 1024), (12, 196, 1024)]
+    xs = [make_input(F, N, D, "bf16", 30 + i, "drift").cuda() for i, (F, N, D) in enumerate(shapes)]
+    want = [vc.vidcom2.compress(x, 196, 0.25) for x in xs]
+    for lanes in (1, 2, 3):
+        got = vc.compress_batch(xs, 196, 0.25, in_flight=lanes)
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g.K == w.K and torch.equal(g.global_idx, w.global_idx) and torch.equal(g.rows, w.rows)
+    assert vc.compress_batch([], 196) == []
+    with pytest.raises(RuntimeError):
+        vc.compress_batch([xs[0][:100]], 196)

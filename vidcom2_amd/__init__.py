@@ -15,6 +15,7 @@ from .vidcom2 import (  # noqa: F401
     _map_linear_offset,
     _map_grid_vid,
     compress,
+    compress_batch,
     CompressionResult,
 )
 
