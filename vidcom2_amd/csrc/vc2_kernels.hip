@@ -401,6 +401,13 @@ __device__ float norm_torch_order(const float* sv, int C, int lane) {
     float acc = 0.f;
     if (lane < 8) {
       int p = lane;
+      for (; p + 8 * 31 < nv; p += 8 * 32) {                     // 32 LDS reads in flight per round trip
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = sv[p + 8 * u];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc = fmaf(v[u], v[u], acc);
+      }
       for (; p + 56 < nv; p += 64) {
         float v[8];
 #pragma unroll
@@ -726,8 +733,11 @@ __device__ float wave_cascade_final(const float* l1, int64_t nb, const void* __r
   float acc2 = 0.f;
   for (int g = 16 * n2; g < n1c; ++g) acc2 += l1[g];
   const float acc1 = (nb & 15) ? l1[n1c] : 0.f;
+  // the < 16 leftover rows: fetched by as many lanes at once, added in row order
+  const int ntail = int(n - (nb << 4));
+  const float tv = lane < ntail ? xhat_at<DT>(x, r0 + ((nb << 4) + lane) * rs, D, col, den) : 0.f;
   float r = 0.f;
-  for (int64_t e = nb << 4; e < n; ++e) r += xhat_at<DT>(x, r0 + e * rs, D, col, den);
+  for (int u = 0; u < ntail; ++u) r += __shfl(tv, u, 64);
   r += acc1; r += acc2; r += acc3;
   return r;
 }
