@@ -385,12 +385,19 @@ __device__ float norm_torch_order(const float* sv, int C, int lane) {
   if constexpr (DT == VC2_F16) {                                // generic path: ONE sequential fp32 chain
     if (lane == 0) {
       int p = 0;
+      for (; p + 32 <= C; p += 32) {                            // 32 LDS reads in flight per round trip
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = sv[p + u];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) s = s + v[u] * v[u];       // fp16 x fp16 is exact in fp32
+      }
       for (; p + 8 <= C; p += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = sv[p + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s = s + v[u] * v[u];        // fp16 x fp16 is exact in fp32
+        for (int u = 0; u < 8; ++u) s = s + v[u] * v[u];
       }
       for (; p < C; ++p) { const float v = sv[p]; s = s + v * v; }
     }
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
 // values scattered to their SORTED positions, then the 8-chain / sequential fp32 sum).  Almost always the
 // T-rounded norm equals the exactly-rounded one already in den[]; when it does not, den[] is corrected and
 // the row is recorded so that k_centres can correct the column sums of its frame.  One wave per entry.
-struct NormCorr { int row; float den_old; float den_new; int pad; };
+struct NormCorr { int row; float den_old; float den_new; int frame; };
 constexpr int kMaxCorr = 4096;
 
 template <int DT, int VEC, int NPLB>
@@ -560,7 +567,8 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
                                                  const int* __restrict__ cols, const int* __restrict__ spos,
                                                  float* __restrict__ den, const int* __restrict__ nfix_count,
                                                  const int* __restrict__ nfix_list, int max_entries,
-                                                 int* __restrict__ corr_count, NormCorr* __restrict__ corr) {
+                                                 int* __restrict__ corr_count, NormCorr* __restrict__ corr,
+                                                 int N) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
     if (lane == 0 && !(dn == dn_old) && !(dn != dn && dn_old != dn_old)) {
       den[row] = dn;
       const int j = atomicAdd(corr_count, 1);
-      if (j < kMaxCorr) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; }
+      if (j < kMaxCorr) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
     }
     wave_lds_fence();
     if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
@@ -627,8 +635,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
     for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
     const int nc = corr_count ? min(*corr_count, kMaxCorr) : 0;
     for (int e = 0; e < nc; ++e) {
-      const int row = corr[e].row;
-      if (row / N == f) {
+      if (corr[e].frame == f) {
+        const int row = corr[e].row;
         const float v = ldT<DT>(x, int64_t(row) * D + (cols ? cols[c] : c));
         const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_old)));
         const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_new)));
@@ -1582,11 +1590,12 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   const size_t smem1 = std::max(row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(cs.C) * 4 + 16);   // row, then C fp32
   int rc1 = allow_big_lds(&k_norm_fix<DT, VEC, NPLB>, smem1, "k_norm_fix");
   if (rc1) return rc1;
-  const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(p.R, 4096)) : 512;
+  // fp16 queues ~3 % of the rows (its T ulp is 2^13 fp32 ulps) and replays ONE sequential chain per row: more waves
+  const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(p.R, 4096)) : (p.dt == VC2_F16 ? 2048 : 512);
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
                      cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + 2,
                      wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + 3,
-                     wsp<NormCorr>(ws, p.o_corr));
+                     wsp<NormCorr>(ws, p.o_corr), int(p.N));
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -1613,7 +1622,7 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hip
     const size_t smem1 = std::max(row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16);   // row, then C fp32
     int rc1 = allow_big_lds(&k_dist_fix<DT, VEC, NPLB>, smem1, "k_dist_fix");
     if (rc1) return rc1;
-    const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(2 * p.R, kMaxFix)) : 512;
+    const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(2 * p.R, kMaxFix)) : (p.dt == VC2_F16 ? 2048 : 512);
     hipLaunchKernelGGL((k_dist_fix<DT, VEC, NPLB>), dim3(unsigned(std::min(nfix, 4096))), dim3(64), smem1, st, x,
                        int(p.N), int(p.D), p.CV, C, cols, cs.spos, wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
                        wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df),
