@@ -436,3 +436,22 @@ def test_qwen3_hook_logic_cpu(c, monkeypatch):
 @pytest.mark.parametrize("c", CASES["qwen3_vl"], ids=lambda c: c["name"])
 def test_qwen3_hook_gpu(c):
     _check_qwen3(c, _run_qwen3(c, "cuda"))
+
+
+def test_qwen_hook_four_row_position_ids_and_cache_position(monkeypatch):
+    """transformers >= 4.5x layout: row 0 of a 4-row position tensor carries text positions for packed-sequence
+    detection; after pruning it must stay contiguous, rows 1..3 (rope) are sliced; a prefill `cache_position` of the
+    full prompt length shrinks with the prompt."""
+    _use_oracle(monkeypatch)
+    from vidcom2_amd.models.qwen2_5_vl import Qwen2_5_VLModel_forward as hook
+    c = CASES["qwen2_5_vl"][0]
+    ids, feats, pos3, mask = S.qwen_inputs(c)
+    L = ids.shape[1]
+    pos4 = torch.cat((torch.arange(L).view(1, 1, L), pos3 * 2 + 1), dim=0)
+    _, seen, _ = _run_qwen("qwen2_5_vl", hook, c, "cpu", position_ids=pos4, cache_position=torch.arange(L))
+    keep = torch.tensor(c["keep_token_indices"])
+    got = seen["position_ids"]
+    assert got.shape == (4, 1, keep.numel())
+    assert got[0, 0].tolist() == list(range(keep.numel()))
+    assert torch.equal(got[1:, 0], (pos3 * 2 + 1)[:, 0][:, keep])
+    assert seen["cache_position"].tolist() == list(range(keep.numel()))

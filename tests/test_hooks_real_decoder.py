@@ -1,0 +1,74 @@
+"""The Qwen2.5-VL hook through the installed transformers' REAL decoder stack (tiny random-init model on CPU; the
+device pass is replaced by the oracle): the hooked forward must equal running the decoder by hand on the pruned
+prompt with positions computed BEFORE pruning (the reference's semantics, models/qwen2_5_vl.py:89-183)."""
+import os
+import types
+
+import pytest
+import torch
+
+import _stub_models as S
+import oracle as O
+
+D = 64
+
+
+def _model():
+    from transformers.models.qwen2_5_vl import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLModel
+    vision = dict(depth=1, hidden_size=32, intermediate_size=32, num_heads=2, out_hidden_size=D,
+                  fullatt_block_indexes=[0], spatial_merge_size=2)
+    text = dict(vocab_size=S.VOCAB, hidden_size=D, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=2, max_position_embeddings=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                rope_parameters=dict(rope_type="default", mrope_section=[4, 6, 6], rope_theta=10000.0))
+    cfg = Qwen2_5_VLConfig(text_config=text, vision_config=vision, image_token_id=S.IMAGE_ID, video_token_id=S.VIDEO_ID)
+    torch.manual_seed(0)
+    return Qwen2_5_VLModel(cfg).eval()
+
+
+@pytest.fixture()
+def hooked(monkeypatch):
+    import vidcom2_amd.models.qwen2_5_vl as H
+
+    def keep(feat, g, m, base):
+        t, h, w = g.tolist()
+        return O.compress_indices(feat.contiguous(), (h * w) // (m * m), base)["global_idx"]
+
+    O.set_mode("torch")
+    monkeypatch.setattr(H, "_compute_keep_indices", keep)
+    monkeypatch.setenv("COMPRESSOR", "vidcom2")
+    monkeypatch.setenv("R_RATIO", "0.5")
+    return H.Qwen2_5_VLModel_forward
+
+
+@pytest.mark.parametrize("with_types", [True, False], ids=["mrope_positions", "decoder_inferred_positions"])
+@torch.no_grad()
+def test_hook_equals_manual_pruned_run(hooked, with_types):
+    c = dict(D=D, dt="f32", seed=22, r="0.5", grids=[[4, 8, 8], [6, 12, 8]], prefix=7, between=3, suffix=5, mask="2d")
+    ids, feats, _, mask = S.qwen_inputs(c)
+    grid = torch.tensor(c["grids"])
+    model = _model()
+    S.set_video_features(model, feats)
+    mm = (ids == S.VIDEO_ID).int() * 2 if with_types else None
+    kw = dict(input_ids=ids, attention_mask=mask, pixel_values_videos=torch.zeros(1, 4), video_grid_thw=grid,
+              mm_token_type_ids=mm)
+    dense = model(**kw).last_hidden_state
+    model.forward = types.MethodType(hooked, model)
+    out = model(**kw).last_hidden_state
+    st = model._vidcom2_last
+    keep = st.keep_token_indices
+    assert st.pruned and out.shape[1] == keep.numel() < dense.shape[1]
+
+    emb = model.get_input_embeddings()(ids).clone()
+    emb[ids == S.VIDEO_ID] = torch.cat(feats)
+    if with_types:
+        model.rope_deltas = None
+        pos = model.compute_3d_position_ids(input_ids=ids, image_grid_thw=None, video_grid_thw=grid, inputs_embeds=emb,
+                                            attention_mask=mask, past_key_values=None, mm_token_type_ids=mm)
+        pos = pos[..., keep]
+    else:
+        pos = torch.cat((torch.arange(keep.numel()).view(1, 1, -1), keep.view(1, 1, -1).expand(3, 1, -1)), dim=0)
+    manual = model.language_model(inputs_embeds=emb[:, keep], position_ids=pos, attention_mask=mask[:, keep])
+    assert torch.allclose(out, manual.last_hidden_state, atol=1e-6)
+    # and pruning really changes what the decoder sees
+    assert not torch.allclose(out, dense[:, keep], atol=1e-3)

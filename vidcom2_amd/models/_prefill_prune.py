@@ -76,7 +76,24 @@ class _LanguageModelShim:
                                                 if isinstance(am, dict) else _prune_attention(am, keep))
                 pos = kwargs.get("position_ids")
                 if torch.is_tensor(pos):
-                    kwargs["position_ids"] = pos[..., keep.to(pos.device)]
+                    pos = pos[..., keep.to(pos.device)]
+                    if pos.dim() == 3 and pos.shape[0] == 4:
+                        # transformers >= 4.5x prepends a row of TEXT positions that the decoder only uses to
+                        # detect packed sequences (any step != 1 starts a new one).  The gaps left by the dropped
+                        # video tokens must not read as packing: the kept prompt is one sequence.
+                        pos = pos.clone()
+                        pos[0] = torch.arange(pos.shape[-1], device=pos.device, dtype=pos.dtype).expand_as(pos[0])
+                    kwargs["position_ids"] = pos
+                elif pos is None and "position_ids" in kwargs:
+                    # the model could not build 3-D positions and leaves them to the decoder, which would number
+                    # the PRUNED prompt 0..S'-1.  The reference computes positions before pruning and slices them
+                    # (qwen2_5_vl.py:89-118): do the same with the plain positions of the full prompt.
+                    rope = keep.view(1, 1, -1).expand(3, embeds.shape[0], -1)
+                    text = torch.arange(keep.numel(), device=keep.device).view(1, 1, -1).expand(1, embeds.shape[0], -1)
+                    kwargs["position_ids"] = torch.cat((text, rope), dim=0)
+                cp = kwargs.get("cache_position")
+                if torch.is_tensor(cp) and cp.dim() == 1 and cp.numel() == embeds.shape[1]:
+                    kwargs["cache_position"] = cp[: keep.numel()]       # prefill: slots 0 .. S'-1 of the KV cache
                 # Qwen3-VL deepstack: per-layer features of the visual tokens, row i <-> i-th True of the mask
                 # (models/qwen3_vl.py:141-149, 200-226 of the reference)
                 vpm = kwargs.get("visual_pos_masks")
