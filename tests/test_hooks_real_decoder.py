@@ -72,3 +72,37 @@ def test_hook_equals_manual_pruned_run(hooked, with_types):
     assert torch.allclose(out, manual.last_hidden_state, atol=1e-6)
     # and pruning really changes what the decoder sees
     assert not torch.allclose(out, dense[:, keep], atol=1e-3)
+
+
+@torch.no_grad()
+def test_generate_runs_with_pruned_prefill(hooked):
+    """`generate()` of the installed transformers with the hook bound on the inner model: the prefill is pruned, the
+    decode steps run on the shorter KV cache, and the first new token is the one the manual pruned prefill predicts."""
+    from transformers.models.qwen2_5_vl import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+    from vidcom2_amd.models import install
+    inner_cfg = _model().config
+    torch.manual_seed(0)
+    model = Qwen2_5_VLForConditionalGeneration(inner_cfg).eval()
+    c = dict(D=D, dt="f32", seed=22, r="0.5", grids=[[4, 8, 8], [6, 12, 8]], prefix=7, between=3, suffix=5, mask="2d")
+    ids, feats, _, mask = S.qwen_inputs(c)
+    grid = torch.tensor(c["grids"])
+    S.set_video_features(model.model, feats)
+    mm = (ids == S.VIDEO_ID).int() * 2
+    kw = dict(input_ids=ids, attention_mask=mask, pixel_values_videos=torch.zeros(1, 4), video_grid_thw=grid,
+              mm_token_type_ids=mm, max_new_tokens=3, do_sample=False, eos_token_id=None, pad_token_id=0)
+    assert install(model)
+    out = model.generate(**kw)
+    assert out.shape == (1, ids.shape[1] + 3)
+    st = model.model._vidcom2_last
+    assert st.pruned
+    keep = st.keep_token_indices
+    emb = model.model.get_input_embeddings()(ids).clone()
+    emb[ids == S.VIDEO_ID] = torch.cat(feats)
+    model.model.rope_deltas = None
+    pos = model.model.compute_3d_position_ids(input_ids=ids, image_grid_thw=None, video_grid_thw=grid, inputs_embeds=emb,
+                                              attention_mask=mask, past_key_values=None, mm_token_type_ids=mm)
+    h = model.model.language_model(inputs_embeds=emb[:, keep], position_ids=pos[..., keep],
+                                   attention_mask=mask[:, keep]).last_hidden_state
+    first = model.lm_head(h[:, -1]).argmax(-1)
+    assert int(first) == int(out[0, ids.shape[1]])
