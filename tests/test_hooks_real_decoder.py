@@ -106,3 +106,64 @@ def test_generate_runs_with_pruned_prefill(hooked):
                                    attention_mask=mask[:, keep]).last_hidden_state
     first = model.lm_head(h[:, -1]).argmax(-1)
     assert int(first) == int(out[0, ids.shape[1]])
+
+
+@torch.no_grad()
+def test_qwen3_hook_through_real_decoder_with_deepstack(hooked):
+    from transformers.models.qwen3_vl import Qwen3VLConfig
+    from transformers.models.qwen3_vl.modeling_qwen3_vl import Qwen3VLModel
+    from vidcom2_amd.models.qwen3_vl import Qwen3VLModel_forward
+    vision = dict(depth=1, hidden_size=32, intermediate_size=32, num_heads=2, out_hidden_size=D, spatial_merge_size=2,
+                  deepstack_visual_indexes=[0], num_position_embeddings=16)
+    text = dict(vocab_size=S.VOCAB, hidden_size=D, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=2, head_dim=32, max_position_embeddings=4096, bos_token_id=1, eos_token_id=2,
+                pad_token_id=0, rope_parameters=dict(rope_type="default", mrope_section=[4, 6, 6], rope_theta=10000.0,
+                                                     mrope_interleaved=True))
+    cfg = Qwen3VLConfig(text_config=text, vision_config=vision, image_token_id=S.IMAGE_ID, video_token_id=S.VIDEO_ID)
+    torch.manual_seed(0)
+    model = Qwen3VLModel(cfg).eval()
+    c = dict(D=D, dt="f32", seed=22, r="0.5", grids=[[4, 8, 8], [6, 12, 8]], prefix=7, between=3, suffix=5, mask="2d")
+    ids, feats, pos, mask = S.qwen_inputs(c)
+    deep = S.deepstack_feats(sum(f.shape[0] for f in feats), D, torch.float32, 5, layers=1)
+    S.set_video_features(model, feats, deep)
+    kw = dict(input_ids=ids, attention_mask=mask, position_ids=pos, pixel_values_videos=torch.zeros(1, 4),
+              video_grid_thw=torch.tensor(c["grids"]))
+    model.forward = types.MethodType(Qwen3VLModel_forward, model)
+    out = model(**kw).last_hidden_state
+    st = model._vidcom2_last
+    keep = st.keep_token_indices
+    assert st.pruned and out.shape[1] == keep.numel()
+    emb = model.get_input_embeddings()(ids).clone()
+    vm = ids == S.VIDEO_ID
+    emb[vm] = torch.cat(feats)
+    flags = torch.zeros(ids.shape[1], dtype=torch.bool)
+    flags[keep] = True
+    manual = model.language_model(inputs_embeds=emb[:, keep], position_ids=pos[..., keep], attention_mask=mask[:, keep],
+                                  visual_pos_masks=vm[:, keep], deepstack_visual_embeds=[d[flags[vm[0]]] for d in deep])
+    assert torch.allclose(out, manual.last_hidden_state, atol=1e-6)
+
+
+@torch.no_grad()
+def test_qwen2vl_hook_through_real_decoder(monkeypatch):
+    from transformers.models.qwen2_vl import Qwen2VLConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLModel
+    import vidcom2_amd.models.qwen2_vl as H2
+    O.set_mode("torch")
+    monkeypatch.setenv("R_RATIO", "0.5")
+    monkeypatch.setattr(H2, "_keep_index", lambda merged, g, ms=2: O.compress_indices(
+        merged.contiguous(), int((g[:, 1] // ms) * (g[:, 2] // ms)), 0.5)["global_idx"])
+    vision = dict(depth=1, embed_dim=32, hidden_size=D, num_heads=2, mlp_ratio=1, spatial_merge_size=2)
+    text = dict(vocab_size=S.VOCAB, hidden_size=D, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=2, max_position_embeddings=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                rope_parameters=dict(rope_type="default", mrope_section=[4, 6, 6], rope_theta=10000.0))
+    cfg = Qwen2VLConfig(text_config=text, vision_config=vision, image_token_id=S.IMAGE_ID, video_token_id=S.VIDEO_ID)
+    torch.manual_seed(0)
+    model = Qwen2VLModel(cfg).eval()
+    c = dict(D=D, dt="f32", seed=23, r="0.5", grids=[[6, 12, 8]], prefix=7, between=0, suffix=5, mask="2d")
+    ids, feats, _, mask = S.qwen_inputs(c)
+    S.set_video_features(model, feats)
+    model.forward = types.MethodType(H2.Qwen2VLModel_forward, model)
+    out = model(input_ids=ids, attention_mask=mask, pixel_values_videos=torch.zeros(1, 4),
+                video_grid_thw=torch.tensor(c["grids"]), mm_token_type_ids=(ids == S.VIDEO_ID).int() * 2)
+    st = model._vidcom2_last
+    assert st.pruned and out.last_hidden_state.shape[1] == st.keep_token_indices.numel() < ids.shape[1]
