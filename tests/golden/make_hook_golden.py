@@ -101,6 +101,21 @@ def run_llava():
         stub = S.StubLlava(c["D"], DT[c["dt"]], "cpu", c["seed"], c["merge"], c["newline"])
         mine = stub.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [feats], ["video"], None)
         assert torch.equal(mine[4], plain[4]), c["name"]
+        # and our wrapper hook bound on UPSTREAM's real class (device pass replaced by the oracle) must give what
+        # the reference's patched copy gives
+        import oracle as O
+        import vidcom2_amd.models.llava as HL
+        O.set_mode("torch")
+        saved = HL.vidcom2_compression
+        HL.vidcom2_compression = (lambda flat, model="llava_ov", base_scale=0.25, frame_token_len=None, img_feat=None:
+                                  O.vidcom2_compression(flat.contiguous(), model, base_scale, frame_token_len, img_feat))
+        try:
+            m2 = RefLlava(c)
+            m2.prepare_inputs_labels_for_multimodal = types.MethodType(HL.cus_prepare_inputs_labels_for_multimodal, m2)
+            ours = m2.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [feats], ["video"], None)
+        finally:
+            HL.vidcom2_compression = saved
+        assert torch.equal(ours[4], comp[4]), ("wrapper on upstream != reference hook", c["name"])
         out.append(dict(c, plain_shape=list(plain[4].shape), plain_sha=sha(plain[4]),
                         comp_shape=list(comp[4].shape), comp_sha=sha(comp[4])))
         print("llava", c["name"], list(plain[4].shape), "->", list(comp[4].shape))
