@@ -106,15 +106,17 @@ __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __r
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { sm[wave][j][lane] = s[j]; sm[wave][VEC + j][lane] = q[j]; }
   __syncthreads();
-  if (wave == 0 && active) {
+  // all four waves add the four wave sums (wave order: fixed) and store with consecutive threads on consecutive
+  // columns of the slab: the slab's 64 * VEC columns, sums first, then squares
+  const int64_t c0 = int64_t(blockIdx.x) * 64 * VEC;
+  for (int t = threadIdx.x; t < 2 * 64 * VEC; t += kStatsWaves * 64) {
+    const int which = t / (64 * VEC), lc = t % (64 * VEC);
+    const int l = lc / VEC, j = lc % VEC;
+    if (c0 + lc < D) {
+      double a = 0.0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int w = 0; w < kStatsWaves; ++w) { a += sm[w][j][lane]; b += sm[w][VEC + j][lane]; }
-      const int64_t c = int64_t(cv) * VEC + j;
-      part[(int64_t(blockIdx.y) * 2 + 0) * D + c] = a;
-      part[(int64_t(blockIdx.y) * 2 + 1) * D + c] = b;
+      for (int w = 0; w < kStatsWaves; ++w) a += sm[w][which * VEC + j][l];
+      part[(int64_t(blockIdx.y) * 2 + which) * D + c0 + lc] = a;
     }
   }
 }
