@@ -191,6 +191,10 @@ int vc2_kat_round(const float* in, int64_t n, int dtype, void* out_T, void* stre
 int vc2_profile_enable(int on);
 int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, int64_t* launches);
 
+/* Diagnostic (SYNCHRONISES the device): the "torch order" replay counters of the last pass that used `ws`
+ * for this shape, out8 = host int32[8]. */
+int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws, int32_t* out8_host);
+
 /* ---- host helper -------------------------------------------------------------------- */
 /* torch.topk(v, k, largest=False, sorted=sorted) ORDER on host memory (ATen TopKImpl.h:
  * libstdc++ partial_sort / nth_element + sort).  Used only by the standalone

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "_lib", "libvc2hip.so")
+LIB_PATH = os.environ.get("VC2_LIB_PATH") or os.path.join(_PKG, "_lib", "libvc2hip.so")   # (override: A/B builds)
 
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 MAP_LINEAR, MAP_GRID_VID, MAP_LOCAL = 0, 1, 2
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "vc2_set_side_stream": [_i32],
     "vc2_profile_enable": [_i32],
     "vc2_profile_collect": [_i32, _vp, _vp, _vp],
+    "vc2_pass_counters": [_i64, _i64, _i64, _i32, _vp, _vp],
     "vc2_last_error": [],
     "vc2_version": [],
 }

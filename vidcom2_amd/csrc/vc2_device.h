@@ -31,6 +31,43 @@ template <> __device__ __forceinline__ float rnT<VC2_F16>(float v) {
   return static_cast<float>(static_cast<_Float16>(v));      // v_cvt_f16_f32 (RNE) + v_cvt_f32_f16
 }
 
+// RN_T of two values at once (one v_cvt_pk_* instead of two)
+template <int DT> __device__ __forceinline__ void rnT2(float a, float b, float& ra, float& rb) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  if constexpr (DT == VC2_F32) { ra = a; rb = b; }
+  else if constexpr (DT == VC2_BF16) {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    const f2_t w = __builtin_convertvector(__builtin_convertvector((f2_t){a, b}, b2_t), f2_t);
+    ra = w.x; rb = w.y;
+  } else {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const f2_t w = __builtin_convertvector(__builtin_convertvector((f2_t){a, b}, h2_t), f2_t);
+    ra = w.x; rb = w.y;
+  }
+}
+
+// the same on a register pair
+typedef float f2_t __attribute__((ext_vector_type(2)));
+template <int DT> __device__ __forceinline__ f2_t rnT2v(f2_t v) {
+  if constexpr (DT == VC2_F32) {
+    return v;
+  } else if constexpr (DT == VC2_BF16) {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(__builtin_convertvector(v, b2_t), f2_t);
+  } else {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(__builtin_convertvector(v, h2_t), f2_t);
+  }
+}
+
+// (a, b) -> (a*a, b*b) in ONE packed instruction (the compiler scalarises the vector multiply here)
+__device__ __forceinline__ f2_t pk_square(f2_t v) {
+  f2_t r;
+  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
+
 // ---- scalar T load / store -----------------------------------------------------------
 template <int DT> __device__ __forceinline__ float ldT(const void* p, int64_t i) {
   if constexpr (DT == VC2_F32) {
@@ -126,6 +163,28 @@ __device__ __forceinline__ double wave_sum_bcast(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
+}
+
+// The same for fp32 (the "torch order" sweeps accumulate in fp32 with a proven error bound):
+// a fixed reduction tree, so every lane returns the same bits and the result is run-to-run identical.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_addf(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_bcast_f32(float v) {
+  v = dpp_addf<0xB1, 0xF>(v);
+  v = dpp_addf<0x4E, 0xF>(v);
+  v = dpp_addf<0x141, 0xF>(v);
+  v = dpp_addf<0x140, 0xF>(v);
+  v = dpp_addf<0x142, 0xA>(v);
+  v = dpp_addf<0x143, 0xC>(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t wave_max_bcast_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
 }
 
 __device__ __forceinline__ float wave_max_nanprop(float v) {  // NaN wins (torch max semantics)

@@ -29,6 +29,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -284,6 +287,59 @@ template <int DT> __device__ __forceinline__ float lds_elem(const unsigned char*
   else return float(reinterpret_cast<const _Float16*>(rowbuf)[c]);
 }
 
+// the raw bits of one row element in LDS (16-bit types zero-extended), and their fp32 value
+template <int DT> __device__ __forceinline__ uint32_t lds_raw(const unsigned char* rowbuf, int c) {
+  if constexpr (DT == VC2_F32) return reinterpret_cast<const uint32_t*>(rowbuf)[c];
+  else return uint32_t(reinterpret_cast<const uint16_t*>(rowbuf)[c]);
+}
+template <int DT> __device__ __forceinline__ float raw_to_f32(uint32_t raw) {
+  if constexpr (DT == VC2_F32) return __uint_as_float(raw);
+  else if constexpr (DT == VC2_BF16) return __uint_as_float(raw << 16);
+  else { union { uint16_t u; _Float16 h; } c; c.u = uint16_t(raw); return float(c.h); }
+}
+// two raw row elements in registers
+template <int DT> struct RawPair {
+  typedef uint32_t type;
+  static __device__ __forceinline__ type make(uint32_t a, uint32_t b) { return a | (b << 16); }
+  static __device__ __forceinline__ float lo(type p) {
+    if constexpr (DT == VC2_BF16) return __uint_as_float(p << 16); else return raw_to_f32<DT>(p & 0xFFFFu);
+  }
+  static __device__ __forceinline__ float hi(type p) {
+    if constexpr (DT == VC2_BF16) return __uint_as_float(p & 0xFFFF0000u); else return raw_to_f32<DT>(p >> 16);
+  }
+};
+template <> struct RawPair<VC2_F32> {
+  struct type { uint32_t a, b; };
+  static __device__ __forceinline__ type make(uint32_t a, uint32_t b) { return type{a, b}; }
+  static __device__ __forceinline__ float lo(type p) { return __uint_as_float(p.a); }
+  static __device__ __forceinline__ float hi(type p) { return __uint_as_float(p.b); }
+};
+// two T values (both exactly representable in T) kept in registers: fp32 -> a register pair, 16-bit T -> packed
+template <int DT> struct CentrePair {
+  typedef uint32_t type;
+  static __device__ __forceinline__ uint32_t t_bits(float v) {
+    if constexpr (DT == VC2_BF16) return __float_as_uint(v) >> 16;
+    else { union { uint16_t u; _Float16 h; } c; c.h = _Float16(v); return uint32_t(c.u); }
+  }
+  static __device__ __forceinline__ type pack(float a, float b) { return t_bits(a) | (t_bits(b) << 16); }
+  // (volatile asm: the unpack must stay inside the row loop -- hoisted, it would double the registers again)
+  static __device__ __forceinline__ f2_t unpack(type p) {
+    f2_t r;
+    if constexpr (DT == VC2_BF16)
+      asm volatile("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2" : "=&v"(r.x), "=v"(r.y) : "v"(p));
+    else
+      asm volatile("v_cvt_f32_f16_e32 %0, %2\n\t"
+                   "v_cvt_f32_f16_sdwa %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+                   : "=&v"(r.x), "=v"(r.y) : "v"(p));
+    return r;
+  }
+};
+template <> struct CentrePair<VC2_F32> {
+  typedef f2_t type;
+  static __device__ __forceinline__ type pack(float a, float b) { return (f2_t){a, b}; }
+  static __device__ __forceinline__ f2_t unpack(type p) { return p; }
+};
+
 // x^ = RN_f32(v / dn) through one fp64 multiply: inv = RN_f64(1/dn); a quotient of two fp32 numbers is
 // never closer than 2^-49 (relative) to a fp32 rounding boundary, the fp64 product is within 2^-52 of
 // it, so the final fp64->fp32 rounding lands where the IEEE fp32 division does -- at a third of the
@@ -295,7 +351,14 @@ __device__ __forceinline__ float div_via_f64(float v, double inv) { return float
 __host__ __device__ inline size_t row_lds_bytes(int D, int ES) { return (size_t(D) * ES + 15) / 16 * 16 + 16; }
 
 // Issue the DMA of one row into `rowbuf` (VEC > 1) / copy it synchronously (scalar fallback).
-template <int DT, int VEC>
+// AUX = cache policy bits of the DMA (0 default, 2 = nt: streamed, not kept).
+#ifndef VC2_AUX_S2
+#define VC2_AUX_S2 0
+#endif
+#ifndef VC2_AUX_S3
+#define VC2_AUX_S3 0
+#endif
+template <int DT, int VEC, int AUX = 0>
 __device__ __forceinline__ void row_issue(const void* __restrict__ x, int64_t row, int D, int CV,
                                           unsigned char* rowbuf, int lane) {
   constexpr int ES = Tr<DT>::ES;
@@ -311,7 +374,7 @@ __device__ __forceinline__ void row_issue(const void* __restrict__ x, int64_t ro
       const int cv = j * 64 + lane;
       if (cv < CV)
         __builtin_amdgcn_global_load_lds((glb_void_t*)(src + int64_t(cv) * 16), (lds_void_t*)(rowbuf + j * 1024),
-                                         16, 0, 0);
+                                         16, 0, AUX);
     }
   }
 }
@@ -327,11 +390,14 @@ __device__ __forceinline__ void row_wait() {
 template <int NPLB>
 __device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, int C, int D, int lane,
                                                  int (&coff)[NPLB]) {
+  int t[NPLB];
 #pragma unroll
-  for (int i = 0; i < NPLB; ++i) {
-    const int p = i * 64 + lane;
-    coff[i] = p < C ? (cols ? cols[p] : p) : D;
+  for (int i = 0; i < NPLB; ++i) {                      // unconditional (clamped) loads: all in flight together
+    const uint32_t p = uint32_t(i * 64 + lane);
+    t[i] = cols ? cols[p < uint32_t(C) ? p : uint32_t(C - 1)] : int(p);
   }
+#pragma unroll
+  for (int i = 0; i < NPLB; ++i) coff[i] = i * 64 + lane < C ? t[i] : D;
 }
 
 // ---- strict mode: torch's own fp32 accumulation order for the tokens where it matters -----------------
@@ -341,7 +407,6 @@ __device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, i
 // Their fp32 noise (<~1e-6 relative) changes the T-rounded result only when the exact value sits that
 // close to a T rounding boundary.  So: compute exactly (fp64), and only when the exact value is within
 // kFragileUlps fp32-ulps of a boundary replay torch's order for that token -- a few tokens per thousand.
-constexpr int kMaxFix = 1 << 16;           // capacity of the sweep-3 strict-mode fix-up queue (entries)
 constexpr int kFragileUlpsNorm = 128;   // >= worst-case bound of the 8-chain FMA norm (232 * 2^-24 on the sum)
 constexpr int kFragileUlpsDist = 48;    // >= worst-case bound of the cascade sum (~42 fp32 adds per lane)
 
@@ -483,16 +548,39 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- "torch order" mode, half precision: fp32 accumulation with a proven bound (ACC = 1) -----------------
+// In "torch order" mode every sum whose exact value lies within kFragileUlps* fp32-ulps of a T rounding boundary
+// is replayed in torch's own order anyway, so the sweeps need not be exact: any fp32 accumulation whose error is
+// bounded by E ulps gives identical bits once the replay margin is widened by E (the value torch computes, the
+// exact value and ours all lie on the same side of every boundary farther than kFragile + E from ours).
+//   norm:  per lane NPLB fused multiply-adds (x*x is exact in fp32 for 8- / 11-bit significands) in two chains,
+//          one add, six tree levels -> relative error <= (NPLB + 7) * 2^-24 on the sum of squares, half of that
+//          plus one rounding after the (correctly rounded) square root: <= (NPLB + 7) / 2 + 1 fp32-ulps;
+//   dist:  per lane NPLB - 1 adds of non-negative terms and six tree levels: <= NPLB + 5 fp32-ulps.
+__host__ __device__ constexpr int acc_norm_ulps(int nplb) { return (nplb + 7) / 2 + 4; }
+__host__ __device__ constexpr int acc_dist_ulps(int nplb) { return nplb + 8; }
+
+// bf16 only: x^ = RN_T(RN_f32(x / dn)) through ONE fp32 multiply by r = v_rcp_f32(dn).  The quotient of two bf16
+// numbers (8-bit significands mx, md) is never a bf16 rounding midpoint (odd 9-bit M): mx * 2^t == md * M would need
+// M | mx; so it stays >= 1 / (md * M) > 2^-17 (relative) away from every midpoint, and a product within 2^-22 of the
+// quotient (1 ulp of v_rcp_f32 + the multiply's rounding) rounds to the same bf16 number.  That argument needs a
+// NORMAL bf16 result; a row takes this path only when every selected element is zero-free and within
+// 2^-63 <= |x| <= 2^50 (then 2^-63 <= dn <= 2^56 and |x^| >= 2^-119); other rows divide exactly (fp64 reciprocal).
+constexpr uint32_t kBf16SpanLo = 0x2000u;     // bf16 bits of 2^-63
+constexpr uint32_t kBf16SpanLen = 0x3880u;    // ... up to 2^50 (0x5880)
+
 // sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and the
 // per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels (compact order).
 // NPLB = compile-time bound on compact positions per lane (ceil(C/64) <= NPLB).
-template <int DT, int VEC, int NPLB>
+// ACC = 0: norms accumulated in fp64 (exactly rounded; "exact" mode and fp32 inputs); ACC = 1: see above.
+// rflag[r] = 1 marks the rows that divide exactly (consumed by sweep 3; ACC = 1, bf16).
+template <int DT, int VEC, int NPLB, int ACC>
 __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
                                                                 int C, const int* __restrict__ cols,
                                                                 int strict, int S, int rows_per_split,
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ nfix_count, int* __restrict__ nfix_list,
-                                                                int nfix_cap) {
+                                                                int nfix_cap, uint8_t* __restrict__ rflag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -512,32 +600,69 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
   int n = n0 + wave;
-  if (n < n1) row_issue<DT, VEC>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+  if (n < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, int64_t(f) * N + n, D, CV, buf0, lane);
   for (; n < n1; n += kRowWaves) {
     const int64_t row = int64_t(f) * N + n;
     row_wait();
-    if (n + kRowWaves < n1) row_issue<DT, VEC>(x, row + kRowWaves, D, CV, buf1, lane);
+    if (n + kRowWaves < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, row + kRowWaves, D, CV, buf1, lane);
     float xv[NPLB];
-    double t = 0.0;
+    float nrm32;
+    bool exact_div = true;                                      // this row's quotients go through the fp64 reciprocal
+    int margin = kFragileUlpsNorm;
+    float s0 = 0.f, s1 = 0.f;
+    if constexpr (ACC == 1) {
+      uint32_t span = 0u;
 #pragma unroll
-    for (int i = 0; i < NPLB; ++i) {
-      xv[i] = lds_elem<DT>(buf0, coff[i]);
-      t = fma(double(xv[i]), double(xv[i]), t);
+      for (int i = 0; i < NPLB; ++i) {
+        if constexpr (DT == VC2_BF16) {
+          const uint32_t raw = reinterpret_cast<const uint16_t*>(buf0)[coff[i]];
+          xv[i] = __uint_as_float(raw << 16);
+          // (padded positions i*64 + lane >= C read the zero pad element: they must not force the exact path)
+          const uint32_t sp = (raw & 0x7FFFu) - kBf16SpanLo;
+          if (i * 64 + 63 < C || i * 64 + lane < C) span = sp > span ? sp : span;
+        } else {
+          xv[i] = lds_elem<DT>(buf0, coff[i]);
+        }
+        if (i & 1) s1 = fmaf(xv[i], xv[i], s1); else s0 = fmaf(xv[i], xv[i], s0);
+      }
+      if constexpr (DT == VC2_BF16) exact_div = __any(span > kBf16SpanLen) != 0;
     }
-    const double n2 = wave_sum_bcast(t);
-    const float nrm32 = float(sqrt(n2));
+    if (ACC == 0 || (DT == VC2_BF16 && exact_div)) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < NPLB; ++i) {
+        if constexpr (ACC == 0) xv[i] = lds_elem<DT>(buf0, coff[i]);
+        t = fma(double(xv[i]), double(xv[i]), t);
+      }
+      nrm32 = float(sqrt(wave_sum_bcast(t)));
+    } else {
+      nrm32 = float(sqrt(double(wave_sum_bcast_f32(s0 + s1))));   // correctly rounded fp32 square root
+      margin = kFragileUlpsNorm + acc_norm_ulps(NPLB);
+    }
     const float norm = rnT<DT>(nrm32);
-    // strict mode: where the exact norm sits within a few fp32 ulps of a T rounding boundary, torch's own
+    // strict mode: where the norm sits within a few fp32 ulps of a T rounding boundary, torch's own
     // fp32 accumulation order decides the result -> queue the row for k_norm_fix (a few per thousand)
-    if (strict && lane == 0 && (strict >= 2 || near_T_boundary<DT>(nrm32, kFragileUlpsNorm)))
+    if (strict && lane == 0 && (strict >= 2 || near_T_boundary<DT>(nrm32, margin)))
       { const int j = atomicAdd(nfix_count, 1); if (j < nfix_cap) nfix_list[j] = int(row); }
     // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
     float dn = rnT<DT>(fmaxf(norm, 1e-12f));
     if (norm != norm) dn = norm;
-    const double inv = 1.0 / double(dn);
-    if (lane == 0) den_out[row] = dn;
+    if (lane == 0) { den_out[row] = dn; if (ACC == 1 && rflag) rflag[row] = exact_div ? 1 : 0; }
+    if (ACC == 1 && DT == VC2_BF16 && !exact_div) {
+      const float r = __builtin_amdgcn_rcpf(dn);
+      static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
 #pragma unroll
-    for (int i = 0; i < NPLB; ++i) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
+      for (int i = 0; i < NPLB; i += 2) {
+        float a, b;
+        rnT2<DT>(xv[i] * r, xv[i + 1] * r, a, b);
+        acc[i] += double(a);
+        acc[i + 1] += double(b);
+      }
+    } else {
+      const double inv = 1.0 / double(dn);
+#pragma unroll
+      for (int i = 0; i < NPLB; ++i) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
+    }
     unsigned char* tbuf = buf0; buf0 = buf1; buf1 = tbuf;
   }
   // combine the 4 waves' column sums in wave order (fixed order): every wave parks its sums in LDS (the row
@@ -853,54 +978,46 @@ __global__ __launch_bounds__(kCFixWaves * 64) void k_centre_fix(const void* __re
   }
 }
 
-// RN_T of two values at once (one v_cvt_pk_* instead of two)
-template <int DT> __device__ __forceinline__ void rnT2(float a, float b, float& ra, float& rb) {
-  typedef float f2_t __attribute__((ext_vector_type(2)));
-  if constexpr (DT == VC2_F32) { ra = a; rb = b; }
-  else if constexpr (DT == VC2_BF16) {
-    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
-    const f2_t w = __builtin_convertvector(__builtin_convertvector((f2_t){a, b}, b2_t), f2_t);
-    ra = w.x; rb = w.y;
-  } else {
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    const f2_t w = __builtin_convertvector(__builtin_convertvector((f2_t){a, b}, h2_t), f2_t);
-    ra = w.x; rb = w.y;
+// 5-scale Gaussian sum of one squared distance (vidcom2.py:62): every op rounded to T, exp = fp64 exp rounded once
+template <int DT>
+__device__ __forceinline__ float gauss_term(float dist, int a) {
+  const float two_a = a == 0 ? 0.25f : a == 1 ? 0.5f : a == 2 ? 1.0f : a == 3 ? 2.0f : 4.0f;   // 2*alpha, alpha = 2^-3 .. 2^1
+  const float arg = rnT<DT>((-dist) / two_a);
+  return rnT<DT>(float(exp(double(arg))));
+}
+template <int DT>
+__device__ __forceinline__ float gauss_sum(float dist) {
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {
+    const float e = gauss_term<DT>(dist, a);
+    acc = (a == 0) ? e : rnT<DT>(acc + e);                   // Python sum(): 0 + t1 is exact
   }
+  return acc;
 }
 
-// the same on a register pair
-typedef float f2_t __attribute__((ext_vector_type(2)));
-template <int DT> __device__ __forceinline__ f2_t rnT2v(f2_t v) {
-  if constexpr (DT == VC2_F32) {
-    return v;
-  } else if constexpr (DT == VC2_BF16) {
-    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
-    return __builtin_convertvector(__builtin_convertvector(v, b2_t), f2_t);
-  } else {
-    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-    return __builtin_convertvector(__builtin_convertvector(v, h2_t), f2_t);
-  }
-}
+// sweep 3 (vidcom2.py:61-62, :32-33): per token dist_v = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with
+// the frame centre, x^ recomputed from X and den; then -- still inside the workgroup -- the 5-scale Gaussian sums
+// v, f, total = RN_T(v + f) and the workgroup's partial sum of v (for the per-frame uniqueness score).
+// Column offsets and both centres of the lane's compact positions live in registers for the whole workgroup; the
+// row loop touches LDS only for the row itself.  Three phases per workgroup (one frame split, <= 64 rows):
+//   1. row loop, one wave per row (ACC: see k_norm_colsum).  In "torch order" mode a sum within the replay margin
+//      of a T rounding boundary is put on a workgroup-local list;
+//   2. the (rare) listed sums are replayed in torch's cascade order by the whole workgroup: every thread recomputes
+//      a few squares from X and scatters them to their SORTED positions (spos) in LDS, wave 0 adds them;
+//   3. 10 exp per token spread over the workgroup's threads, the two running sums, outputs.
+constexpr int kDistMaxRows = 64;
 
-// (a, b) -> (a*a, b*b) in ONE packed instruction (the compiler scalarises the vector multiply here)
-__device__ __forceinline__ f2_t pk_square(f2_t v) {
-  f2_t r;
-  asm("v_pk_mul_f32 %0, %1, %1" : "=v"(r) : "v"(v));
-  return r;
-}
-
-// sweep 3: dist_v[r] = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with the frame centre
-// (vidcom2.py:61), x^ recomputed from X and den.  Column offsets and both centres of the lane's compact
-// positions live in registers for the whole workgroup; the row loop touches LDS only for the row itself.
-template <int DT, int VEC, int NPLB>
+template <int DT, int VEC, int NPLB, int ACC>
 __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
                                                          const int* __restrict__ cols,
                                                          const int* __restrict__ spos, int strict, int S,
                                                          int rows_per_split, const float* __restrict__ den,
+                                                         const uint8_t* __restrict__ rflag,
                                                          const float* __restrict__ vc,
                                                          const float* __restrict__ fc,
-                                                         float* __restrict__ dv_out, float* __restrict__ df_out,
-                                                         int* __restrict__ fix_count, int* __restrict__ fix_list) {
+                                                         void* __restrict__ v_T, void* __restrict__ f_T,
+                                                         float* __restrict__ total, double* __restrict__ vpart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -908,66 +1025,214 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
+  const int nrows = n1 - n0;
   // One row buffer per wave and no intra-wave prefetch: measured faster than double buffering here
   // (45 vs 50 us at 128x196x3584) because the smaller LDS footprint doubles the resident waves.
-  unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]
-  float* dens = reinterpret_cast<float*>(smem + size_t(kRowWaves) * rowb);   // [rows_per_split]
+  unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]; phase 2: float sq[C]
+  const size_t area = (std::max(size_t(kRowWaves) * rowb, size_t(C) * 4 + 16) + 15) / 16 * 16;
+  float* dens = reinterpret_cast<float*>(smem + area);             // [kDistMaxRows]
+  float* dists = dens + kDistMaxRows;                             // [kDistMaxRows][2]  RN_T distances (v, f)
+  float* ebuf = dists + 2 * kDistMaxRows;                         // [kDistMaxRows][10] Gaussian terms
+  int* list = reinterpret_cast<int*>(ebuf + 10 * kDistMaxRows);   // [2 * kDistMaxRows] (local row) * 2 + centre
+  int* lcount = list + 2 * kDistMaxRows;
+  uint8_t* rfl = reinterpret_cast<uint8_t*>(lcount + 4);          // [kDistMaxRows]
+  int n = n0 + wave;
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-  for (int r = n0 + tid; r < n1; r += kRowWaves * 64) dens[r - n0] = den[int64_t(f) * N + r];
-  int coff[NPLB];
-  float cv[NPLB], cf[NPLB];
-  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
-#pragma unroll
-  for (int i = 0; i < NPLB; ++i) {
-    const int p = i * 64 + lane;
-    cv[i] = p < C ? vc[p] : 0.f;
-    cf[i] = p < C ? fc[int64_t(f) * C + p] : 0.f;
+  if (tid == 0) *lcount = 0;
+  for (int r = tid; r < nrows; r += kRowWaves * 64) {
+    dens[r] = den[int64_t(f) * N + n0 + r];
+    rfl[r] = (ACC == 1 && DT == VC2_BF16 && rflag) ? rflag[int64_t(f) * N + n0 + r] : 1;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plain loads done before any DMA is in flight
-  __syncthreads();
-  for (int n = n0 + wave; n < n1; n += kRowWaves) {
-    const int64_t row = int64_t(f) * N + n;
-    row_issue<DT, VEC>(x, row, D, CV, buf0, lane);
-    row_wait();
-    const double inv = 1.0 / double(dens[n - n0]);
-    double pv = 0.0, pf = 0.0;
-    // two compact positions per step: one packed conversion rounds both x^, the two subtract / square pairs
-    // are packed fp32 ops on (video, frame) register pairs -- the kernel is VALU-bound, every
-    // instruction counts.  The fp64 accumulation order (i, then i + 1) is the same as element by element.
-    static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
+  int coff[NPLB];
+  // (video centre, frame centre) of the lane's compact positions: fp32 pairs, or -- half precision -- the two T
+  // values packed in one register (video | frame << 16; two unpack instructions per element buy 28 registers,
+  // i.e. a fourth wave per SIMD)
+#ifndef VC2_DIST_PACKED_CC
+#define VC2_DIST_PACKED_CC 0
+#endif
+  using CP = CentrePair<VC2_DIST_PACKED_CC ? DT : VC2_F32>;
+  typename CP::type cc[NPLB];
+  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
+  {
+    // unconditional loads (clamped index), batched; a load inside a conditional is waited for on the spot, and
+    // 2 * NPLB serialised L2 round trips cost the whole workgroup ~10 us.  (Batches of 8: the temporaries must
+    // not become the kernel's register peak.)
+    constexpr int B = NPLB % 8 == 0 ? 8 : NPLB % 7 == 0 ? 7 : 2;
+    const float* __restrict__ fcf = fc + int64_t(f) * C;
 #pragma unroll
-    for (int i = 0; i < NPLB; i += 2) {
-      const float v0 = lds_elem<DT>(buf0, coff[i]), v1 = lds_elem<DT>(buf0, coff[i + 1]);
-      float xh0, xh1;
-      rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
-      const f2_t d0 = (f2_t){xh0, xh0} - (f2_t){cv[i], cf[i]};
-      const f2_t d1 = (f2_t){xh1, xh1} - (f2_t){cv[i + 1], cf[i + 1]};
-      const f2_t r0 = rnT2v<DT>(d0), r1 = rnT2v<DT>(d1);
-      const f2_t q0 = rnT2v<DT>(pk_square(r0)), q1 = rnT2v<DT>(pk_square(r1));
-      pv += double(q0.x);
-      pf += double(q0.y);
-      pv += double(q1.x);
-      pf += double(q1.y);
-    }
-    pv = wave_sum_bcast(pv);
-    pf = wave_sum_bcast(pf);
-    const float dvv = float(pv), dff = float(pf);
-    if (strict && lane == 0) {
-      // rare: the exact sum is within a few fp32 ulps of a T rounding boundary, where torch's own fp32
-      // accumulation order decides the result -> queue the (row, centre) for k_dist_fix
-      if (strict >= 2 || near_T_boundary<DT>(dvv, kFragileUlpsDist)) {
-        const int j = atomicAdd(fix_count, 1); if (j < kMaxFix) fix_list[j] = int(row) * 2;
+    for (int i0 = 0; i0 < NPLB; i0 += B) {
+      float a[B], b[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const uint32_t p = uint32_t((i0 + j) * 64 + lane), pc = p < uint32_t(C) ? p : uint32_t(C - 1);
+        a[j] = vc[pc];                                             // (32-bit offsets: scalar base + VGPR offset loads)
+        b[j] = fcf[pc];
       }
-      if (strict >= 2 || near_T_boundary<DT>(dff, kFragileUlpsDist)) {
-        const int j = atomicAdd(fix_count, 1); if (j < kMaxFix) fix_list[j] = int(row) * 2 + 1;
+      asm volatile("" ::: "memory");                               // keep the batches apart
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const bool in = (i0 + j) * 64 + lane < C;
+        cc[i0 + j] = CP::pack(in ? a[j] : 0.f, in ? b[j] : 0.f);
       }
     }
-    if (lane == 0) {
-      dv_out[row] = rnT<DT>(dvv);
-      df_out[row] = rnT<DT>(dff);
+  }
+  // (plain loads first: behind an in-flight global_load_lds the compiler waits for EVERY load separately)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (n < n1) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+  __syncthreads();
+  // ---- phase 1 ---------------------------------------------------------------------------------------
+  // The row's results stay in the registers of lane `it` until the loop is over: the compiler orders every LDS
+  // access behind an in-flight global_load_lds with vmcnt(0).
+#ifndef VC2_DIST_PREFETCH
+#define VC2_DIST_PREFETCH 0
+#endif
+  float res_v = 0.f, res_f = 0.f;
+  uint32_t res_flag = 0u;
+  int it = 0;
+  for (; n < n1; n += kRowWaves, ++it) {
+#if VC2_DIST_PREFETCH
+    // wait for the row, pull the lane's elements into registers, re-issue the NEXT row into the same buffer, compute
+    row_wait();
+    const float dn = dens[n - n0];
+    const bool exact_div = DT != VC2_BF16 || ACC == 0 || rfl[n - n0] != 0;
+    typename RawPair<DT>::type raw[NPLB / 2];
+#pragma unroll
+    for (int i = 0; i < NPLB; i += 2) raw[i / 2] = RawPair<DT>::make(lds_raw<DT>(buf0, coff[i]), lds_raw<DT>(buf0, coff[i + 1]));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads are done: the buffer may be refilled
+    if (n + kRowWaves < n1) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n + kRowWaves, D, CV, buf0, lane);
+#define VC2_DIST_ELEMS(i) RawPair<DT>::lo(raw[(i) / 2]), RawPair<DT>::hi(raw[(i) / 2])
+#else
+    // issue the row's DMA, wait, compute straight from LDS
+    if (it) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+    row_wait();
+    const float dn = dens[n - n0];
+    const bool exact_div = DT != VC2_BF16 || ACC == 0 || rfl[n - n0] != 0;
+#define VC2_DIST_ELEMS(i) lds_elem<DT>(buf0, coff[i]), lds_elem<DT>(buf0, coff[(i) + 1])
+#endif
+    float dvv, dff;
+    int margin = kFragileUlpsDist;
+    static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
+    // two compact positions per step: one packed conversion rounds both x^, the two subtract / square pairs
+    // are packed fp32 ops on (video, frame) register pairs
+    if constexpr (ACC == 0) {
+      const double inv = 1.0 / double(dn);
+      double pv = 0.0, pf = 0.0;                                  // accumulation order: i, then i + 1
+#pragma unroll
+      for (int i = 0; i < NPLB; i += 2) {
+        const float vv[2] = {VC2_DIST_ELEMS(i)};
+        const float v0 = vv[0], v1 = vv[1];
+        float xh0, xh1;
+        rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
+        const f2_t d0 = (f2_t){xh0, xh0} - CP::unpack(cc[i]);
+        const f2_t d1 = (f2_t){xh1, xh1} - CP::unpack(cc[i + 1]);
+        const f2_t r0 = rnT2v<DT>(d0), r1 = rnT2v<DT>(d1);
+        const f2_t q0 = rnT2v<DT>(pk_square(r0)), q1 = rnT2v<DT>(pk_square(r1));
+        pv += double(q0.x);
+        pf += double(q0.y);
+        pv += double(q1.x);
+        pf += double(q1.y);
+      }
+      dvv = float(wave_sum_bcast(pv));
+      dff = float(wave_sum_bcast(pf));
+    } else {
+      f2_t acc = (f2_t){0.f, 0.f};
+      auto body = [&](auto exact_tag) {
+        constexpr bool kExact = decltype(exact_tag)::value;
+        const double inv = kExact ? 1.0 / double(dn) : 0.0;
+        const float r = kExact ? 0.f : __builtin_amdgcn_rcpf(dn);
+#pragma unroll
+        for (int i = 0; i < NPLB; i += 2) {
+          const float vv[2] = {VC2_DIST_ELEMS(i)};
+          const float v0 = vv[0], v1 = vv[1];
+          float xh0, xh1;
+          if constexpr (kExact) rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
+          else rnT2<DT>(v0 * r, v1 * r, xh0, xh1);
+          const f2_t d0 = (f2_t){xh0, xh0} - CP::unpack(cc[i]);
+          const f2_t d1 = (f2_t){xh1, xh1} - CP::unpack(cc[i + 1]);
+          const f2_t r0 = rnT2v<DT>(d0), r1 = rnT2v<DT>(d1);
+          const f2_t q0 = rnT2v<DT>(pk_square(r0)), q1 = rnT2v<DT>(pk_square(r1));
+          acc = acc + q0;
+          acc = acc + q1;
+        }
+      };
+      if (exact_div) body(std::true_type{}); else body(std::false_type{});
+      dvv = wave_sum_bcast_f32(acc.x);
+      dff = wave_sum_bcast_f32(acc.y);
+      margin = kFragileUlpsDist + acc_dist_ulps(NPLB);
     }
+    // rare: a sum within a few fp32 ulps of a T rounding boundary, where torch's own fp32 accumulation order
+    // decides the result -> phase 2
+    const uint32_t fl = !strict ? 0u
+                                : ((strict >= 2 || near_T_boundary<DT>(dvv, margin)) ? 1u : 0u) |
+                                      ((strict >= 2 || near_T_boundary<DT>(dff, margin)) ? 2u : 0u);
+    if (lane == it) { res_v = rnT<DT>(dvv); res_f = rnT<DT>(dff); res_flag = fl; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // LDS reads done before the buffer is refilled
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < it) {
+    const int nl = wave + lane * kRowWaves;
+    dists[2 * nl] = res_v;
+    dists[2 * nl + 1] = res_f;
+    if (res_flag & 1u) list[atomicAdd(lcount, 1)] = nl * 2;
+    if (res_flag & 2u) list[atomicAdd(lcount, 1)] = nl * 2 + 1;
+  }
+  __syncthreads();
+  // ---- phase 2: replay torch's cascade sum for the listed (row, centre) pairs ---------------------------
+  if (strict) {
+    const int cnt = *lcount;
+    float* sq = reinterpret_cast<float*>(smem);
+    for (int e = 0; e < cnt; ++e) {
+      const int ent = list[e];
+      const int nl = ent >> 1, which = ent & 1;
+      const int64_t row = int64_t(f) * N + n0 + nl;
+      const double inv = 1.0 / double(dens[nl]);
+      const float* cen = which ? fc + int64_t(f) * C : vc;
+      for (int p = tid; p < C; p += kRowWaves * 64) {
+        const int col = cols ? cols[p] : p, spp = spos ? spos[p] : p;
+        const float xh = rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), inv));
+        const float a = rnT<DT>(xh - cen[p]);
+        sq[spp] = rnT<DT>(a * a);
+      }
+      __syncthreads();
+      if (wave == 0) {
+        const float r = sum_torch_order<DT>(sq, C, lane);
+        if (lane == 0) dists[ent] = rnT<DT>(r);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- phase 3: Gaussian sums, total, partial frame sum ---------------------------------------------
+  for (int it = tid; it < nrows * 10; it += kRowWaves * 64) {
+    const int nl = it / 10, j = it - nl * 10;
+    ebuf[it] = gauss_term<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double vd = 0.0;
+    if (lane < nrows) {
+      const float* e = ebuf + lane * 10;
+      float v = e[0], g = e[5];
+#pragma unroll
+      for (int a = 1; a < 5; ++a) { v = rnT<DT>(v + e[a]); g = rnT<DT>(g + e[5 + a]); }
+      const int64_t row = int64_t(f) * N + n0 + lane;
+      if (v_T) stT<DT>(v_T, row, v);
+      if (f_T) stT<DT>(f_T, row, g);
+      total[row] = rnT<DT>(v + g);
+      vd = double(v);
+    }
+    vd = wave_sum(vd);                                            // fixed tree over T values: exact in fp64
+    if (lane == 0) vpart[blockIdx.x] = vd;
+  }
+}
+
+// s[f] = -mean_T(sum of the frame's v) from the S workgroup partials of k_dist (vidcom2.py:32)
+template <int DT>
+__global__ void k_frame_scores(const double* __restrict__ vpart, int F, int S, int N, float* __restrict__ s_out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double t = 0.0;
+  for (int i = 0; i < S; ++i) t += vpart[int64_t(f) * S + i];
+  s_out[f] = -mean_T<DT>(t, N);
 }
 
 // ======================================================================================
@@ -1048,79 +1313,6 @@ __global__ __launch_bounds__(kBudNT) void k_scales(const float* __restrict__ s, 
   scales_body<DT>(s, F, base, temp, zbuf, scales_f32, scales_T);
 }
 
-// Strict-mode fix-up of sweep 3: for every queued (row, centre) recompute the squares, scatter them to their
-// SORTED positions (fp32, over the row buffer once the row has been consumed) and add them in torch's
-// cascade-sum order.  One wave per entry; a handful of entries per thousand tokens.
-template <int DT, int VEC, int NPLB>
-__global__ __launch_bounds__(64) void k_dist_fix(const void* __restrict__ x, int N, int D, int CV, int C,
-                                                 const int* __restrict__ cols, const int* __restrict__ spos,
-                                                 const float* __restrict__ den, const float* __restrict__ vc,
-                                                 const float* __restrict__ fc, float* __restrict__ dv_out,
-                                                 float* __restrict__ df_out, const int* __restrict__ fix_count,
-                                                 const int* __restrict__ fix_list, int max_entries) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int ES = Tr<DT>::ES;
-  const size_t rowb = row_lds_bytes(D, ES);
-  const int lane = threadIdx.x;
-  unsigned char* buf0 = smem;
-  const int count = min(*fix_count, max_entries);
-  if (int(blockIdx.x) >= count) return;
-  if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-  int coff[NPLB], sp[NPLB];
-  bool first = true;
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
-    const int ent = fix_list[e];
-    const int64_t row = ent >> 1;
-    const int which = ent & 1;
-    row_issue<DT, VEC>(x, row, D, CV, buf0, lane);              // the DMA overlaps the loads below
-    if (first) {
-      load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
-#pragma unroll
-      for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; sp[i] = p < C ? (spos ? spos[p] : p) : -1; }
-      first = false;
-    }
-    const int f = int(row / N);
-    const float* cen = which ? fc + int64_t(f) * C : vc;
-    const double inv = 1.0 / double(den[row]);
-    float q[NPLB];
-    float cc[NPLB];
-#pragma unroll
-    for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; cc[i] = p < C ? cen[p] : 0.f; }
-    row_wait();
-#pragma unroll
-    for (int i = 0; i < NPLB; ++i) {
-      const float v = lds_elem<DT>(buf0, coff[i]);
-      const float xh = rnT<DT>(div_via_f64(v, inv));
-      const float a = rnT<DT>(xh - cc[i]);
-      q[i] = rnT<DT>(a * a);
-    }
-    wave_lds_fence();
-    float* sq = reinterpret_cast<float*>(buf0);
-#pragma unroll
-    for (int i = 0; i < NPLB; ++i) if (sp[i] >= 0) sq[sp[i]] = q[i];
-    wave_lds_fence();
-    const float r = sum_torch_order<DT>(sq, C, lane);
-    if (lane == 0) (which ? df_out : dv_out)[row] = rnT<DT>(r);
-    wave_lds_fence();
-    if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-  }
-}
-
-// per-token epilogue (vidcom2.py:62, :32-33): 5-scale Gaussian sums of both distances, total = v+f,
-// and per frame s = -mean(v).  One workgroup per frame.
-template <int DT>
-__device__ __forceinline__ float gauss_sum(float dist) {
-  const float two_a[5] = {0.25f, 0.5f, 1.0f, 2.0f, 4.0f};   // 2*alpha, alpha = 2^-3 .. 2^1
-  float acc = 0.f;
-#pragma unroll
-  for (int a = 0; a < 5; ++a) {
-    const float arg = rnT<DT>((-dist) / two_a[a]);
-    const float e = rnT<DT>(float(exp(double(arg))));
-    acc = (a == 0) ? e : rnT<DT>(acc + e);                   // Python sum(): 0 + t1 is exact
-  }
-  return acc;
-}
-
 // _multi_scale_gaussian(x, center, alphas) as a standalone call (vidcom2.py:59-62): x T[R, C] is taken
 // as given (already normalised / channel-selected by the caller), centre T[1 | R/N, C].  One wave per
 // row: RN_T(RN_T(x - c)^2) per element, the row sum exact (fp64) or -- `strict` -- in torch's cascade
@@ -1163,29 +1355,6 @@ __global__ __launch_bounds__(kMsgWaves * 64) void k_multi_scale_gaussian(const v
       stT<DT>(out, r, g);
     }
   }
-}
-
-template <int DT>
-__global__ __launch_bounds__(256) void k_token_epilogue(const float* __restrict__ dv,
-                                                        const float* __restrict__ df, int N,
-                                                        void* __restrict__ v_T, void* __restrict__ f_T,
-                                                        float* __restrict__ total, float* __restrict__ s_out) {
-  __shared__ double sm[4];
-  const int f = blockIdx.x;
-  double acc = 0.0;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const int64_t i = int64_t(f) * N + n;
-    const float v = gauss_sum<DT>(dv[i]);
-    const float g = gauss_sum<DT>(df[i]);
-    if (v_T) stT<DT>(v_T, i, v);
-    if (f_T) stT<DT>(f_T, i, g);
-    total[i] = rnT<DT>(v + g);
-    acc += double(v);
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) s_out[f] = -mean_T<DT>(sm[0] + sm[1] + sm[2] + sm[3], N);
 }
 
 // k_f = clamp_min(long(round(RN_T(scale_f * tpf))), 1)   (vidcom2.py:72)
@@ -1396,10 +1565,11 @@ struct Plan {
   int64_t F, N, D, R;
   int dt, ES, VEC, CV, TPB;     // VEC actually used (1 = scalar fallback), column vectors, threads
   int G, rows_per_group;        // sweep-1 row groups
-  int S, rows_per_split;        // sweep-2/3 splits per frame
+  int S, rows_per_split;        // sweep-2 splits per frame
+  int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_dv, o_df, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_fixlist, o_nfixlist, o_corr, o_cfixlist, o_vfixlist, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_cfixlist, o_vfixlist, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
   int cfix_cap, vstride;
 };
 
@@ -1423,6 +1593,14 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, cdiv(512, F)));
   p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), std::min<int64_t>(N, 8 * kRowWaves)));
   p->S = int(cdiv(N, p->rows_per_split));
+  {
+    // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
+    // that the 10 exp per token of the fused epilogue are ONE round over the workgroup's 256 threads
+    int64_t rps = std::max<int64_t>(16, std::min<int64_t>(25, cdiv(p->R, 1024)));
+    rps = std::min<int64_t>(rps, N);
+    p->S2 = int(cdiv(N, rps));
+    p->rows_per_split2 = int(cdiv(N, p->S2));
+  }
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
   p->o_part_stats = take(size_t(p->G) * 2 * D * 8);
@@ -1440,8 +1618,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_csum = take(size_t(D) * 8);
   p->o_csum_part = take(size_t(cdiv(F, kCentreFL)) * D * 8);
   p->o_vc = take(size_t(D) * 4);
-  p->o_dv = take(size_t(p->R) * 4);
-  p->o_df = take(size_t(p->R) * 4);
+  p->o_rflag = take(size_t(p->R));
+  p->o_vpart = take(size_t(F) * p->S2 * 8);
   p->o_total = take(size_t(p->R) * 4);
   p->o_s = take(size_t(F) * 4);
   p->o_zbuf = take(size_t(std::max<int64_t>(F, kMaxFramesTotal)) * 4);       // whole-video frame count
@@ -1449,7 +1627,6 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_scales_T = take(size_t(F) * 4);
   p->o_offs = take(size_t(F + 1) * 8);
   p->o_ticket = take(64);
-  p->o_fixlist = take(size_t(kMaxFix) * 4);
   p->o_nfixlist = take(size_t(p->R) * 4);
   p->o_corr = take(size_t(kMaxCorr) * sizeof(NormCorr));
   p->cfix_cap = int(std::min<int64_t>(std::max<int64_t>(4096, F * D / 32), int64_t(1) << 22));
@@ -1528,31 +1705,34 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, voi
   return check_launch("chan_stats");
 }
 
+// Opt a kernel into > 48 KiB of dynamic LDS -- once per (kernel, device), not per launch.
+std::mutex g_attr_mu;
+std::set<std::pair<const void*, int>> g_attr_done;
+template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what) {
+  if (smem <= 48 * 1024) return VC2_OK;
+  if (smem > 160 * 1024 - 256) return fail(VC2_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (D too large)", what, smem);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  if (g_attr_done.count(key)) return VC2_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024 - 256);
+  if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+  g_attr_done.insert(key);
+  return VC2_OK;
+}
+
 int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* order, int* opos,
                        int* spos, hipStream_t st, int kid = KID_CHAN_SELECT) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = (sel_shared_bytes(int(D)) + 15) / 16 * 16 + (order ? sort_scratch_bytes(int(D)) : 0);
-  static bool attr_set = false;
-  if (smem > 48 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chan_select),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(k_chan_select): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  { int rca = allow_big_lds(&k_chan_select, smem, "k_chan_select"); if (rca) return rca; }
   { ProfScope ps_(kid, st);
   hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, order,
                      opos, spos); }
   return check_launch("chan_select");
-}
-
-template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what) {
-  if (smem <= 48 * 1024) return VC2_OK;
-  if (smem > 160 * 1024 - 256) return fail(VC2_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (D too large)", what, smem);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - 256);
-  if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
-  return VC2_OK;
 }
 
 // 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
@@ -1574,18 +1754,29 @@ inline ChanSet make_chanset(const Plan& p, const int* cols, const int* spos, int
   return cs;
 }
 
-template <int DT, int VEC, int NPLB>
-int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+// ACC policy of the two scoring sweeps: fp32 accumulation + wider replay margins in "torch order" mode (half
+// precision only), fp64 otherwise
+inline bool fast_acc(const Plan& p, const ChanSet& cs) { return cs.strict != 0 && p.dt != VC2_F32; }
+
+template <int DT, int VEC, int NPLB, int ACC>
+int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
   const int* cols = cs.cols; const int C = cs.C;
   const size_t smem = std::max<size_t>(2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES),
                                       size_t(kRowWaves) * NPLB * 64 * 8);          // row buffers, then the combine
-  int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB>, smem, "k_norm_colsum");
+  int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC>, smem, "k_norm_colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.rows_per_split,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
-                     wsp<int>(ws, p.o_nfixlist), int(p.R));
+                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag));
   return VC2_OK;
+}
+template <int DT, int VEC, int NPLB>
+int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+  if constexpr (DT != VC2_F32) {
+    if (fast_acc(p, cs)) return launch_norm_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, st);
+  }
+  return launch_norm_acc<DT, VEC, NPLB, 0>(p, x, cs, ws, st);
 }
 template <int DT, int VEC, int NPLB>
 int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
@@ -1600,37 +1791,28 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
                      wsp<NormCorr>(ws, p.o_corr), int(p.N));
   return VC2_OK;
 }
-template <int DT, int VEC, int NPLB>
-int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+struct DistOut { void* v_T; void* f_T; float* total; };
+
+template <int DT, int VEC, int NPLB, int ACC>
+int launch_dist_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
   const int* cols = cs.cols; const int C = cs.C;
-  // one workgroup per (frame, split): ~32 rows each, at least ~768 workgroups when the video allows
-  int64_t rps = std::max<int64_t>(16, std::min<int64_t>(64, cdiv(p.R, 768)));
-  rps = std::min<int64_t>(rps, p.N);
-  const int S2 = int(cdiv(p.N, rps));
-  rps = cdiv(p.N, S2);
-  const size_t smem = kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES) + size_t(rps) * 4 + 32;
-  int rc = allow_big_lds(&k_dist<DT, VEC, NPLB>, smem, "k_dist");
+  const size_t area = (std::max(size_t(kRowWaves) * row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16) + 15) / 16 * 16;
+  const size_t smem = area + size_t(kDistMaxRows) * (4 + 8 + 40 + 8 + 1) + 64;
+  int rc = allow_big_lds(&k_dist<DT, VEC, NPLB, ACC>, smem, "k_dist");
   if (rc) return rc;
-  { ProfScope ps_(KID_DIST, st);
-  hipLaunchKernelGGL((k_dist<DT, VEC, NPLB>), dim3(unsigned(p.F * S2)), dim3(kRowWaves * 64), smem, st, x, int(p.N),
-                     int(p.D), p.CV, C, cols, cs.spos, cs.strict, S2, int(rps), wsp<float>(ws, p.o_den),
-                     wsp<float>(ws, p.o_vc),
-                     wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df),
-                     wsp<int>(ws, p.o_ticket) + 1, wsp<int>(ws, p.o_fixlist)); }
-  if (cs.strict) {
-    ProfScope ps_(KID_DIST_FIX, st);
-    // fix-up of the queued boundary-fragile sums (the queue length is only known on the device: launch a
-    // fixed number of single-wave workgroups, the surplus ones exit at once)
-    const size_t smem1 = std::max(row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16);   // row, then C fp32
-    int rc1 = allow_big_lds(&k_dist_fix<DT, VEC, NPLB>, smem1, "k_dist_fix");
-    if (rc1) return rc1;
-    const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(2 * p.R, kMaxFix)) : (p.dt == VC2_F16 ? 2048 : 512);
-    hipLaunchKernelGGL((k_dist_fix<DT, VEC, NPLB>), dim3(unsigned(std::min(nfix, 4096))), dim3(64), smem1, st, x,
-                       int(p.N), int(p.D), p.CV, C, cols, cs.spos, wsp<float>(ws, p.o_den), wsp<float>(ws, p.o_vc),
-                       wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df),
-                       wsp<int>(ws, p.o_ticket) + 1, wsp<int>(ws, p.o_fixlist), kMaxFix);
-  }
+  ProfScope ps_(KID_DIST, st);
+  hipLaunchKernelGGL((k_dist<DT, VEC, NPLB, ACC>), dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st, x,
+                     int(p.N), int(p.D), p.CV, C, cols, cs.spos, cs.strict, p.S2, p.rows_per_split2,
+                     wsp<float>(ws, p.o_den), wsp<uint8_t>(ws, p.o_rflag), wsp<float>(ws, p.o_vc),
+                     wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total, wsp<double>(ws, p.o_vpart));
   return VC2_OK;
+}
+template <int DT, int VEC, int NPLB>
+int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
+  if constexpr (DT != VC2_F32) {
+    if (fast_acc(p, cs)) return launch_dist_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, o, st);
+  }
+  return launch_dist_acc<DT, VEC, NPLB, 0>(p, x, cs, ws, o, st);
 }
 // compact positions per lane -> compile-time bucket (28 = 3584-d, 32 = 4096-d models)
 #define VC2_DISPATCH_NPL(npl, FN, ...)                                   \
@@ -1704,17 +1886,22 @@ int zero_counters(const Plan& p, void* ws, hipStream_t st) {
   return VC2_OK;
 }
 
+// sweep 3 incl. the per-token epilogue; s != nullptr: also the per-frame uniqueness scores (stage APIs / sharded
+// path -- the fused pass hands the workgroup partials straight to k_select)
 int launch_phase2(const Plan& p, const void* x, const ChanSet& cs, void* ws, void* v_T, void* f_T,
                   float* total, float* s, hipStream_t st) {
   const int C = cs.C;
+  if (p.rows_per_split2 > kDistMaxRows) return fail(VC2_ERR_UNSUPPORTED, "internal: sweep-3 split too long");
   { int rc = VC2_OK;
   const int npl = int(cdiv(C, 64));
-  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cs, ws, st));
+  const DistOut o{v_T, f_T, total};
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cs, ws, o, st));
   if (rc) return rc; }
-  { ProfScope ps_(KID_EPILOGUE, st);
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_token_epilogue<DT>), dim3(unsigned(p.F)), dim3(256), 0, st,
-                                           wsp<float>(ws, p.o_dv), wsp<float>(ws, p.o_df), int(p.N), v_T, f_T,
-                                           total, s)); }
+  if (s) {
+    ProfScope ps_(KID_EPILOGUE, st);
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_scores<DT>), dim3(unsigned(cdiv(p.F, 128))), dim3(128), 0, st,
+                                             wsp<double>(ws, p.o_vpart), int(p.F), p.S2, int(p.N), s));
+  }
   return check_launch("scores phase 2");
 }
 
@@ -2147,6 +2334,18 @@ int vc2_kat_round(const float* in, int64_t n, int dtype, void* out_T, void* stre
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_kat_round<DT>), dim3(unsigned(cdiv(n, 256))), dim3(256), 0,
                                             static_cast<hipStream_t>(stream), in, n, out_T));
   return check_launch("kat_round");
+}
+
+int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws, int32_t* out8) {
+  // diagnostic: the strict-mode queue counters of the last pass that used `ws` (synchronises the device)
+  if (!ws || !out8) return fail(VC2_ERR_ARG, "null pointer");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(out8, static_cast<const char*>(ws) + p.o_ticket, 32, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(VC2_ERR_LAUNCH, "counter read-back failed");
+  return VC2_OK;
 }
 
 int vc2_profile_enable(int on) {
