@@ -122,7 +122,6 @@ def main():
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 side measurement")
-    ap.add_argument("--no-side-stream", action="store_true", help="A/B: keep the channel-order replay on the main stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,8 +146,6 @@ def main():
     from vidcom2_amd import _ffi, synth
 
     F, N, D, dtype, base = WORKLOADS[args.workload]
-    side = 0 if args.no_side_stream else 1
-    _ffi.lib().vc2_set_side_stream(side)
     es = 4 if dtype == torch.float32 else 2
     F_total = F * world
 
@@ -198,14 +195,12 @@ def main():
     # ---- roofline leg: same steps again with hipEvents around every kernel --------------------------
     roof = None
     kern = {}
-    _ffi.lib().vc2_set_side_stream(0)      # per-kernel events need the kernels back to back on ONE stream
     _ffi.profile_enable(True)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     prof = _ffi.profile_collect()
     _ffi.profile_enable(False)
-    _ffi.lib().vc2_set_side_stream(side)
     for name, (tot, cnt) in prof.items():
         kern[name] = round(tot / cnt * 1e3, 2)          # us per launch
     sweeps = {n: kern[n] for n in ("k_chan_stats", "k_norm_colsum", "k_dist", "k_gather_rows") if n in kern}

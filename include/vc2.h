@@ -56,11 +56,6 @@ const char* vc2_version(void);
  * fp32 inputs are unaffected.  Process-wide. */
 int vc2_set_mode(int mode);
 int vc2_get_mode(void);
-/* 1 (default): in mode 1 vc2_compress replays torch.topk's channel ORDER on an internal side stream, forked from
- * and joined to the caller's stream with events, concurrently with sweep 2.  0: everything on the caller's stream
- * (used by bench.py's per-kernel timing leg). */
-int vc2_set_side_stream(int on);
-
 /* Workspace (bytes) needed by any entry point below for an [F*N, D] input. */
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes);
 
@@ -79,20 +74,15 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
 /* vidcom2.py:41-42  torch.topk(var, k, largest=False): the SET of the k selected channels, with ties
  * at the k-th value broken exactly like the CPU reference (libstdc++ introselect; SURVEY.md
  * Appendix A).  var_f32 = widened T values.  Outputs (each may be NULL): byte mask mask[D]
- * (1 = selected); the ascending channel list cols[k] the scoring sweeps consume; order[k] = the channels
- * in torch.topk(sorted=True)'s OWN order (ascending variance, libstdc++ sort tie order -- the column
- * order of `x[:, topk_idx]`, vidcom2.py:43), opos[k] = position of order[p] inside cols, and its inverse
- * spos[k] = position of cols[i] in that order (what the scoring sweeps need in mode 1). */
-int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
+ * (1 = selected); the ascending channel list cols[k] the scoring sweeps consume; perm[k] = the selected channels
+ * in the order nth_element / partial_sort left them (the input of the ORDER replay below).
+ * With order / opos / spos (need perm; opos / spos also need cols) a second kernel replays torch.topk(sorted=True)'s
+ * OWN order: order[k] = ascending variance, libstdc++ sort tie order -- the column order of `x[:, topk_idx]`,
+ * vidcom2.py:43; opos[k] = position of order[p] inside cols; spos[k] = its inverse (position of cols[i] in that
+ * order: what the "torch order" replays of the scoring sweeps need).  The fused pass and vc2_scores_phase1 do not
+ * call this second kernel: they attach the same job to sweep 2 as a rider workgroup. */
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, int32_t* perm,
                     int32_t* order, int32_t* opos, int32_t* spos, void* stream);
-
-/* vc2_chan_select for the scoring entry points, with the ORDER replay off the critical path:
- * `cols` (and `mask`) are produced on `stream`; in "torch order" mode order/opos/spos are produced on an internal
- * side stream forked from `stream` (one per caller stream), and the next vc2_scores_phase1 / vc2_scores call on that stream waits for them
- * (event join) right before its first fix-up kernel.  In "exact" mode the order outputs are not needed by the
- * scoring entry points and are not computed.  Use plain vc2_chan_select when the order is consumed elsewhere. */
-int vc2_chan_select_overlapped(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
-                               int32_t* order, int32_t* opos, int32_t* spos, void* stream);
 
 /* vidcom2.py:43  x[:, idx] column gather -> out T[R, C]; idx int64[C] on device. */
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C,
@@ -155,9 +145,12 @@ int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, siz
                    double* stats /*[2][D]*/, void* stream);
 int vc2_chan_var_from_stats(const double* stats /*[P][2][D]*/, int64_t P, int64_t R_total, int64_t D,
                             int dtype, void* var_T, float* var_f32, void* stream);
+/* perm != NULL (with var_f32 = the widened variances vc2_chan_select consumed): in mode 1 spos[C] is PRODUCED by a
+ * rider workgroup of sweep 2 (the ORDER replay of vc2_chan_select, off the critical path) and then used by the
+ * fix-up kernels; perm == NULL: spos must already be valid (or NULL: mode 0 / cols == NULL). */
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-                      int64_t C, const int32_t* spos, void* ws, size_t ws_bytes, double* csum /*[C]*/,
-                      void* stream);
+                      int64_t C, int32_t* spos, const int32_t* perm, const float* var_f32, void* ws,
+                      size_t ws_bytes, double* csum /*[C]*/, void* stream);
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                       int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
@@ -194,6 +187,9 @@ int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, i
 /* Diagnostic (SYNCHRONISES the device): the "torch order" replay counters of the last pass that used `ws`
  * for this shape, out8 = host int32[8]. */
 int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws, int32_t* out8_host);
+/* Diagnostic (SYNCHRONISES): every loop of the selection replay is bounded; out8 = how often each bound actually
+ * expired since the last reset (all zero on a healthy run; the test-suite asserts it). */
+int vc2_selftest_counters(int32_t* out8_host, int reset);
 
 /* ---- host helper -------------------------------------------------------------------- */
 /* torch.topk(v, k, largest=False, sorted=sorted) ORDER on host memory (ATen TopKImpl.h:

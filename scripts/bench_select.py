@@ -32,7 +32,7 @@ for D in (1024, 3584, 4096):
         v = torch.rand(D, device=dev)
         if tie: v = (v * 40).round() / 40
         mask = torch.empty(D, dtype=torch.uint8, device=dev); cols = torch.empty(D, dtype=torch.int32, device=dev)
-        fn = lambda: check(lib().vc2_chan_select(ptr(v), D, D // 2, ptr(mask), ptr(cols), None, None, None, stream_ptr(dev)), "cs")
+        fn = lambda: check(lib().vc2_chan_select(ptr(v), D, D // 2, ptr(mask), ptr(cols), None, None, None, None, stream_ptr(dev)), "cs")
         print(f"chan_select D={D} ties={tie}: {timeit(fn):.1f} us")
 # empty kernel launch floor
 x = torch.zeros(16, device=dev)

@@ -172,14 +172,17 @@ def test_selection_kat(i):
     want_set = sorted(want.tolist())
     mask = torch.zeros(n, dtype=torch.uint8, device=dev())
     cols = torch.full((n,), -1, dtype=torch.int32, device=dev())
-    check(lib().vc2_chan_select(ptr(t), n, k, ptr(mask), ptr(cols), None, None, None, stream_ptr(dev())), "chan_select")
+    check(lib().vc2_chan_select(ptr(t), n, k, ptr(mask), ptr(cols), None, None, None, None, stream_ptr(dev())), "chan_select")
     assert mask.cpu().nonzero().flatten().tolist() == want_set
     assert cols[:k].cpu().tolist() == want_set and bool((cols[k:] == -1).all())
     if srt:     # torch.topk(sorted=True) ORDER, replayed on the device (introselect + introsort)
         order = torch.full((n,), -1, dtype=torch.int32, device=dev())
         opos = torch.full((n,), -1, dtype=torch.int32, device=dev())
         spos = torch.full((n,), -1, dtype=torch.int32, device=dev())
-        check(lib().vc2_chan_select(ptr(t), n, k, None, ptr(cols), ptr(order), ptr(opos), ptr(spos), stream_ptr(dev())), "chan_select")
+        perm = torch.full((n,), -1, dtype=torch.int32, device=dev())
+        check(lib().vc2_chan_select(ptr(t), n, k, None, ptr(cols), ptr(perm), ptr(order), ptr(opos), ptr(spos),
+                                    stream_ptr(dev())), "chan_select")
+        assert sorted(perm[:k].cpu().tolist()) == want_set
         assert order[:k].cpu().tolist() == want.tolist()
         assert cols[opos[:k].long()].cpu().tolist() == want.tolist()
         assert order[spos[:k].long()].cpu().tolist() == cols[:k].cpu().tolist()
@@ -364,3 +367,16 @@ def test_compress_batch_matches_sequential():
     assert vc.compress_batch([], 196) == []
     with pytest.raises(RuntimeError):
         vc.compress_batch([xs[0][:100]], 196)
+
+
+def test_selection_engine_loop_bounds_never_expire():
+    """Every loop of the selection / sort replay (vc2_select2.h) is bounded; a bound that expires is counted on the
+    device.  After a spread of passes (incl. everything the tests above ran in this process) all counters are 0."""
+    for (F, N, D, dn) in [(1, 196, 512, "bf16"), (6, 196, 256, "bf16"), (8, 196, 1024, "f16"), (4, 100, 3584, "bf16"),
+                          (3, 1100, 128, "bf16"), (2, 2100, 64, "f32")]:
+        x = make_input(F, N, D, dn, 0, "iid")
+        vc.compress(x.to(dev()), N, 0.25)
+        vc.low_var_channel_order(x.to(dev()))
+    out = (ctypes.c_int32 * 8)()
+    check(lib().vc2_selftest_counters(out, 0), "vc2_selftest_counters")
+    assert list(out) == [0] * 8, list(out)

@@ -30,7 +30,7 @@ def run_case(F, N, D, dt, seed, dist, base):
     res["cidx"] = int((order.cpu() != ref["chan_idx"]).sum())
     # stage: device mask vs oracle set
     mask = torch.zeros(D, dtype=torch.uint8, device=dev)
-    check(lib().vc2_chan_select(ptr(var_f), D, int(D * 0.5), ptr(mask), None, None, None, None, stream_ptr(dev)), "chan_select")
+    check(lib().vc2_chan_select(ptr(var_f), D, int(D * 0.5), ptr(mask), None, None, None, None, None, stream_ptr(dev)), "chan_select")
     rmask = torch.zeros(D, dtype=torch.uint8); rmask[ref["chan_idx"]] = 1
     res["mask"] = int((mask.cpu() != rmask).sum())
     # full pass

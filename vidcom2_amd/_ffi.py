@@ -28,8 +28,7 @@ _SIGNATURES = {
     "vc2_workspace_bytes": [_i64, _i64, _i64, _i32, ctypes.POINTER(_sz)],
     "vc2_kept_capacity": [_i64, _i64, _dbl],
     "vc2_chan_var": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp, _vp],
-    "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
-    "vc2_chan_select_overlapped": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "vc2_gather_cols": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
     "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "vc2_compute_scales": [_vp, _i64, _dbl, _dbl, _i32, _vp, _sz, _vp, _vp],
@@ -40,7 +39,7 @@ _SIGNATURES = {
                      _vp, _vp, _vp, _vp],
     "vc2_chan_stats": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp],
     "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
-    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp],
+    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
     "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp,
                           _vp, _vp, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
@@ -51,10 +50,10 @@ _SIGNATURES = {
     "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],
     "vc2_set_mode": [_i32],
     "vc2_get_mode": [],
-    "vc2_set_side_stream": [_i32],
     "vc2_profile_enable": [_i32],
     "vc2_profile_collect": [_i32, _vp, _vp, _vp],
     "vc2_pass_counters": [_i64, _i64, _i64, _i32, _vp, _vp],
+    "vc2_selftest_counters": [_vp, _i32],
     "vc2_last_error": [],
     "vc2_version": [],
 }

@@ -36,7 +36,7 @@
 #include <vector>
 
 #include "vc2_device.h"
-#include "vc2_select.h"
+#include "vc2_select2.h"
 
 using namespace vc2;
 
@@ -193,64 +193,126 @@ __global__ void k_var_from_stats(const double* __restrict__ stats, const int64_t
 }
 
 // ======================================================================================
-// channel selection (single workgroup; D <= 8192)
+// channel selection (single workgroup of 4 waves; D <= 8192)
 // ======================================================================================
-constexpr int kSelNT = 1024;
+// vidcom2.py:41-42.  k_chan_select replays torch.topk's SELECTION (libstdc++ introselect / heap-select,
+// vc2_select2.h) and writes the ascending list of kept channels the scoring sweeps consume, plus -- perm -- the kept
+// channels in the order nth_element left them.  torch.topk(sorted=True)'s ORDER of those channels (std::sort on that
+// permutation; only the "torch order" replays and the select_low_var_channels API need it) is a second, separate
+// piece of work, chan_order_body: either its own kernel, or a RIDER workgroup of sweep 2 (k_norm_colsum), where it
+// costs nothing -- it finishes long before the sweep does and its consumers run after the sweep.
+constexpr int kSelNT = 1024;        // k_chan_select / k_chan_order: 16 waves (the rider in sweep 2 has 4)
 
-__global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
-                                                        uint8_t* __restrict__ mask, int* __restrict__ cols,
-                                                        int* __restrict__ order, int* __restrict__ opos,
-                                                        int* __restrict__ spos) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  SelShared S = sel_carve(smem, D);
+// block-wide exclusive prefix of a small count (thread-contiguous chunks), fixed order; NW waves
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t c, uint32_t* xch, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan_u32(c);
+  if (lane == 63) xch[wave] = incl;
+  __syncthreads();
+  uint32_t pre = 0u, all = 0u;
+#pragma unroll
+  for (int v = 0; v < NW; ++v) { const uint32_t t = xch[v]; pre += v < wave ? t : 0u; all += t; }
+  total = all;
+  return pre + incl - c;
+}
+
+template <typename W>
+__device__ __forceinline__ void chan_select_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
+                                                 uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                 int* __restrict__ perm) {
+  using T = WordTr<W>;
+  constexpr int NW = kSelNT / 64;
   const int tid = threadIdx.x;
-  dbg_stamp(1);
-  for (int i = tid; i < D; i += kSelNT) {
-    S.key[i] = topk_key(var_f32[i]);
-    S.idx[i] = uint16_t(i);
-  }
+  Sel2<W> S = sel2_carve<W>(smem, D);
+  for (int i = tid; i < D; i += kSelNT) S.w[i] = T::pack(topk_key(var_f32[i]), i);
   __syncthreads();
-  const bool partial = int64_t(k) * 64 <= int64_t(D);
-  if (k >= D && order) introselect_block<kSelNT>(S, D, D - 1);       // nth_element(n-1) still permutes
-  else topk_smallest_block<kSelNT>(S, D, k);
+  if (k >= D) { if (perm) introselect2<W, NW, 2, 2>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
+  else topk_smallest2<W, NW, 2, 2>(S, D, k, tid);
   __syncthreads();
-  if (order) {
-    // torch.topk(sorted=True) ORDER (vidcom2.py:42 returns it; the reference's reductions run in it)
-    if (partial) {
-      if (tid == 0) sel_sort_heap(S, 0, k);                           // partial_sort = heap_select + sort_heap
-      __syncthreads();
-      for (int p = tid; p < k; p += kSelNT) order[p] = int(S.idx[p]);
-    } else {
-      SortScratch Q = sort_carve(smem + (sel_shared_bytes(D) + 15) / 16 * 16, D);
-      introsort_block<kSelNT>(S, Q, k - 1, order);                    // std::sort(q, q + k - 1)
-      if (tid == 0) order[k - 1] = int(S.idx[k - 1]);                 // the nth_element pivot stays last
-    }
-    __syncthreads();
-  }
-  // kept flags (reuse la), mask bytes, and the ascending list of kept channels (ordered compaction)
+  if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
+  // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction)
   for (int i = tid; i < D; i += kSelNT) S.la[i] = (k >= D) ? 1 : 0;
   __syncthreads();
-  if (k < D) {
-    if (order) { for (int i = tid; i < k; i += kSelNT) S.la[order[i]] = 1; }
-    else { for (int i = tid; i < k; i += kSelNT) S.la[S.idx[i]] = 1; }
-  }
+  if (k < D) for (int i = tid; i < k; i += kSelNT) S.la[T::idx(S.w[i])] = 1;
   __syncthreads();
-  const int E = (D + kSelNT - 1) / kSelNT;
-  const int b = tid * E, e = min(D, b + E);
+  const int Ept = (D + kSelNT - 1) / kSelNT;
+  const int b = tid * Ept, e = min(D, b + Ept);
   uint32_t cnt = 0;
   for (int p = b; p < e; ++p) cnt += S.la[p];
-  uint32_t excl, tot;
-  block_scan_pair<kSelNT>(cnt, excl, tot, S.wtot);
-  int o = int(excl);
+  uint32_t tot;
+  int o = int(block_excl_scan<NW>(cnt, S.xch, tot));
   for (int p = b; p < e; ++p) {
     const bool on = S.la[p] != 0;
     if (mask) mask[p] = on ? 1 : 0;
-    if (on) { if (cols) cols[o] = p; S.lb[p] = uint16_t(o); ++o; }     // lb: channel -> compact position
+    if (on) { if (cols) cols[o] = p; ++o; }
+  }
+}
+
+__global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
+                                                        uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                        int* __restrict__ perm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int bad = 0;
+  for (int i = threadIdx.x; i < D; i += kSelNT) bad |= key_fits_u32(var_f32[i]) ? 0 : 1;
+  // widened 16-bit variances pack into 32-bit words (the common case); arbitrary fp32 ones take 64-bit words
+  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, var_f32, D, k, mask, cols, perm);
+  else chan_select_body<uint32_t>(smem, var_f32, D, k, mask, cols, perm);
+}
+__host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
+
+// torch.topk(sorted=True)'s ORDER of the k kept channels from `perm` (what nth_element / partial_sort left in
+// [0, k)): std::sort(q, q + k - 1) with the nth_element pivot staying last, or sort_heap in the partial_sort
+// regime (TopKImpl.h).  order[p] = channel at sorted position p, opos[p] = its position in the ascending list
+// `cols`, spos = the inverse of opos.  64*NW threads; any of the outputs may be null.
+template <typename W, int NW, int SOLO, int COOP>
+__device__ __forceinline__ void chan_order_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
+                                                const int* __restrict__ perm, const int* __restrict__ cols,
+                                                int* __restrict__ order, int* __restrict__ opos,
+                                                int* __restrict__ spos) {
+  using T = WordTr<W>;
+  constexpr int NT = 64 * NW;
+  const int tid = threadIdx.x;
+  Sel2<W> S = sel2_carve<W>(smem, k);
+  unsigned char* p = smem + (sel2_bytes(k, int(sizeof(W))) + 15) / 16 * 16;
+  SortScratch2 Q = sort2_carve(p);
+  int* ord = reinterpret_cast<int*>(p + (sort2_bytes(k) + 15) / 16 * 16);      // [k] sorted order (LDS)
+  uint16_t* cpos = reinterpret_cast<uint16_t*>(ord + k);                       // [D] channel -> position in cols
+  for (int i = tid; i < k; i += NT) { const int c = perm[i]; S.w[i] = T::pack(topk_key(var_f32[c]), c); }
+  if (cols) for (int j = tid; j < k; j += NT) cpos[cols[j]] = uint16_t(j);
+  __syncthreads();
+  const bool partial = int64_t(k) * 64 <= int64_t(D) && k < D;
+  if (partial) {
+    if (tid == 0) s2_sort_heap(S.w, 0, k);                                     // partial_sort = heap_select + sort_heap
+    __syncthreads();
+    for (int q = tid; q < k; q += NT) ord[q] = T::idx(S.w[q]);
+  } else {
+    introsort2<W, NW, SOLO, COOP>(S, Q, k - 1, ord, tid);                      // std::sort(q, q + k - 1)
+    if (tid == 0) ord[k - 1] = T::idx(S.w[k - 1]);                             // the nth_element pivot stays last
   }
   __syncthreads();
-  if (order && opos)        // opos[p] = compact position of the channel at sorted position p; spos = its inverse
-    for (int p = tid; p < k; p += kSelNT) { const int cp = int(S.lb[order[p]]); opos[p] = cp; if (spos) spos[cp] = p; }
-  dbg_stamp(9);
+  for (int q = tid; q < k; q += NT) {
+    const int c = ord[q];
+    if (order) order[q] = c;
+    if (cols && opos) { const int cp = int(cpos[c]); opos[q] = cp; if (spos) spos[cp] = q; }
+  }
+}
+__host__ inline size_t chan_order_lds(int D, int k, int wbytes) {
+  return (sel2_bytes(k, wbytes) + 15) / 16 * 16 + (sort2_bytes(k) + 15) / 16 * 16 + size_t(k) * 4 + size_t(D) * 2 + 64;
+}
+struct OrderArgs {          // the ORDER job (all null: none)
+  const float* var_f32; const int* perm; const int* cols; int* order; int* opos; int* spos; int D; int k;
+};
+
+__global__ __launch_bounds__(kSelNT) void k_chan_order(OrderArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = kSelNT / 64;
+  int bad = 0;
+  for (int i = threadIdx.x; i < a.k; i += kSelNT) bad |= key_fits_u32(a.var_f32[a.perm[i]]) ? 0 : 1;
+  if (__syncthreads_or(bad))
+    chan_order_body<uint64_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos);
+  else
+    chan_order_body<uint32_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos);
 }
 
 template <int DT>
@@ -574,18 +636,31 @@ constexpr uint32_t kBf16SpanLen = 0x3880u;    // ... up to 2^50 (0x5880)
 // NPLB = compile-time bound on compact positions per lane (ceil(C/64) <= NPLB).
 // ACC = 0: norms accumulated in fp64 (exactly rounded; "exact" mode and fp32 inputs); ACC = 1: see above.
 // rflag[r] = 1 marks the rows that divide exactly (consumed by sweep 3; ACC = 1, bf16).
-template <int DT, int VEC, int NPLB, int ACC>
+template <int DT, int VEC, int NPLB, int ACC, int RIDER>
 __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
                                                                 int C, const int* __restrict__ cols,
                                                                 int strict, int S, int rows_per_split,
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ nfix_count, int* __restrict__ nfix_list,
-                                                                int nfix_cap, uint8_t* __restrict__ rflag) {
+                                                                int nfix_cap, uint8_t* __restrict__ rflag,
+                                                                OrderArgs rider) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
+  // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
+  // (RIDER = 0 instantiations carry no ORDER code: it is only ever attached in "torch order" mode.)
+  const int nrider = (RIDER && rider.perm) ? 1 : 0;
+  if constexpr (RIDER != 0) {
+    if (nrider && blockIdx.x == 0) {
+      chan_order_body<uint32_t, kRowWaves, 4, 4>(smem, rider.var_f32, rider.D, rider.k, rider.perm, rider.cols,
+                                                 rider.order, rider.opos, rider.spos);   // (16-bit variances: 32-bit words)
+      return;
+    }
+  }
+  const int bid = int(blockIdx.x) - nrider;
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.x / S, sp = blockIdx.x % S;
+  const int f = bid / S, sp = bid % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
   unsigned char* buf0 = smem + size_t(2 * wave) * rowb;          // [kRowWaves][2][rowb]; later double sacc[C]
@@ -678,7 +753,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     double t = sacc[p];
 #pragma unroll
     for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
-    part[int64_t(blockIdx.x) * C + p] = t;
+    part[int64_t(bid) * C + p] = t;
   }
 }
 
@@ -1372,117 +1447,49 @@ __global__ void k_widen(const void* __restrict__ in, int64_t n, float* __restric
 }
 
 // ======================================================================================
-// per-frame selection + index mapping (vidcom2.py:74-77, :99-115): one workgroup per frame
+// budgets + per-frame selection + index mapping (vidcom2.py:64-77, :99-115): one workgroup per frame
 // ======================================================================================
-// One wave per frame (no workgroup barriers anywhere): the wave computes its own output offset as the
-// sum of the budgets of all earlier frames, replays torch.topk's selection on its N scores in LDS,
-// and writes the kept token indices ascending, already mapped (linear / grid_vid / local).
-constexpr int kFrameNT = 64;
-constexpr int kFusedScalesMaxF = 1024;      // up to this many frames every k_select wave derives the budgets itself
+// Every workgroup (4 waves) first derives the budgets of ALL frames -- compute_scales over the F frame scores, one
+// frame per thread, five block reductions; the scores come straight from sweep 3's workgroup partials (vpart) --
+// and with them its own k and output offset; then replays torch.topk's selection on its N scores (one wave for
+// N <= 1020, all four beyond; vc2_select2.h) and writes the kept token indices ascending, already mapped
+// (linear / grid_vid / local).  No host round trip, no separate budget kernel.
+constexpr int kFrameNT = 256;
+constexpr int kFusedScalesMaxF = 1024;      // up to this many frames every k_select workgroup derives the budgets itself
 
-// compute_scales (vidcom2.py:64-68) by ONE wave, every op in T exactly like scales_body; each lane ends up with
-// the scale of the frames i = lane, lane + 64, ... it asks for through `want` (returns scale of frame `i`).
-// The three reductions are recomputed from the F frame scores (L2-resident, F <= 1024) instead of staged.
-template <int DT> struct WaveScales {
-  float mx, zmax, pmean, base, temp;
-  double esum;
-  __device__ __forceinline__ float z_of(float sv) const { return rnT<DT>(rnT<DT>(sv - mx) / temp); }
-  __device__ __forceinline__ float p_of(float sv) const {
-    const double e = double(float(exp(double(z_of(sv) - zmax))));
-    return rnT<DT>(float(e / esum));
-  }
-  __device__ __forceinline__ float scale_of(float sv) const {
-    float t = rnT<DT>(1.0f + p_of(sv));
-    t = rnT<DT>(t - pmean);
-    t = rnT<DT>(base * t);
-    return t > 1.0f ? 1.0f : t;
-  }
-  __device__ void init(const float* __restrict__ s, int F, float base_, float temp_, int lane) {
-    base = base_; temp = temp_;
-    float m = -INFINITY;
-    bool first = true;
-    for (int i = lane; i < F; i += 64) {
-      const float v = s[i];
-      m = first ? v : ((m != m) ? m : ((v != v) ? v : fmaxf(m, v)));
-      first = false;
-    }
-    mx = wave_max_nanprop(m);
-    float zm = -INFINITY;
-    for (int i = lane; i < F; i += 64) {
-      const float z = z_of(s[i]);
-      zm = (zm != zm) ? zm : ((z != z) ? z : fmaxf(zm, z));
-    }
-    zmax = wave_max_nanprop(zm);
-    double es = 0.0;
-    for (int i = lane; i < F; i += 64) es += double(float(exp(double(z_of(s[i]) - zmax))));
-    esum = wave_sum(es);
-    double ps = 0.0;
-    for (int i = lane; i < F; i += 64) ps += double(p_of(s[i]));
-    pmean = mean_T<DT>(wave_sum(ps), F);
-  }
-};
+__device__ __forceinline__ float block_max_nanprop_256(float v, float* sm) {
+  v = wave_max_nanprop(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int i = 1; i < 4; ++i) { const float t = sm[i]; r = (r != r) ? r : ((t != t) ? t : fmaxf(r, t)); }
+  return r;
+}
 
-
-template <int DT>
-__global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total,
-                                                     const float* __restrict__ scales_f32, int F, int N,
-                                                     int map_mode, int grid_h, int64_t stride, int64_t cap,
-                                                     int64_t* __restrict__ ks, int64_t* __restrict__ offs,
-                                                     int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out,
-                                                     const float* __restrict__ frame_scores, float base,
-                                                     float temp, float* __restrict__ scales_out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  SelShared S = sel_carve(smem, N);
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
-  // budgets: offs[f] = sum_{f' < f} (k_f' + extra).  With frame_scores the wave computes the scales itself
-  // (saves the k_scales kernel boundary, ~5 us); otherwise it reads them.
-  int64_t before = 0;
-  int k;
-  if (frame_scores) {
-    WaveScales<DT> ws;
-    ws.init(frame_scores, F, base, temp, tid);
-    for (int i = tid; i < f; i += kFrameNT) before += budget_k<DT>(ws.scale_of(frame_scores[i]), N) + extra;
-    const float sc = ws.scale_of(frame_scores[f]);
-    k = budget_k<DT>(sc, N);
-    if (tid == 0 && scales_out) scales_out[f] = sc;
-  } else {
-    for (int i = tid; i < f; i += kFrameNT) before += budget_k<DT>(scales_f32[i], N) + extra;
-    k = budget_k<DT>(scales_f32[f], N);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
-  const int64_t o0 = before;
-  if (tid == 0) {
-    ks[f] = k;
-    offs[f] = o0;
-    if (f == F - 1) {
-      const int64_t K = o0 + k + extra;
-      offs[F] = K;
-      K_out[0] = K;
-      K_out[1] = K > cap ? 1 : 0;
-    }
-  }
-  for (int i = tid; i < N; i += kFrameNT) {
-    S.key[i] = topk_key(total[int64_t(f) * N + i]);
-    S.idx[i] = uint16_t(i);
-  }
-  sel_sync<kFrameNT>();
-  topk_smallest_block<kFrameNT>(S, N, k);
-  sel_sync<kFrameNT>();
-  // kept flags (reuse la), then ordered compaction = idx.sort().values
+template <int DT, typename W>
+__device__ __forceinline__ void select_frame_body(unsigned char* smem, const float* __restrict__ total, int f, int N, int k,
+                                  int64_t o0, int map_mode, int grid_h, int64_t stride, int64_t cap,
+                                  int64_t* __restrict__ idx_out) {
+  using T = WordTr<W>;
+  const int tid = threadIdx.x;
+  Sel2<W> S = sel2_carve<W>(smem, N);
+  for (int i = tid; i < N; i += kFrameNT) S.w[i] = T::pack(topk_key(total[int64_t(f) * N + i]), i);
+  __syncthreads();
+  if (N > sel2_capacity(1, 4)) topk_smallest2<W, 4, 4, 8>(S, N, k, tid);
+  else if (tid < 64) topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
+  __syncthreads();
+  // kept flags (la is free now), then ordered compaction = idx.sort().values
   for (int i = tid; i < N; i += kFrameNT) S.la[i] = (k >= N) ? 1 : 0;
-  sel_sync<kFrameNT>();
-  if (k < N)
-    for (int i = tid; i < k; i += kFrameNT) S.la[S.idx[i]] = 1;
-  sel_sync<kFrameNT>();
-  const int E = (N + kFrameNT - 1) / kFrameNT;
-  const int b = tid * E, e = min(N, b + E);
+  __syncthreads();
+  if (k < N) for (int i = tid; i < k; i += kFrameNT) S.la[T::idx(S.w[i])] = 1;
+  __syncthreads();
+  const int Ept = (N + kFrameNT - 1) / kFrameNT;
+  const int b = tid * Ept, e = min(N, b + Ept);
   uint32_t cnt = 0;
   for (int p = b; p < e; ++p) cnt += S.la[p];
-  uint32_t excl, tot;
-  block_scan_pair<kFrameNT>(cnt, excl, tot, S.wtot);
-  int64_t o = o0 + excl;
+  uint32_t tot;
+  int64_t o = o0 + block_excl_scan<kFrameNT / 64>(cnt, S.xch, tot);
   for (int p = b; p < e; ++p) {
     if (S.la[p]) {
       int64_t g;
@@ -1500,6 +1507,145 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       if (oo < cap) idx_out[oo] = int64_t(f) * grid_h * (grid_h + 1) + int64_t(a) * (grid_h + 1) + grid_h;
     }
   }
+}
+
+// Budget sources, in order of preference: vpart (sweep-3 workgroup partials, S2 per frame) or frame_scores
+// (fp32-widened s[F]) -> compute_scales here; else scales_f32[F] as given (the stage API and F > 1024).
+// F_sel / f0: the frames this launch selects ([f0, f0 + gridDim.x) of the F budget frames; the frame-sharded pass
+// budgets over the whole video and selects its own frames).
+template <int DT>
+__global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total,
+                                                     const float* __restrict__ scales_f32, int F, int f0, int N,
+                                                     int map_mode, int grid_h, int64_t stride, int64_t cap,
+                                                     int64_t* __restrict__ ks, int64_t* __restrict__ offs,
+                                                     int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out,
+                                                     const double* __restrict__ vpart, int S2,
+                                                     const float* __restrict__ frame_scores, float base,
+                                                     float temp, float* __restrict__ scales_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float smf[4];
+  __shared__ double smd[4];
+  __shared__ long long smi[8];
+  const int fl = blockIdx.x, FS = gridDim.x;                   // local frame, frames selected by this launch
+  const int f = f0 + fl;                                        // its index among the F budget frames
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
+  // ---- budgets of all frames; thread t holds frames t, t + 256, ...
+  constexpr int FPT = kFusedScalesMaxF / kFrameNT;
+  long long before = 0, all = 0;
+  int kmine = 1;
+  float scmine = 0.f;
+  if (vpart || frame_scores) {
+    float sv[FPT], zz[FPT], pp[FPT];
+    float m = -INFINITY;
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+      const int i = tid + j * kFrameNT;
+      sv[j] = 0.f;
+      if (i < F) {
+        if (vpart) {
+          double t = 0.0;
+          for (int q = 0; q < S2; ++q) t += vpart[int64_t(i) * S2 + q];
+          sv[j] = -mean_T<DT>(t, N);                              // vidcom2.py:32
+        } else {
+          sv[j] = frame_scores[i];
+        }
+        const float v = sv[j];
+        m = first ? v : ((m != m) ? m : ((v != v) ? v : fmaxf(m, v)));
+        first = false;
+      }
+    }
+    // a thread without frames must not inject -inf into a NaN-propagating max of finite values: -inf is the
+    // identity there as well (max(-inf, v) = v), and NaN still wins
+    const float mx = block_max_nanprop_256(m, smf);
+    float zm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+      const int i = tid + j * kFrameNT;
+      zz[j] = 0.f;
+      if (i < F) {
+        zz[j] = rnT<DT>(rnT<DT>(sv[j] - mx) / temp);
+        const float z = zz[j];
+        zm = (zm != zm) ? zm : ((z != z) ? z : fmaxf(zm, z));
+      }
+    }
+    const float zmax = block_max_nanprop_256(zm, smf);
+    double es = 0.0;
+    float ee[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+      const int i = tid + j * kFrameNT;
+      ee[j] = 0.f;
+      if (i < F) { ee[j] = float(exp(double(zz[j] - zmax))); es += double(ee[j]); }
+    }
+    es = wave_sum(es);
+    __syncthreads();
+    if (lane == 0) smd[wave] = es;
+    __syncthreads();
+    const double esum = smd[0] + smd[1] + smd[2] + smd[3];
+    double ps = 0.0;
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+      const int i = tid + j * kFrameNT;
+      pp[j] = 0.f;
+      if (i < F) { pp[j] = rnT<DT>(float(double(ee[j]) / esum)); ps += double(pp[j]); }
+    }
+    ps = wave_sum(ps);
+    __syncthreads();
+    if (lane == 0) smd[wave] = ps;
+    __syncthreads();
+    const float pmean = mean_T<DT>(smd[0] + smd[1] + smd[2] + smd[3], F);
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) {
+      const int i = tid + j * kFrameNT;
+      if (i < F) {
+        float t = rnT<DT>(1.0f + pp[j]);
+        t = rnT<DT>(t - pmean);
+        t = rnT<DT>(base * t);
+        if (t > 1.0f) t = 1.0f;
+        const int kk = budget_k<DT>(t, N);
+        if (i >= f0 && i < f) before += kk + extra;
+        if (i >= f0 && i < f0 + FS) all += kk + extra;
+        if (i == f) { kmine = kk; scmine = t; }
+      }
+    }
+  } else {
+    for (int i = f0 + tid; i < f0 + FS; i += kFrameNT) {
+      const int kk = budget_k<DT>(scales_f32[i], N);
+      if (i < f) before += kk + extra;
+      all += kk + extra;
+      if (i == f) { kmine = kk; scmine = scales_f32[i]; }
+    }
+  }
+  // block sums of (before, all) and broadcast of this frame's k (exactly one thread holds it)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
+  __syncthreads();
+  if (lane == 0) { smi[wave] = before; smi[4 + wave] = all; }
+  __syncthreads();
+  const int64_t o0 = smi[0] + smi[1] + smi[2] + smi[3];
+  const int64_t Ktot = smi[4] + smi[5] + smi[6] + smi[7];
+  __syncthreads();
+  // the thread that holds frame f publishes k and the scale
+  {
+    const bool holder = (vpart || frame_scores) ? (tid == f % kFrameNT) : (tid == (f - f0) % kFrameNT);
+    if (holder) { smi[0] = kmine; smf[0] = scmine; }
+  }
+  __syncthreads();
+  const int k = int(smi[0]);
+  if (tid == 0) {
+    ks[fl] = k;
+    offs[fl] = o0;
+    if (scales_out) scales_out[fl] = smf[0];
+    if (fl == FS - 1) {
+      offs[FS] = Ktot;
+      K_out[0] = Ktot;
+      K_out[1] = Ktot > cap ? 1 : 0;
+    }
+  }
+  if constexpr (DT == VC2_F32) select_frame_body<DT, uint64_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
+  else select_frame_body<DT, uint32_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
 }
 
 // standalone mappers on already-selected local indices
@@ -1568,7 +1714,7 @@ struct Plan {
   int S, rows_per_split;        // sweep-2 splits per frame
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
-  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
+  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
       o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_cfixlist, o_vfixlist, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
   int cfix_cap, vstride;
 };
@@ -1612,6 +1758,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_order = take(size_t(D) * 4);
   p->o_opos = take(size_t(D) * 4);
   p->o_spos = take(size_t(D) * 4);
+  p->o_perm = take(size_t(D) * 4);
   p->o_den = take(size_t(p->R) * 4);
   p->o_part_col = take(size_t(F) * p->S * D * 8);
   p->o_fc = take(size_t(F) * D * 4);
@@ -1723,22 +1870,28 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what)
   return VC2_OK;
 }
 
-int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* order, int* opos,
-                       int* spos, hipStream_t st, int kid = KID_CHAN_SELECT) {
+int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* perm,
+                       hipStream_t st) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
-  const size_t smem = (sel_shared_bytes(int(D)) + 15) / 16 * 16 + (order ? sort_scratch_bytes(int(D)) : 0);
+  const size_t smem = chan_select_lds(int(D));
   { int rca = allow_big_lds(&k_chan_select, smem, "k_chan_select"); if (rca) return rca; }
-  { ProfScope ps_(kid, st);
-  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, order,
-                     opos, spos); }
+  { ProfScope ps_(KID_CHAN_SELECT, st);
+  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, perm); }
   return check_launch("chan_select");
+}
+// torch.topk's ORDER of the kept channels as its own kernel (the scoring entry points attach it to sweep 2 instead)
+int launch_chan_order(const OrderArgs& oa, hipStream_t st) {
+  const size_t smem = chan_order_lds(oa.D, oa.k, 8);
+  { int rca = allow_big_lds(&k_chan_order, smem, "k_chan_order"); if (rca) return rca; }
+  { ProfScope ps_(KID_CHAN_ORDER, st);
+  hipLaunchKernelGGL(k_chan_order, dim3(1), dim3(kSelNT), smem, st, oa); }
+  return check_launch("chan_order");
 }
 
 // 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
 // result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
 int g_strict = 1;
-int g_use_side_stream = 1;   // 0: run the channel-order replay on the caller's stream (clean per-kernel timing)
 
 // the scored channels: ascending list (nullptr = all D), the same channels in torch.topk's order and their
 // positions in `cols` (both nullptr = identity when cols is nullptr, else strict mode is unavailable)
@@ -1759,24 +1912,28 @@ inline ChanSet make_chanset(const Plan& p, const int* cols, const int* spos, int
 inline bool fast_acc(const Plan& p, const ChanSet& cs) { return cs.strict != 0 && p.dt != VC2_F32; }
 
 template <int DT, int VEC, int NPLB, int ACC>
-int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
   const int* cols = cs.cols; const int C = cs.C;
-  const size_t smem = std::max<size_t>(2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES),
-                                      size_t(kRowWaves) * NPLB * 64 * 8);          // row buffers, then the combine
-  int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC>, smem, "k_norm_colsum");
+  constexpr int RIDER = (ACC == 1 && VEC > 1) ? 1 : 0;       // the kernels that can carry the ORDER rider
+  if (rider.perm && !RIDER) return fail(VC2_ERR_UNSUPPORTED, "internal: ORDER rider on a sweep without one");
+  size_t smem = std::max<size_t>(2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES),
+                                 size_t(kRowWaves) * NPLB * 64 * 8);               // row buffers, then the combine
+  if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
+  int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>, smem, "k_norm_colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC>), dim3(unsigned(p.F * p.S)), dim3(kRowWaves * 64), smem, st, x,
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.F * p.S + (rider.perm ? 1 : 0))),
+                     dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.rows_per_split,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
-                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag));
+                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
-int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
+int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
   if constexpr (DT != VC2_F32) {
-    if (fast_acc(p, cs)) return launch_norm_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, st);
+    if (fast_acc(p, cs)) return launch_norm_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, rider, st);
   }
-  return launch_norm_acc<DT, VEC, NPLB, 0>(p, x, cs, ws, st);
+  return launch_norm_acc<DT, VEC, NPLB, 0>(p, x, cs, ws, rider, st);
 }
 template <int DT, int VEC, int NPLB>
 int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, hipStream_t st) {
@@ -1823,23 +1980,25 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, con
 
 // sweep 2 + centres.  single_rank: also the video centre; else only the rank's csum (for the all-gather).
 // The two strict-mode queue counters (ticket[2], ticket[3]) must be zero on entry (zero_counters).
-// wait_before_fix: event after which cs.spos is valid (the channel sort may run on a side stream).
+// rider: an ORDER job (chan_order_body) attached to sweep 2 -- it produces cs.spos for the fix-up kernels.
 int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, bool single_rank, hipStream_t st,
-                  hipEvent_t wait_before_fix = nullptr) {
+                  const OrderArgs& rider = OrderArgs{}) {
   const int C = cs.C;
   double* part = wsp<double>(ws, p.o_part_col);
   double* cpart = wsp<double>(ws, p.o_csum_part);
   const int FG = int(cdiv(p.F, kCentreFL));
   const int npl = int(cdiv(C, 64));
+  OrderArgs ride = rider;
+  if (ride.perm && (p.VEC == 1 || !fast_acc(p, cs) || g_prof)) {   // no rider on this sweep variant (or per-kernel
+    int rc = launch_chan_order(ride, st);                          // timing wanted): the ORDER job as its own kernel
+    if (rc) return rc;
+    ride = OrderArgs{};
+  }
   { ProfScope ps_(KID_NORM_COLSUM, st);
   int rc = VC2_OK;
-  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, st));
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, ride, st));
   if (rc) return rc; }
   if (cs.strict) {
-    if (wait_before_fix) {
-      hipError_t e = hipStreamWaitEvent(st, wait_before_fix, 0);
-      if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipStreamWaitEvent: %s", hipGetErrorString(e));
-    }
     ProfScope ps_(KID_OTHER, st);
     int rc = VC2_OK;
     VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_fix_t, p, x, cs, ws, st));
@@ -1913,15 +2072,22 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
   return check_launch("compute_scales");
 }
 
-int launch_select(int dt, const float* total, const float* scales_f32, int64_t F, int64_t N, int map_mode,
+// F budget frames, of which this launch selects [f0, f0 + F_sel) (total / ks / offs are indexed by the local frame).
+// Budgets: vpart (sweep-3 partials, S2 per frame) or frame_scores -> compute_scales in the kernel; else scales_f32[F].
+struct BudgetSrc { const float* scales_f32; const double* vpart; int S2; const float* frame_scores; double base; double temp;
+                   float* scales_out; };
+int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_sel, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
-                  hipStream_t st, const float* frame_scores = nullptr, double base = 0.0, double temp = 0.01,
-                  float* scales_out = nullptr) {
-  const size_t smem = sel_shared_bytes(int(N));
+                  const BudgetSrc& b, hipStream_t st) {
+  const size_t smem = sel2_bytes(int(N), dt == VC2_F32 ? 8 : 4);
   ProfScope ps_(KID_SELECT, st);
-  VC2_DISPATCH_DT(dt, hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F)), dim3(kFrameNT), smem, st, total,
-                                         scales_f32, int(F), int(N), map_mode, int(grid_h), N, cap, ks, offs,
-                                         idx_out, K_out, frame_scores, float(base), float(temp), scales_out));
+  VC2_DISPATCH_DT(dt, {
+    int rca = allow_big_lds(&k_select<DT>, smem, "k_select");
+    if (rca) return rca;
+    hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F_sel)), dim3(kFrameNT), smem, st, total, b.scales_f32, int(F),
+                       int(f0), int(N), map_mode, int(grid_h), N, cap, ks, offs, idx_out, K_out, b.vpart, b.S2,
+                       b.frame_scores, float(b.base), float(b.temp), b.scales_out);
+  });
   return check_launch("select");
 }
 
@@ -1933,39 +2099,6 @@ int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, con
   hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, st, static_cast<const unsigned char*>(src),
                      src_rows, D * ES, idx, K_dev, cap, static_cast<unsigned char*>(dst));
   return check_launch("gather_rows");
-}
-
-// ---- side stream for the strict-mode channel sort (fork/join with events around the caller's stream) ----
-// One side stream (+ fork / join events) per CALLER stream, so that passes enqueued on different streams -- several
-// clips in flight, one stream each -- replay their channel orders concurrently instead of queueing on one stream.
-// Up to kSideSlots caller streams per device are remembered (the least recently created slot is recycled).
-struct SideStream { hipStream_t owner = nullptr; bool used = false; hipStream_t s = nullptr;
-                    hipEvent_t fork = nullptr, join = nullptr; bool pending = false; };
-constexpr int kSideSlots = 8;
-SideStream g_side[64][kSideSlots];
-int g_side_next[64];
-SideStream* find_side(int dev, hipStream_t owner) {
-  for (int i = 0; i < kSideSlots; ++i)
-    if (g_side[dev][i].used && g_side[dev][i].owner == owner) return &g_side[dev][i];
-  return nullptr;
-}
-int get_side(hipStream_t owner, SideStream** out) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(VC2_ERR_LAUNCH, "hipGetDevice failed");
-  SideStream* ss = find_side(dev, owner);
-  if (!ss) {
-    ss = &g_side[dev][g_side_next[dev]];
-    g_side_next[dev] = (g_side_next[dev] + 1) % kSideSlots;
-    if (!ss->s) {
-      if (hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ss->join, hipEventDisableTiming) != hipSuccess)
-        return fail(VC2_ERR_LAUNCH, "could not create the side stream");
-    }
-    ss->owner = owner; ss->used = true; ss->pending = false;
-  }
-  *out = ss;
-  return VC2_OK;
 }
 
 }  // namespace
@@ -1984,7 +2117,6 @@ int vc2_set_mode(int mode) {
   return VC2_OK;
 }
 int vc2_get_mode(void) { return g_strict; }
-int vc2_set_side_stream(int on) { g_use_side_stream = on ? 1 : 0; return VC2_OK; }
 
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
   if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
@@ -2036,43 +2168,16 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
   return launch_chan_stats(p, x, ws, nullptr, var_T, vf, static_cast<hipStream_t>(stream));
 }
 
-int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, int32_t* order,
-                    int32_t* opos, int32_t* spos, void* stream) {
-  if (!var_f32 || (!mask && !cols && !order)) return fail(VC2_ERR_ARG, "null pointer");
-  if ((opos || spos) && !(order && opos)) return fail(VC2_ERR_ARG, "opos/spos need order and opos");
-  if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
-  return launch_chan_select(var_f32, D, k, mask, cols, order, opos, spos, static_cast<hipStream_t>(stream));
-}
-
-int vc2_chan_select_overlapped(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols,
-                               int32_t* order, int32_t* opos, int32_t* spos, void* stream) {
-  if (!var_f32 || !cols) return fail(VC2_ERR_ARG, "null pointer");
+int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int32_t* cols, int32_t* perm,
+                    int32_t* order, int32_t* opos, int32_t* spos, void* stream) {
+  if (!var_f32 || (!mask && !cols && !perm && !order)) return fail(VC2_ERR_ARG, "null pointer");
+  if ((order || opos || spos) && !perm) return fail(VC2_ERR_ARG, "order / opos / spos need the perm scratch array");
+  if ((opos || spos) && !(cols && opos)) return fail(VC2_ERR_ARG, "opos / spos need cols and opos");
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool want_order = g_strict != 0 && order && opos && spos;
-  int rc;
-  if (want_order && g_use_side_stream && !g_prof) {
-    SideStream* ss = nullptr;
-    if ((rc = get_side(st, &ss))) return rc;
-    if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
-      return fail(VC2_ERR_LAUNCH, "side-stream fork failed");
-    if ((rc = launch_chan_select(var_f32, D, k, nullptr, nullptr, order, opos, spos, ss->s, KID_CHAN_ORDER))) return rc;
-    if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(VC2_ERR_LAUNCH, "side-stream join failed");
-    ss->pending = true;                                       // consumed by the next vc2_scores_phase1 / vc2_scores
-  } else if (want_order) {
-    if ((rc = launch_chan_select(var_f32, D, k, nullptr, nullptr, order, opos, spos, st, KID_CHAN_ORDER))) return rc;
-  }
-  return launch_chan_select(var_f32, D, k, mask, cols, nullptr, nullptr, nullptr, st);
-}
-
-// the join event of a pending vc2_chan_select_overlapped issued on `st` (or nullptr); clears the flag
-static hipEvent_t take_pending_join(hipStream_t st) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream* ss = find_side(dev, st);
-  if (!ss || !ss->pending) return nullptr;
-  ss->pending = false;
-  return ss->join;
+  int rc = launch_chan_select(var_f32, D, k, mask, cols, perm, st);
+  if (rc || !(order || opos || spos)) return rc;
+  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k)}, st);
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -2100,8 +2205,10 @@ static int check_cols(const int32_t* cols, int64_t C, int64_t D) {
 }
 
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      const int32_t* spos, void* ws, size_t ws_bytes, double* csum, void* stream) {
+                      int32_t* spos, const int32_t* perm, const float* var_f32, void* ws, size_t ws_bytes,
+                      double* csum, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
+  if (perm && !(var_f32 && cols && spos)) return fail(VC2_ERR_ARG, "the ORDER rider needs perm, var_f32, cols and spos");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
@@ -2109,7 +2216,11 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  rc = launch_phase1(p, x, make_chanset(p, cols, spos, C), ws, /*single_rank=*/false, st, take_pending_join(st));
+  const ChanSet cs = make_chanset(p, cols, spos, C);
+  OrderArgs rider{};
+  if (perm && cs.strict)      // torch.topk's ORDER of the channels (-> spos), replayed by a rider workgroup of sweep 2
+    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C)};
+  rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider);
   if (rc) return rc;
   if (csum) {
     hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
@@ -2149,7 +2260,7 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st, take_pending_join(st)))) return rc;
+  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st);
@@ -2187,7 +2298,8 @@ int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N,
     hipLaunchKernelGGL((k_widen<DT>), dim3(unsigned(cdiv(F * N, 256))), dim3(256), 0, st, scores_T, F * N, tot);
     hipLaunchKernelGGL((k_widen<DT>), dim3(unsigned(cdiv(F, 256))), dim3(256), 0, st, scales_T, F, sc);
   });
-  return launch_select(dtype, tot, sc, F, N, map_mode, grid_h, ks, offs, idx_out, cap, K_out, st);
+  return launch_select(dtype, tot, F, 0, F, N, map_mode, grid_h, ks, offs, idx_out, cap, K_out,
+                       BudgetSrc{sc, nullptr, 0, nullptr, 0.0, 0.01, nullptr}, st);
 }
 
 int vc2_map_indices(const int64_t* local_idx, const int64_t* ks, const int64_t* offs, int64_t F, int map_mode,
@@ -2225,45 +2337,32 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
   const bool strict = g_strict && p.ES == 2;
   int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;
-  hipEvent_t join = nullptr;
-  if (strict && !g_use_side_stream) {
-    if ((rc = launch_chan_select(var_f32, D, kc, nullptr, nullptr, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos,
-                                 st, KID_CHAN_ORDER)))
-      return rc;
-  } else if (strict) {
-    // torch.topk's ORDER of the selected channels (needed only by the strict-mode fix-ups) is replayed on a side
-    // stream, concurrently with the channel-set selection and sweep 2 on the caller's stream.
-    SideStream* ss = nullptr;
-    if ((rc = get_side(st, &ss))) return rc;
-    if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess)
-      return fail(VC2_ERR_LAUNCH, "side-stream fork failed");
-    if ((rc = launch_chan_select(var_f32, D, kc, nullptr, nullptr, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos,
-                                 ss->s, KID_CHAN_ORDER)))
-      return rc;
-    if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(VC2_ERR_LAUNCH, "side-stream join failed");
-    join = ss->join;
-  }
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, nullptr, nullptr, nullptr, st))) return rc;
+  int* perm = strict ? wsp<int>(ws, p.o_perm) : nullptr;
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st))) return rc;
   const ChanSet cs = make_chanset(p, cols, spos, kc);
-  if ((rc = launch_phase1(p, x, cs, ws, true, st, join))) return rc;
+  // torch.topk's ORDER of the selected channels (needed only by the "torch order" fix-ups, which run after sweep 2)
+  // is replayed by a rider workgroup of sweep 2 itself
+  OrderArgs rider{};
+  if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc)};
+  if ((rc = launch_phase1(p, x, cs, ws, true, st, rider))) return rc;
   float* total = wsp<float>(ws, p.o_total);
-  float* s = wsp<float>(ws, p.o_s);
   float* scales = wsp<float>(ws, p.o_scales_f32);
-  if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st))) return rc;
-  // budgets: every k_select wave derives them from the F frame scores itself (F <= 1024; saves the k_scales kernel
-  // boundary).  Fusing them into the epilogue's last workgroup through an agent-scope ticket measured SLOWER than
-  // a separate kernel -- the release fences write back L2.
   const double bs = base_scale < 0 ? 0.0 : base_scale;
-  if (F <= kFusedScalesMaxF) {
-    if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
-                            cap, K_out, st, s, bs, 0.01, scales)))
-      return rc;
+  const bool fused_budget = F <= kFusedScalesMaxF;
+  // budgets: every k_select workgroup derives them itself from sweep 3's workgroup partials (F <= 1024; saves two
+  // kernel boundaries).  Fusing them into sweep 3's last workgroup through an agent-scope ticket measured SLOWER than
+  // a separate kernel -- the release fences write back L2.
+  float* s = fused_budget ? nullptr : wsp<float>(ws, p.o_s);
+  if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st))) return rc;
+  if (fused_budget) {
+    rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
+                       BudgetSrc{nullptr, wsp<double>(ws, p.o_vpart), p.S2, nullptr, bs, 0.01, scales}, st);
   } else {
     if ((rc = launch_scales(dtype, s, F, bs, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
-    if ((rc = launch_select(dtype, total, scales, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out,
-                            cap, K_out, st)))
-      return rc;
+    rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
+                       BudgetSrc{scales, nullptr, 0, nullptr, bs, 0.01, nullptr}, st);
   }
+  if (rc) return rc;
   if (out_rows && gather_src)
     rc = launch_gather_rows(gather_src, gather_rows, D, p.ES, idx_out, K_out, cap, out_rows, st);
   return rc;
@@ -2284,13 +2383,18 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* scales = wsp<float>(ws, p.o_scales_f32);
-  // budgets over ALL frames of the video (softmax + mean are global, vidcom2.py:66-67) ...
-  if ((rc = launch_scales(dtype, s_all_f32, F_total, base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st)))
-    return rc;
-  // ... selection only for this rank's frames
-  if ((rc = launch_select(dtype, total_f32, scales + f0, F_local, N, VC2_MAP_LINEAR, 0, ks,
-                          wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out, st)))
-    return rc;
+  // budgets over ALL frames of the video (softmax + mean are global, vidcom2.py:66-67), selection only for this
+  // rank's frames [f0, f0 + F_local)
+  if (F_total <= kFusedScalesMaxF) {
+    rc = launch_select(dtype, total_f32, F_total, f0, F_local, N, VC2_MAP_LINEAR, 0, ks, wsp<int64_t>(ws, p.o_offs),
+                       idx_out, cap, K_out, BudgetSrc{nullptr, nullptr, 0, s_all_f32, base_scale, 0.01, nullptr}, st);
+  } else {
+    if ((rc = launch_scales(dtype, s_all_f32, F_total, base_scale, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st)))
+      return rc;
+    rc = launch_select(dtype, total_f32, F_total, f0, F_local, N, VC2_MAP_LINEAR, 0, ks, wsp<int64_t>(ws, p.o_offs),
+                       idx_out, cap, K_out, BudgetSrc{scales, nullptr, 0, nullptr, base_scale, 0.01, nullptr}, st);
+  }
+  if (rc) return rc;
   if (out_rows && gather_src)
     rc = launch_gather_rows(gather_src, F_local * N, D, p.ES, idx_out, K_out, cap, out_rows, st);
   return rc;
@@ -2345,6 +2449,16 @@ int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws
   if (hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(out8, static_cast<const char*>(ws) + p.o_ticket, 32, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(VC2_ERR_LAUNCH, "counter read-back failed");
+  return VC2_OK;
+}
+
+int vc2_selftest_counters(int32_t* out8_host, int reset) {
+  // diagnostic (SYNCHRONISES): how often a loop bound of the selection engine expired (must be all zero)
+  if (!out8_host) return fail(VC2_ERR_ARG, "null pointer");
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(vc2::g_sel2_guard_hits), 32) != hipSuccess)
+    return fail(VC2_ERR_LAUNCH, "counter read-back failed");
+  if (reset) { int z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(vc2::g_sel2_guard_hits), z, 32); }
   return VC2_OK;
 }
 

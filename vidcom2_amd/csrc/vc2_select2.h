@@ -1,0 +1,563 @@
+// vc2_select2.h -- low-latency replay of the selection torch.topk performs on CPU (second generation).
+//
+// The reference decides which tokens / channels are kept with torch.topk(largest=False) (vidcom2.py:42 and
+// :76), i.e. libstdc++ std::nth_element / std::partial_sort / std::sort on (value, index) pairs
+// (ATen/native/TopKImpl.h).  In bf16 / fp16 the kept SET is decided by how those
+// algorithms permute ties, so they are replayed step by step.  What is parallel in them is one Hoare partition
+// (__unguarded_partition): its i-th swap pairs the i-th element from the left that is !(a < pivot) with the i-th
+// from the right that is !(pivot < a) while the left position is below the right one -- two prefix counts, a
+// rank -> position scatter and independent swaps reproduce the serial loop's permutation exactly.
+//
+// A partition ROUND here is built for latency (the rounds are a serial chain of 13 + ~12 at D = 3584):
+//   * an element is ONE word: (order-preserving key | index).  Half-precision values widened to fp32 have 13 zero
+//     low bits, so key and index share 32 bits (W = uint32_t); arbitrary fp32 values take 64 (W = uint64_t);
+//   * a thread owns CONSECUTIVE positions of the current range (re-blocked every round: 4, 8, .. 32 elements
+//     per thread), fetched with 16-byte LDS reads; its ranks are a running count on top of one DPP wave scan;
+//   * long ranges are partitioned by 4 cooperating waves (3 workgroup barriers per round), ranges of at most
+//     2048 elements by ONE wave with no barrier at all (a wave's LDS accesses execute in order);
+//   * the cut needs no search: it is the minimum of "partner position" over the swapped left elements and
+//     "own position" over the unswapped ones -- a DPP wave minimum (+ one LDS atomic-min across waves).
+// The rarely taken pieces (heap-select fallback at the depth limit, partial_sort for k*64 <= n, the final
+// insertion sort of <= 3 elements) run serially on one lane, replaying libstdc++ statement by statement.
+#pragma once
+
+#include "vc2_device.h"
+
+namespace vc2 {
+
+// ---- element words -------------------------------------------------------------------------------
+template <typename W> struct WordTr;
+template <> struct WordTr<uint32_t> {
+  static constexpr int kIdxBits = 13;                        // n <= 8192
+  static __device__ __forceinline__ uint32_t key(uint32_t w) { return w >> kIdxBits; }
+  static __device__ __forceinline__ int idx(uint32_t w) { return int(w & ((1u << kIdxBits) - 1u)); }
+  // key32 = topk_key(value); the low 13 bits carry no order information for widened 16-bit values (all equal)
+  static __device__ __forceinline__ uint32_t pack(uint32_t key32, int i) {
+    return (key32 & ~((1u << kIdxBits) - 1u)) | uint32_t(i);
+  }
+};
+template <> struct WordTr<uint64_t> {
+  static __device__ __forceinline__ uint32_t key(uint64_t w) { return uint32_t(w >> 32); }
+  static __device__ __forceinline__ int idx(uint64_t w) { return int(uint32_t(w)); }
+  static __device__ __forceinline__ uint64_t pack(uint32_t key32, int i) { return (uint64_t(key32) << 32) | uint32_t(i); }
+};
+// can the values (fp32-widened) be packed into 32-bit words?  (a property of the whole array)
+__device__ __forceinline__ bool key_fits_u32(float f) {
+  return (f != f) || (__float_as_uint(f) & 0x1FFFu) == 0u;
+}
+
+// self-check: every loop of the engine is bounded; a bound that actually expires is counted here (read back by
+// vc2_selftest_counters; the test-suite asserts zeros)
+__device__ int g_sel2_guard_hits[8];
+__device__ __forceinline__ void guard_hit(int which) { atomicAdd(&g_sel2_guard_hits[which], 1); }
+
+#ifdef VC2_SEL2_DEBUG
+__device__ unsigned long long g_sel2_dbg[128];
+#endif
+
+constexpr int kXchCut = 16, kXchDummy = 20;
+constexpr int kSel2Pad = 64;           // positions a round may read past the end of the range (never used)
+
+template <typename W> struct Sel2 {
+  W* w;            // [n + kSel2Pad]
+  uint16_t* la;    // [n + kSel2Pad] left-stop positions by rank
+  uint16_t* lb;    // [n + kSel2Pad] right-stop positions by rank (numbered from the left)
+  uint32_t* xch;   // [24] cross-wave exchange: [0,16) per-wave totals, [16] cut, [20..21] dummy cells (predicated stores)
+  int dumw;        // index of a dummy word in w[] (predicated swaps of no-op elements land there)
+};
+__host__ __device__ inline size_t sel2_bytes(int n, int wbytes) {
+  return (size_t(n + kSel2Pad) * size_t(wbytes) + 15) / 16 * 16 + size_t(n + kSel2Pad) * 2 * 2 + 128 + 32;
+}
+template <typename W> __device__ __forceinline__ Sel2<W> sel2_carve(unsigned char* smem, int n) {
+  Sel2<W> S;
+  const size_t wb = (size_t(n + kSel2Pad) * sizeof(W) + 15) / 16 * 16;
+  S.w = reinterpret_cast<W*>(smem);
+  unsigned char* p = smem + wb;
+  S.xch = reinterpret_cast<uint32_t*>(p);
+  S.la = reinterpret_cast<uint16_t*>(p + 128);
+  S.lb = S.la + (n + kSel2Pad);
+  S.dumw = n + kSel2Pad - 1;
+  return S;
+}
+
+// ---- wave primitives (DPP: VALU latency, no LDS crossbar round trip) -------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, false));   // row_shr:1
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, false));   // row_shr:2
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, false));   // row_shr:4
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, false));   // row_shr:8 -> scan inside each row of 16
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 into rows 2, 3
+  return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+  const uint32_t t = uint32_t(__builtin_amdgcn_update_dpp(-1, int(v), CTRL, ROW_MASK, 0xF, false));
+  return t < v ? t : v;
+}
+__device__ __forceinline__ uint32_t wave_min_bcast_u32(uint32_t v) {
+  v = dpp_min_u32<0xB1, 0xF>(v);
+  v = dpp_min_u32<0x4E, 0xF>(v);
+  v = dpp_min_u32<0x141, 0xF>(v);
+  v = dpp_min_u32<0x140, 0xF>(v);
+  v = dpp_min_u32<0x142, 0xA>(v);
+  v = dpp_min_u32<0x143, 0xC>(v);
+  return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
+__device__ __forceinline__ void wave_lds_order() {     // single wave: the DS queue is in order; pin the compiler
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int NW> __device__ __forceinline__ void sel2_sync() {
+  if constexpr (NW > 1) __syncthreads(); else wave_lds_order();
+}
+
+// ---- serial libstdc++ pieces (one lane) ------------------------------------------------------------
+template <typename W> __device__ __forceinline__ bool w_less(W a, W b) { return WordTr<W>::key(a) < WordTr<W>::key(b); }
+
+// bits/stl_heap.h __adjust_heap (+ inlined __push_heap)
+template <typename W>
+__device__ __forceinline__ void s2_adjust_heap(W* w, int first, int hole, int len, W v) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (w_less(w[first + child], w[first + child - 1])) child--;
+    w[first + hole] = w[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    w[first + hole] = w[first + child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && w_less(w[first + parent], v)) {
+    w[first + hole] = w[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  w[first + hole] = v;
+}
+// bits/stl_algo.h __heap_select(first, middle, last)
+template <typename W>
+__device__ __forceinline__ void s2_heap_select(W* w, int first, int middle, int last) {
+  const int len = middle - first;
+  if (len >= 2) {   // __make_heap
+    int parent = (len - 2) / 2;
+    while (true) {
+      const W v = w[first + parent];
+      s2_adjust_heap(w, first, parent, len, v);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  for (int i = middle; i < last; ++i) {
+    if (w_less(w[i], w[first])) {   // __pop_heap(first, middle, i)
+      const W v = w[i];
+      w[i] = w[first];
+      s2_adjust_heap(w, first, 0, len, v);
+    }
+  }
+}
+// bits/stl_heap.h __sort_heap(first, last) on a heap
+template <typename W>
+__device__ __forceinline__ void s2_sort_heap(W* w, int first, int last) {
+  while (last - first > 1) {
+    --last;
+    const W v = w[last];
+    w[last] = w[first];
+    s2_adjust_heap(w, first, 0, last - first, v);
+  }
+}
+// bits/stl_algo.h __insertion_sort
+template <typename W>
+__device__ __forceinline__ void s2_insertion_sort(W* w, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    const W v = w[i];
+    if (w_less(v, w[first])) {
+      for (int j = i; j > first; --j) w[j] = w[j - 1];
+      w[first] = v;
+    } else {   // __unguarded_linear_insert
+      int l = i, nx = i - 1;
+      while (w_less(v, w[nx])) { w[l] = w[nx]; l = nx; --nx; }
+      w[l] = v;
+    }
+  }
+}
+
+// ---- one __unguarded_partition_pivot(lo, hi) by NW cooperating waves ---------------------------------
+// (hi - lo > 3.)  tid = 0 .. 64*NW-1 inside the group; every thread of the group calls this with identical
+// arguments; for NW > 1 the group must be the whole workgroup (__syncthreads).  la / lb: rank scratch with room
+// for hi - lo entries that no concurrent partition uses.  The thread's 4*EQ consecutive elements live in registers
+// for the whole round (4*EQ*64*NW >= hi - lo + 3).  Returns the cut (the same value in every thread).
+// BRANCH-FREE: every LDS access is issued unconditionally, "not mine" cases redirected to a dummy cell or a clamped
+// index -- an exec-masked branch per element per step costs ~50 cycles, and a lone wave issues one instruction
+// every ~4 cycles, so the instruction count IS the round time (measured: 350 instructions = 1500 cycles at EQ = 1).
+template <typename W, int NW, int EQ>
+__device__ __forceinline__ int sel2_partition_t(const Sel2<W>& S, int lo, int hi, uint16_t* la, uint16_t* lb, int tid) {
+  using T = WordTr<W>;
+  constexpr int E = EQ == 0 ? 1 : 4 * EQ, NT = 64 * NW;        // EQ = 0: ONE element per thread (ranges <= 64*NW)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int first = lo + 1;
+  const int base = EQ == 0 ? first : (first & ~3);           // 16-byte aligned blocking of [base, hi)
+  const int er = EQ == 0 ? 1 : ((((hi - base) + NT - 1) / NT + 3) & ~3);   // elements per thread this round (<= E)
+  const int p0 = base + tid * er;
+  W el[E];
+  if constexpr (EQ == 0) {
+    el[0] = S.w[p0 < hi ? p0 : lo];
+  } else {
+    constexpr int WPV = 16 / int(sizeof(W));                 // words per 16-byte read
+    const uint4* src = reinterpret_cast<const uint4*>(S.w + (p0 < hi ? p0 : (hi & ~3)));   // (idle threads: any valid quad)
+    union { uint4 v; W e[WPV]; } u;
+#pragma unroll
+    for (int q = 0; q < E / WPV; ++q) {                       // (reads past the range stay inside the padded array)
+      u.v = src[q];
+#pragma unroll
+      for (int t = 0; t < WPV; ++t) el[q * WPV + t] = u.e[t];
+    }
+  }
+  const int pa = lo + 1, pb = lo + (hi - lo) / 2, pc = hi - 1;
+  const W wlo = S.w[lo], wa = S.w[pa], wb = S.w[pb], wc = S.w[pc];
+  int msrc;
+  W wp;
+  {
+    const uint32_t ka = T::key(wa), kb = T::key(wb), kc = T::key(wc);
+    const bool ab = ka < kb, bc = kb < kc, ac = ka < kc;
+    const int sel = ab ? (bc ? 1 : (ac ? 2 : 0)) : (ac ? 0 : (bc ? 2 : 1));
+    msrc = sel == 0 ? pa : (sel == 1 ? pb : pc);
+    wp = sel == 0 ? wa : (sel == 1 ? wb : wc);
+  }
+  const uint32_t pk = T::key(wp);
+  uint32_t mA = 0u, mB = 0u, cA = 0u, cB = 0u;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int p = p0 + j;
+    el[j] = (p == msrc) ? wlo : el[j];                         // iter_swap(lo, msrc), register copy
+    const uint32_t k = T::key(el[j]);
+    const bool in = j < er && p >= first && p < hi;
+    const uint32_t a = (in && k >= pk) ? 1u : 0u, b = (in && k <= pk) ? 1u : 0u;
+    mA |= a << j; mB |= b << j;
+    cA += a; cB += b;
+  }
+  const uint32_t packed = cA | (cB << 16);
+  const uint32_t incl = wave_incl_scan_u32(packed);
+  const uint32_t wtot = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+  uint32_t bas = incl - packed, tot = wtot;
+  if constexpr (NW > 1) {
+    if (lane == 63) S.xch[wave] = incl;
+    __syncthreads();                                         // also: every trip-1 read is done before the swaps
+    uint32_t pre = 0u, all = 0u;
+#pragma unroll
+    for (int v = 0; v < NW; ++v) { const uint32_t t = S.xch[v]; pre += v < wave ? t : 0u; all += t; }
+    bas += pre; tot = all;
+  }
+  if (tid == 0) {                                            // iter_swap(lo, msrc), LDS copy
+    S.w[lo] = wp;
+    S.w[msrc] = wlo;
+    if constexpr (NW > 1) S.xch[kXchCut] = 0xFFFFFFFFu;
+  }
+  const int totA = int(tot & 0xFFFFu), totB = int(tot >> 16);
+  uint16_t* const dum16 = reinterpret_cast<uint16_t*>(S.xch + kXchDummy);
+  {
+    int rA = int(bas & 0xFFFFu), rB = int(bas >> 16);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const bool A = (mA >> j) & 1u, B = (mB >> j) & 1u;
+      uint16_t* da = A ? la + rA : dum16;
+      uint16_t* db = B ? lb + rB : dum16 + 1;
+      *da = uint16_t(p0 + j);
+      *db = uint16_t(p0 + j);
+      rA += A ? 1 : 0; rB += B ? 1 : 0;
+    }
+  }
+  sel2_sync<NW>();
+  uint32_t cand = 0xFFFFFFFFu;
+  {
+    int rA = int(bas & 0xFFFFu), rB = int(bas >> 16);
+    constexpr int CH = E < 8 ? E : 8;                        // lookups in flight together (bounded: registers)
+#pragma unroll
+    for (int j0 = 0; j0 < E; j0 += CH) {
+      int qa[CH], qb[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j0 + c;
+        const bool A = (mA >> j) & 1u, B = (mB >> j) & 1u;
+        const int ia = totB - 1 - rA, ib = totB - 1 - rB;      // A: partner = lb_right[rA]; B: own right rank
+        const bool okA = A && rA < totB, okB = B && ib < totA;
+        const int ra = int(lb[okA ? ia : 0]), rb = int(la[okB ? ib : 0]);
+        qa[c] = okA ? ra : -1;
+        qb[c] = okB ? rb : 0x7FFFFFFF;
+        rA += A ? 1 : 0; rB += B ? 1 : 0;
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int j = j0 + c;
+        const int p = p0 + j;
+        const bool A = (mA >> j) & 1u;
+        const bool vA = qa[c] > p;                            // swapped as a left element (qa = -1 otherwise)
+        const bool vB = !vA && qb[c] < p;                     // swapped as a right element (qb = INT_MAX otherwise)
+        const uint32_t cc = A ? (vA ? uint32_t(qa[c]) : uint32_t(p)) : 0xFFFFFFFFu;
+        cand = cc < cand ? cc : cand;
+        S.w[vA ? qa[c] : (vB ? qb[c] : S.dumw)] = el[j];
+      }
+    }
+  }
+  uint32_t cutv = wave_min_bcast_u32(cand);
+  if constexpr (NW > 1) {
+    if (lane == 0) atomicMin(&S.xch[kXchCut], cutv);
+    __syncthreads();
+    cutv = S.xch[kXchCut];
+  } else {
+    wave_lds_order();
+  }
+  return cutv < uint32_t(hi) ? int(cutv) : hi;
+}
+
+// dispatch on the elements per thread the range needs; the instantiated sizes are EQLO .. EQHI (powers of two)
+template <typename W, int NW, int EQLO, int EQHI>
+__device__ __forceinline__ int sel2_partition(const Sel2<W>& S, int lo, int hi, uint16_t* la, uint16_t* lb, int tid) {
+  constexpr int NT = 64 * NW;
+  const int q = (((hi - ((lo + 1) & ~3)) + NT - 1) / NT + 3) >> 2;      // quads per thread
+  if constexpr (EQLO == 0) { if (hi - lo - 1 <= NT) return sel2_partition_t<W, NW, 0>(S, lo, hi, la, lb, tid); }
+  if constexpr (EQLO <= 1 && EQHI > 1) { if (q <= 1) return sel2_partition_t<W, NW, 1>(S, lo, hi, la, lb, tid); }
+  if constexpr (EQLO <= 2 && EQHI > 2) { if (q <= 2) return sel2_partition_t<W, NW, 2>(S, lo, hi, la, lb, tid); }
+  if constexpr (EQLO <= 4 && EQHI > 4) { if (q <= 4) return sel2_partition_t<W, NW, 4>(S, lo, hi, la, lb, tid); }
+  return sel2_partition_t<W, NW, EQHI>(S, lo, hi, la, lb, tid);
+}
+// the longest range a group of NW waves partitions with 4*EQ elements per thread
+__host__ __device__ constexpr int sel2_capacity(int nw, int eq) { return 64 * nw * 4 * eq - 4; }
+
+// std::nth_element(first, first + nth, first + n) on S.w[0, n).  All 64*NW threads of the workgroup call this
+// (tid = threadIdx.x).  Ranges longer than sel2_capacity(1, SOLO) are partitioned by all NW waves together
+// (n <= sel2_capacity(NW, COOP)), shorter ones by wave 0 alone.
+template <typename W, int NW, int SOLO, int COOP>
+__device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, int tid) {
+  if (n == 0 || nth >= n) return;
+  int lo = 0, hi = n;
+  int depth = 2 * (31 - __clz(n));                            // std::__lg(n) * 2
+  bool done = false;
+  if constexpr (NW > 1) {
+    for (int guard = 0; hi - lo > sel2_capacity(1, SOLO) && guard < 256; ++guard) {
+      if (depth == 0) {
+        if (tid == 0) { s2_heap_select(S.w, lo, nth + 1, hi); const W t = S.w[lo]; S.w[lo] = S.w[nth]; S.w[nth] = t; }
+        done = true;
+        break;
+      }
+      --depth;
+      const int cut = sel2_partition<W, NW, 1, COOP>(S, lo, hi, S.la, S.lb, tid);
+      if (cut <= nth) lo = cut; else hi = cut;
+      if (guard == 255 && tid == 0) guard_hit(0);
+    }
+  }
+  if (!done && tid < 64) {
+    for (int guard = 0; hi - lo > 3 && guard < 256; ++guard) {
+      if (depth == 0) {
+        if (tid == 0) { s2_heap_select(S.w, lo, nth + 1, hi); const W t = S.w[lo]; S.w[lo] = S.w[nth]; S.w[nth] = t; }
+        done = true;
+        break;
+      }
+      --depth;
+      const int cut = sel2_partition<W, 1, 0, SOLO>(S, lo, hi, S.la, S.lb, tid);
+      if (cut <= nth) lo = cut; else hi = cut;
+      if (guard == 255 && tid == 0) guard_hit(1);
+    }
+    if (!done && tid == 0) s2_insertion_sort(S.w, lo, hi);
+  }
+  sel2_sync<NW>();
+}
+
+// torch.topk(v, k, largest=False) SET: afterwards S.w[0, k) holds the kept elements (ATen/native/TopKImpl.h:
+// partial_sort when k*64 <= n, else nth_element(k-1))
+template <typename W, int NW, int SOLO, int COOP>
+__device__ __forceinline__ void topk_smallest2(const Sel2<W>& S, int n, int k, int tid) {
+  if (k <= 0 || k >= n) return;                               // k == n: everything kept, nothing moves
+  if (int64_t(k) * 64 <= int64_t(n)) {
+    if (tid == 0) s2_heap_select(S.w, 0, k, n);               // partial_sort = heap_select + sort_heap (only permutes [0,k))
+    sel2_sync<NW>();
+  } else {
+    introselect2<W, NW, SOLO, COOP>(S, n, k - 1, tid);
+  }
+}
+
+// ---- std::sort(first, first + n) replay (the `sorted=True` half of torch.topk, TopKImpl.h) ---------------
+// __introsort_loop: every segment longer than 16 is partitioned (the same __unguarded_partition_pivot) and both
+// halves recurse with depth_limit - 1; at depth 0 a segment is heap-sorted instead.  Segments of one recursion
+// level are independent: the workgroup walks the tree level by level -- segments longer than one wave's
+// capacity by all waves together, the others one wave per segment.  __final_insertion_sort then equals a STABLE sort inside every
+// leaf segment (elements never cross a cut and the insertion uses a strict compare), done by rank counting.
+// out_order[p] = original index at sorted position p.
+constexpr int kMaxSeg2 = 1024;
+struct SortScratch2 {
+  uint32_t* segA;   // [kMaxSeg2] phase 1: this level's long segments; phase 2: the work pool
+  uint32_t* segB;   // [kMaxSeg2] phase 1: the next level's
+  int* cnt;         // [8]: [0],[1] entries of list A / B; [2] pool head; [3] pool tail; [4] segments not yet finished
+  uint8_t* bnd;     // [n] 1 = a leaf starts here
+};
+__host__ __device__ inline size_t sort2_bytes(int n) { return size_t(kMaxSeg2) * 8 + 32 + size_t(n) + 16; }
+__device__ __forceinline__ SortScratch2 sort2_carve(unsigned char* p) {
+  SortScratch2 Q;
+  Q.segA = reinterpret_cast<uint32_t*>(p);
+  Q.segB = Q.segA + kMaxSeg2;
+  Q.cnt = reinterpret_cast<int*>(Q.segB + kMaxSeg2);
+  Q.bnd = reinterpret_cast<uint8_t*>(Q.cnt + 8);
+  return Q;
+}
+__device__ __forceinline__ uint32_t seg_pack(int first, int last, int depth) {      // never 0 (last >= 17)
+  return uint32_t(first) | (uint32_t(last) << 13) | (uint32_t(depth) << 26);
+}
+
+// Two phases.  (1) While segments longer than one wave's capacity exist (the top 1-3 levels), the workgroup walks
+// the tree level by level and partitions them with all waves together.  (2) Everything else goes into a work POOL
+// in LDS: a wave takes a segment, partitions it, keeps the left child for itself and publishes the right one; idle
+// waves poll.  No level barriers -- 178 partitions at k = 1792 spread evenly over the waves instead of the slowest
+// subtree of every level adding up.
+template <typename W, int NW, int SOLO, int COOP>
+__device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, int* __restrict__ out_order, int tid) {
+  using T = WordTr<W>;
+  constexpr int NT = 64 * NW;
+  const int lane = tid & 63, wave = tid >> 6;
+  volatile uint32_t* pool = Q.segA;
+  volatile int* cnt = Q.cnt;
+  for (int p = tid; p < n; p += NT) Q.bnd[p] = (p == 0) ? 1 : 0;
+  for (int p = tid; p < kMaxSeg2; p += NT) { Q.segA[p] = 0u; Q.segB[p] = 0u; }
+  if (tid < 8) Q.cnt[tid] = 0;
+  __syncthreads();
+  // ---- phase 1: long segments, level by level, all waves together (lists in segB, ping-pong halves)
+  uint32_t* cur = Q.segB;
+  uint32_t* nxt = Q.segB + kMaxSeg2 / 2;
+  int ci = 0;
+  if (tid == 0 && n > 16) {
+    const uint32_t root = seg_pack(0, n, 2 * (31 - __clz(n)));
+    if (NW > 1 && n > sel2_capacity(1, SOLO)) { cur[0] = root; Q.cnt[0] = 1; }
+    else { Q.segA[0] = root; Q.cnt[3] = 1; Q.cnt[4] = 1; }
+  }
+  __syncthreads();
+  if constexpr (NW > 1) {
+    for (int level = 0; level < 64; ++level) {
+      const int ns = Q.cnt[ci];
+      if (ns == 0) break;
+      for (int si = 0; si < ns; ++si) {
+        const uint32_t sg = cur[si];
+        const int first = int(sg & 0x1FFFu), last = int((sg >> 13) & 0x1FFFu), depth = int(sg >> 26);
+        int cut = first;
+        if (depth != 0) cut = sel2_partition<W, NW, 1, COOP>(S, first, last, S.la + first, S.lb + first, tid);
+        if (tid == 0) {
+          if (depth == 0) {                                     // depth limit: hand it to the pool (heapsort there)
+            const int j = Q.cnt[3]; Q.segA[j] = sg; Q.cnt[3] = j + 1; Q.cnt[4] += 1;
+          } else {
+            Q.bnd[cut] = 1;
+            const int lens[2] = {cut - first, last - cut};
+            const int fs[2] = {first, cut}, ls[2] = {cut, last};
+            for (int c = 0; c < 2; ++c) {
+              if (lens[c] <= 16) continue;
+              const uint32_t ch = seg_pack(fs[c], ls[c], depth - 1);
+              if (lens[c] > sel2_capacity(1, SOLO)) { const int j = Q.cnt[ci ^ 1]; nxt[j] = ch; Q.cnt[ci ^ 1] = j + 1; }
+              else { const int j = Q.cnt[3]; Q.segA[j] = ch; Q.cnt[3] = j + 1; Q.cnt[4] += 1; }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) Q.cnt[ci] = 0;
+      ci ^= 1;
+      uint32_t* t = cur; cur = nxt; nxt = t;
+      __syncthreads();
+    }
+  }
+  // ---- phase 2: the pool.  cnt[2] = head (next entry to take), cnt[3] = tail (next free slot), cnt[4] = segments
+  //      published or in work.  An entry is valid once its word is non-zero (written after the slot was claimed).
+  {
+    uint32_t mine = 0u;                                          // the segment this wave continues with (0: none)
+    for (int guard = 0; guard < 8 * kMaxSeg2; ++guard) {
+      if (mine == 0u) {
+        int got = -1, done = 0;
+        if (lane == 0) {
+          for (int spin = 0; spin < (1 << 20); ++spin) {
+            const int h = cnt[2];
+            if (h < cnt[3]) { if (atomicCAS(const_cast<int*>(&cnt[2]), h, h + 1) == h) { got = h; break; } }
+            else if (cnt[4] == 0) { done = 1; break; }
+            else __builtin_amdgcn_s_sleep(2);
+          }
+          if (got >= 0) { for (int spin = 0; spin < (1 << 20) && pool[got] == 0u; ++spin) __builtin_amdgcn_s_sleep(1); }
+          if (got < 0 && !done) { guard_hit(3); done = 1; }
+        }
+        got = __builtin_amdgcn_readfirstlane(got);
+        done = __builtin_amdgcn_readfirstlane(done);
+        if (done) break;
+        mine = __builtin_amdgcn_readfirstlane(int(pool[got]));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the publisher's swaps are visible
+      }
+      const int f0 = int(mine & 0x1FFFu), l0 = int((mine >> 13) & 0x1FFFu), d0 = int(mine >> 26);
+      mine = 0u;
+      if (d0 == 0) {                                              // __partial_sort(first, last, last): heapsort
+        if (lane == 0) { s2_heap_select(S.w, f0, l0, l0); s2_sort_heap(S.w, f0, l0); }
+        for (int p = f0 + lane; p < l0; p += 64) Q.bnd[p] = 1;               // already final: one leaf per element
+        wave_lds_order();
+        if (lane == 0) atomicSub(const_cast<int*>(&cnt[4]), 1);
+        continue;
+      }
+      const int cut = sel2_partition<W, 1, 0, SOLO>(S, f0, l0, S.la + f0, S.lb + f0, lane);
+      const bool left = cut - f0 > 16, right = l0 - cut > 16;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this partition's swaps before the publication
+      if (lane == 0) {
+        Q.bnd[cut] = 1;
+        if (left && right) {                                      // publish the right child, keep the left one
+          const int j = atomicAdd(const_cast<int*>(&cnt[3]), 1);
+          atomicAdd(const_cast<int*>(&cnt[4]), 1);
+          if (j < kMaxSeg2) pool[j] = seg_pack(cut, l0, d0 - 1); else guard_hit(4);
+        } else if (!left && !right) {
+          atomicSub(const_cast<int*>(&cnt[4]), 1);
+        }
+      }
+      if (left) mine = seg_pack(f0, cut, d0 - 1);
+      else if (right) mine = seg_pack(cut, l0, d0 - 1);
+      wave_lds_order();
+      if (guard == 8 * kMaxSeg2 - 1 && lane == 0) guard_hit(2);
+    }
+  }
+  __syncthreads();
+  // stable sort inside each leaf == __final_insertion_sort.  Leaf id = prefix count of the boundary flags; leaf
+  // starts are scattered by id (into la, free now), so every element finds [ls, le) in two reads.
+  {
+    const int Ept = (n + NT - 1) / NT;
+    const int b = tid * Ept, e = min(n, b + Ept);
+    uint32_t c = 0;
+    for (int p = b; p < e; ++p) c += Q.bnd[p];
+    const uint32_t incl = wave_incl_scan_u32(c);
+    uint32_t pre = 0u, all = incl;
+    if constexpr (NW > 1) {
+      if (lane == 63) S.xch[wave] = incl;
+      __syncthreads();
+      all = 0u;
+#pragma unroll
+      for (int v = 0; v < NW; ++v) { const uint32_t t = S.xch[v]; if (v < wave) pre += t; all += t; }
+    } else {
+      all = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+    }
+    uint32_t id = pre + incl - c;                             // leaves before position b
+    for (int p = b; p < e; ++p) {
+      if (Q.bnd[p]) { S.la[id] = uint16_t(p); ++id; }
+      S.lb[p] = uint16_t(id - 1);                             // leaf id of position p
+    }
+    if (tid == 0) S.la[all] = uint16_t(n);                    // sentinel end
+    __syncthreads();
+    for (int p = tid; p < n; p += NT) {
+      const int lid = S.lb[p];
+      const int ls = S.la[lid], le = S.la[lid + 1];
+      const uint32_t kp = T::key(S.w[p]);
+      int r = ls;
+#pragma unroll 4
+      for (int q = ls; q < le; ++q) {
+        const uint32_t kq = T::key(S.w[q]);
+        r += (kq < kp || (kq == kp && q < p)) ? 1 : 0;
+      }
+      out_order[r] = T::idx(S.w[p]);
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace vc2

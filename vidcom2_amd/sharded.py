@@ -53,8 +53,7 @@ class HipStages:
         self.mask = torch.empty(D, dtype=torch.uint8, device=self.device)
         self.C = int(D * 0.5)                                   # int(x.shape[-1] * ratio), vidcom2.py:41
         self.cols = torch.empty(D, dtype=torch.int32, device=self.device)
-        self.order = torch.empty(D, dtype=torch.int32, device=self.device)    # channels in torch.topk order
-        self.opos = torch.empty(D, dtype=torch.int32, device=self.device)
+        self.perm = torch.empty(D, dtype=torch.int32, device=self.device)     # channels as nth_element left them
         self.spos = torch.empty(D, dtype=torch.int32, device=self.device)     # their positions in that order
         self.total = torch.empty(F * N, dtype=torch.float32, device=self.device)
         self.s = torch.empty(F, dtype=torch.float32, device=self.device)
@@ -68,7 +67,7 @@ class HipStages:
         # device pointers of the fixed buffers, resolved once: the per-pass host work is five C calls plus
         # three collectives, and that host time bounds the pass when it exceeds the ~0.3 ms of GPU work
         self._L = L
-        self._p = {n: ptr(getattr(self, n)) for n in ("ws", "stats", "csum", "var_f32", "mask", "cols", "order", "opos",
+        self._p = {n: ptr(getattr(self, n)) for n in ("ws", "stats", "csum", "var_f32", "mask", "cols", "perm",
                                                      "spos", "total", "s", "idx", "ks", "kout", "rows")}
         self._ws_n = self.ws.numel()
 
@@ -86,15 +85,16 @@ class HipStages:
         P = stats_all.shape[0]
         check(self._L.vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, p["var_f32"], st),
               "vc2_chan_var_from_stats")
-        # cols on this stream; torch.topk's channel ORDER (needed only by the fix-up kernels of phase 1) on the
-        # library's side stream, joined inside vc2_scores_phase1
-        check(self._L.vc2_chan_select_overlapped(p["var_f32"], self.D, self.C, p["mask"], p["cols"], p["order"],
-                                                 p["opos"], p["spos"], st), "vc2_chan_select_overlapped")
+        # the channel SET now; torch.topk's channel ORDER (needed only by the fix-up kernels of phase 1) is
+        # replayed from `perm` by a rider workgroup of sweep 2 inside vc2_scores_phase1
+        check(self._L.vc2_chan_select(p["var_f32"], self.D, self.C, p["mask"], p["cols"], p["perm"], None, None, None,
+                                      st), "vc2_chan_select")
 
     def phase1(self, x):
         p = self._p
         check(self._L.vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
-                                        p["ws"], self._ws_n, p["csum"], self._st()), "vc2_scores_phase1")
+                                        p["perm"], p["var_f32"], p["ws"], self._ws_n, p["csum"], self._st()),
+              "vc2_scores_phase1")
         return self.csum
 
     def phase2(self, x, csum_all, R_total):

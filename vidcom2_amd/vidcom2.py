@@ -200,15 +200,16 @@ def _channel_variance(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 def low_var_channel_order(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
     """Indices torch.topk(var, int(D*ratio), largest=False) returns on the CPU reference, in ITS order
     (ascending variance, libstdc++ nth_element + sort tie order), replayed on the device
-    (k_chan_select: workgroup-parallel introselect + introsort)."""
+    (k_chan_select + k_chan_order: workgroup-parallel introselect + introsort)."""
     x = _prep(x, "x")
     D = x.shape[-1]
     k = int(D * ratio)
     _, var_f = _channel_variance(x)
     order = torch.empty(max(k, 1), dtype=torch.int32, device=x.device)
+    perm = torch.empty(max(k, 1), dtype=torch.int32, device=x.device)
     if k > 0:
-        check(lib().vc2_chan_select(ptr(var_f), D, k, None, None, ptr(order), None, None, stream_ptr(x.device)),
-              "vc2_chan_select")
+        check(lib().vc2_chan_select(ptr(var_f), D, k, None, None, ptr(perm), ptr(order), None, None,
+                                    stream_ptr(x.device)), "vc2_chan_select")
     return order[:k].to(torch.int64)
 
 
