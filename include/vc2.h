@@ -104,9 +104,11 @@ int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int
 /* vidcom2.py:72-77  ks = (scales*tpf).round().long().clamp(min=1); per frame the k_f smallest
  * total scores (CPU-reference tie-breaking), ascending.  map_mode selects the index mapping
  * fused into the output (VC2_MAP_*; grid_h only for GRID_VID).  Outputs: ks int64[F],
- * offs int64[F+1] (exclusive prefix of ks), idx_out int64[cap] and K_out[0] = number of indices
+ * (tpf = the reference's multiplier, normally N; a k_f > N is reported raw in ks while min(k_f, N) tokens are
+ * selected -- the caller raises torch.topk's "k out of range" error),
+ * offs int64[F+1] (exclusive prefix of min(ks, N)), idx_out int64[cap] and K_out[0] = number of indices
  * written (K_out[1] = 1 if it would have exceeded `cap`; then nothing past cap is written). */
-int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int dtype,
+int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int64_t tpf, int dtype,
                int map_mode, int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs,
                int64_t* idx_out, int64_t cap, int64_t* K_out, void* stream);
 

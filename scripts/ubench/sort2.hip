@@ -54,21 +54,23 @@ int main() {
   hipMemcpy(d, w.data(), 4096 * 4, hipMemcpyHostToDevice);
   unsigned long long h[2];
   size_t smem = sel2_bytes(n + 1, 4) + sort2_bytes(n + 1) + (n + 1) * 4 + 256;
-  for (int rep = 0; rep < 2; ++rep) {
+  for (int rep = 0; rep < 1; ++rep) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_sort<4, 4, 4>), dim3(1), dim3(256), smem, 0, d, n, 20, dout, dord);
-    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-    hipMemcpy(h, dout, 8, hipMemcpyDeviceToHost);
-    printf("introsort2 NW=4  n=%d: %llu cycles per sort; wall %.1f us per rep (incl. reload)\n", n, h[0], ms * 1000 / 20);
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL((k_sort<16, 2, 2>), dim3(1), dim3(1024), smem, 0, d, n, 20, dout, dord);
     hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(h, dout, 8, hipMemcpyDeviceToHost);
     printf("introsort2 NW=16 n=%d: %llu cycles per sort; wall %.1f us per rep (incl. reload)\n", n, h[0], ms * 1000 / 20);
+    { unsigned long long z[128] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(vc2::g_sel2_dbg), z, sizeof(z)); }
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_sort<4, 4, 4>), dim3(1), dim3(256), smem, 0, d, n, 20, dout, dord);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h, dout, 8, hipMemcpyDeviceToHost);
+    printf("introsort2 NW=4  n=%d: %llu cycles per sort; wall %.1f us per rep (incl. reload)\n", n, h[0], ms * 1000 / 20);
   }
   { unsigned long long dbg[128]; hipMemcpyFromSymbol(dbg, HIP_SYMBOL(vc2::g_sel2_dbg), sizeof(dbg));
-    for (int l = 0; l < 14; ++l) printf("level %2d: segs %3llu  queue-phase cycles per wave: %6llu %6llu %6llu %6llu\n", l, dbg[l*8+1], dbg[l*8], dbg[l*8+2], dbg[l*8+4], dbg[l*8+6]); }
+    printf("last sort (NW=4): init %llu  phase1 %llu  phase2 %llu  (barrier %llu)\n", dbg[1]-dbg[0], dbg[2]-dbg[1], dbg[3]-dbg[2], dbg[4]-dbg[3]);
+    for (int w = 0; w < 16; ++w) printf("  wave %2d: partition cycles (all reps, both launches) %8llu in %4llu partitions\n", w, dbg[16+2*w], dbg[17+2*w]); }
   hipLaunchKernelGGL((k_small<0>), dim3(1), dim3(64), sel2_bytes(4096, 4), 0, d, 4096, 0, 40, 50, dout);
   hipMemcpy(h, dout, 16, hipMemcpyDeviceToHost); printf("partition E=1  len 40 : %llu cycles (cut %llu)\n", h[0], h[1]);
   hipLaunchKernelGGL((k_small<0>), dim3(1), dim3(64), sel2_bytes(4096, 4), 0, d, 4096, 100, 120, 50, dout);

@@ -32,7 +32,7 @@ _SIGNATURES = {
     "vc2_gather_cols": [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp],
     "vc2_scores": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp],
     "vc2_compute_scales": [_vp, _i64, _dbl, _dbl, _i32, _vp, _sz, _vp, _vp],
-    "vc2_select": [_vp, _vp, _i64, _i64, _i32, _i32, _i64, _vp, _sz, _vp, _vp, _vp, _i64, _vp, _vp],
+    "vc2_select": [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i64, _vp, _sz, _vp, _vp, _vp, _i64, _vp, _vp],
     "vc2_map_indices": [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp],
     "vc2_gather_rows": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "vc2_compress": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
@@ -104,6 +104,13 @@ def require_device(t: torch.Tensor, what: str) -> None:
             "device (torch device type 'cuda'). There is no CPU fallback -- move the tensor to the GPU.")
     if t.dtype not in DTYPE_CODE and t.dtype != torch.int64 and t.dtype != torch.uint8 and t.dtype != torch.float64:
         raise TypeError(f"{what}: unsupported dtype {t.dtype} (fp32 / bf16 / fp16 only)")
+
+
+def on_device(device):
+    """Context: make `device` the current HIP device for the duration of a library call.  The C ABI launches on the
+    stream it is given but keys per-device state (LDS opt-in, events) on the CURRENT device, and a tensor may live on
+    a GPU that is not current (HF device_map='auto' puts the vision tower's output anywhere)."""
+    return torch.cuda.device(device)
 
 
 def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:

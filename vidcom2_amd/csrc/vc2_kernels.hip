@@ -761,8 +761,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
 // values scattered to their SORTED positions, then the 8-chain / sequential fp32 sum).  Almost always the
 // T-rounded norm equals the exactly-rounded one already in den[]; when it does not, den[] is corrected and
 // the row is recorded so that k_centres can correct the column sums of its frame.  One wave per entry.
-struct NormCorr { int row; float den_old; float den_new; int frame; };
-constexpr int kMaxCorr = 4096;
+struct NormCorr { int row; float den_old; float den_new; int frame; };   // capacity: one per row (cannot overflow)
 
 template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int D, int CV, int C,
@@ -803,7 +802,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
     if (lane == 0 && !(dn == dn_old) && !(dn != dn && dn_old != dn_old)) {
       den[row] = dn;
       const int j = atomicAdd(corr_count, 1);
-      if (j < kMaxCorr) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
+      if (j < max_entries) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
     }
     wave_lds_fence();
     if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
@@ -811,7 +810,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
 }
 
 struct CFixEntry { int f; int c; };      // queued (frame, compact column) pair
-constexpr int kCFixMaxVid = 256;        // queued video-centre columns per pass (expected: a handful)
+// (queued video-centre columns: expected a handful; the list holds every column, it cannot overflow)
 
 // centres (compact channel space): frame_center[f][p] = mean_T(sum_n x^) and per-frame-group column
 // sums (fp64, fixed order).  grid = (ceil(C/64), ceil(F/16)); workgroup = 64 columns x 16 frames.
@@ -835,7 +834,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __rest
   double sf = 0.0;
   if (c < C && f < F) {
     for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
-    const int nc = corr_count ? min(*corr_count, kMaxCorr) : 0;
+    const int nc = corr_count ? *corr_count : 0;               // (<= rows: the list holds one entry per row)
     for (int e = 0; e < nc; ++e) {
       if (corr[e].frame == f) {
         const int row = corr[e].row;
@@ -870,7 +869,7 @@ __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t s
                              int* __restrict__ vfix_list = nullptr, int* __restrict__ vticket = nullptr) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [1] k_dist's strict-mode fix-up queue length ([0] spare)
-  if (vticket && c < kCFixMaxVid) vticket[c] = 0;           // per-entry arrival counters of k_centre_fix
+  if (vticket && c < C) vticket[c] = 0;                     // per-entry arrival counters of k_centre_fix
   if (c >= C) return;
   double t = 0.0;
   for (int p = 0; p < NP; ++p) t += parts[int64_t(p) * stride + c];
@@ -879,7 +878,7 @@ __global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t s
     vc[c] = mean_T<DT>(t, R_total);
     if (strict == 1 && vfix_count && mean_near_T_boundary<DT>(float(t) / float(R_total))) {
       const int j = atomicAdd(vfix_count, 1);
-      if (j < kCFixMaxVid) vfix_list[j] = c;
+      vfix_list[j] = c;                                         // (each column at most once: j < C)
     }
   }
 }
@@ -1002,7 +1001,7 @@ __global__ __launch_bounds__(kCFixWaves * 64) void k_centre_fix(const void* __re
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
   const int nf = all ? F * C : min(counts[0], fcap);
-  int nv = !do_vid ? 0 : (all ? C : min(counts[1], kCFixMaxVid));
+  int nv = !do_vid ? 0 : (all ? C : min(counts[1], C));
   if (R > (int64_t(1) << 19)) nv = 0;                         // level_power 5: not replayed (exact mean kept)
   const int64_t nbv = R >> 4;
   const int G1v = int((nbv + 15) >> 4);
@@ -1433,11 +1432,12 @@ __global__ __launch_bounds__(kMsgWaves * 64) void k_multi_scale_gaussian(const v
 }
 
 // k_f = clamp_min(long(round(RN_T(scale_f * tpf))), 1)   (vidcom2.py:72)
-template <int DT> __device__ __forceinline__ int budget_k(float scale, int N) {
-  float t = rnT<DT>(scale * float(N));
+template <int DT> __device__ __forceinline__ int budget_k(float scale, int tpf) {
+  float t = rnT<DT>(scale * float(tpf));
   t = rintf(t);                                    // round-half-even, like torch.round
-  int k = (t != t) ? 1 : (t < 1.f ? 1 : (t > float(N) ? N : int(t)));   // NaN.long() clamps to 1; scale <= 1
-  return k;
+  // NaN.long() clamps to 1 here (clamp(min=1) of the minimum int64); not clamped from above: torch.topk raises when
+  // k exceeds the row length (the callers take min(k, N) for the work and report the raw k)
+  return (t != t) ? 1 : (t < 1.f ? 1 : (t > 1.0e9f ? 1000000000 : int(t)));
 }
 
 template <int DT>
@@ -1516,7 +1516,7 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
 template <int DT>
 __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ total,
                                                      const float* __restrict__ scales_f32, int F, int f0, int N,
-                                                     int map_mode, int grid_h, int64_t stride, int64_t cap,
+                                                     int tpf, int map_mode, int grid_h, int64_t stride, int64_t cap,
                                                      int64_t* __restrict__ ks, int64_t* __restrict__ offs,
                                                      int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out,
                                                      const double* __restrict__ vpart, int S2,
@@ -1604,18 +1604,18 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
         t = rnT<DT>(t - pmean);
         t = rnT<DT>(base * t);
         if (t > 1.0f) t = 1.0f;
-        const int kk = budget_k<DT>(t, N);
+        const int kr = budget_k<DT>(t, tpf), kk = kr < N ? kr : N;
         if (i >= f0 && i < f) before += kk + extra;
         if (i >= f0 && i < f0 + FS) all += kk + extra;
-        if (i == f) { kmine = kk; scmine = t; }
+        if (i == f) { kmine = kr; scmine = t; }
       }
     }
   } else {
     for (int i = f0 + tid; i < f0 + FS; i += kFrameNT) {
-      const int kk = budget_k<DT>(scales_f32[i], N);
+      const int kr = budget_k<DT>(scales_f32[i], tpf), kk = kr < N ? kr : N;
       if (i < f) before += kk + extra;
       all += kk + extra;
-      if (i == f) { kmine = kk; scmine = scales_f32[i]; }
+      if (i == f) { kmine = kr; scmine = scales_f32[i]; }
     }
   }
   // block sums of (before, all) and broadcast of this frame's k (exactly one thread holds it)
@@ -1633,9 +1633,10 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
     if (holder) { smi[0] = kmine; smf[0] = scmine; }
   }
   __syncthreads();
-  const int k = int(smi[0]);
+  const int kraw = int(smi[0]);                                 // round(scale * tpf): may exceed N when tpf != N
+  const int k = kraw < N ? kraw : N;
   if (tid == 0) {
-    ks[fl] = k;
+    ks[fl] = kraw;                                              // (the caller turns k > N into torch.topk's error)
     offs[fl] = o0;
     if (scales_out) scales_out[fl] = smf[0];
     if (fl == FS - 1) {
@@ -1775,13 +1776,13 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   p->o_offs = take(size_t(F + 1) * 8);
   p->o_ticket = take(64);
   p->o_nfixlist = take(size_t(p->R) * 4);
-  p->o_corr = take(size_t(kMaxCorr) * sizeof(NormCorr));
-  p->cfix_cap = int(std::min<int64_t>(std::max<int64_t>(4096, F * D / 32), int64_t(1) << 22));
+  p->o_corr = take(size_t(p->R) * sizeof(NormCorr));
+  p->cfix_cap = int(std::min<int64_t>(F * D, int64_t(1) << 30));     // every (frame, column) pair: cannot overflow
   p->o_cfixlist = take(size_t(p->cfix_cap) * sizeof(CFixEntry));
-  p->o_vfixlist = take(size_t(kCFixMaxVid) * 4);
+  p->o_vfixlist = take(size_t(D) * 4);
   p->vstride = int(cdiv(cdiv(std::min<int64_t>(p->R, int64_t(1) << 19), 16), 16) + 1);
-  p->o_vscratch = take(size_t(kCFixMaxVid) * p->vstride * 4);
-  p->o_vticket = take(size_t(kCFixMaxVid) * 4);
+  p->o_vscratch = take(size_t(D) * p->vstride * 4);
+  p->o_vticket = take(size_t(D) * 4);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
   p->total_bytes = o;
   return VC2_OK;
@@ -1804,7 +1805,8 @@ const char* const kKernelNames[KID_COUNT] = {"k_chan_stats", "k_stats_reduce", "
                                              "k_select", "k_gather_rows", "k_norm_fix", "k_chan_select(order; side stream)",
                                              "k_dist_fix", "k_centre_fix"};
 struct ProfRec { int id; hipEvent_t a, b; };
-bool g_prof = false;
+bool g_prof = false;                // (bench-only; the record list is mutex-protected)
+std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof_recs;
 double g_prof_ms[KID_COUNT];
 int64_t g_prof_n[KID_COUNT];
@@ -1815,7 +1817,7 @@ struct ProfScope {
     if (g_prof) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
   }
   ~ProfScope() {
-    if (g_prof && a) { (void)hipEventRecord(b, st); g_prof_recs.push_back({id, a, b}); }
+    if (g_prof && a) { (void)hipEventRecord(b, st); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back({id, a, b}); }
   }
 };
 
@@ -1891,7 +1893,7 @@ int launch_chan_order(const OrderArgs& oa, hipStream_t st) {
 
 // 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
 // result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
-int g_strict = 1;
+thread_local int g_strict = 1;      // per calling thread (vc2_set_mode): concurrent callers cannot change each other's mode
 
 // the scored channels: ascending list (nullptr = all D), the same channels in torch.topk's order and their
 // positions in `cols` (both nullptr = identity when cols is nullptr, else strict mode is unavailable)
@@ -2014,7 +2016,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
                                            wsp<NormCorr>(ws, p.o_corr), cs.strict, cfix_count, cfix_list,
                                            p.cfix_cap));
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(std::max(C, kCFixMaxVid), 128))),
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))),
                                            dim3(128), 0, st, cpart, FG, int64_t(C), C, p.R,
                                            single_rank ? (double*)nullptr : wsp<double>(ws, p.o_csum),
                                            single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr,
@@ -2075,7 +2077,7 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 // F budget frames, of which this launch selects [f0, f0 + F_sel) (total / ks / offs are indexed by the local frame).
 // Budgets: vpart (sweep-3 partials, S2 per frame) or frame_scores -> compute_scales in the kernel; else scales_f32[F].
 struct BudgetSrc { const float* scales_f32; const double* vpart; int S2; const float* frame_scores; double base; double temp;
-                   float* scales_out; };
+                   float* scales_out; int64_t tpf = 0; };      // tpf: the multiplier of vidcom2.py:72 (0: N)
 int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_sel, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   const BudgetSrc& b, hipStream_t st) {
@@ -2085,7 +2087,8 @@ int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_s
     int rca = allow_big_lds(&k_select<DT>, smem, "k_select");
     if (rca) return rca;
     hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F_sel)), dim3(kFrameNT), smem, st, total, b.scales_f32, int(F),
-                       int(f0), int(N), map_mode, int(grid_h), N, cap, ks, offs, idx_out, K_out, b.vpart, b.S2,
+                       int(f0), int(N), int(b.tpf > 0 ? b.tpf : N), map_mode, int(grid_h), N, cap, ks, offs, idx_out, K_out,
+                       b.vpart, b.S2,
                        b.frame_scores, float(b.base), float(b.temp), b.scales_out);
   });
   return check_launch("select");
@@ -2280,7 +2283,7 @@ int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int
   return launch_scales(dtype, s32, F, base, temp, zbuf, nullptr, scales_T, st);
 }
 
-int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int dtype, int map_mode,
+int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int64_t tpf, int dtype, int map_mode,
                int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs, int64_t* idx_out,
                int64_t cap, int64_t* K_out, void* stream) {
   if (!scores_T || !scales_T || !ks || !offs || !idx_out || !K_out || F <= 0 || N <= 0)
@@ -2299,7 +2302,7 @@ int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N,
     hipLaunchKernelGGL((k_widen<DT>), dim3(unsigned(cdiv(F, 256))), dim3(256), 0, st, scales_T, F, sc);
   });
   return launch_select(dtype, tot, F, 0, F, N, map_mode, grid_h, ks, offs, idx_out, cap, K_out,
-                       BudgetSrc{sc, nullptr, 0, nullptr, 0.0, 0.01, nullptr}, st);
+                       BudgetSrc{sc, nullptr, 0, nullptr, 0.0, 0.01, nullptr, tpf}, st);
 }
 
 int vc2_map_indices(const int64_t* local_idx, const int64_t* ks, const int64_t* offs, int64_t F, int map_mode,
@@ -2472,6 +2475,7 @@ int vc2_profile_enable(int on) {
 
 int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, int64_t* launches) {
   // synchronises on the recorded events, accumulates and frees them
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof_recs) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {

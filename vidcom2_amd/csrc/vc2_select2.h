@@ -421,10 +421,16 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
   const int lane = tid & 63, wave = tid >> 6;
   volatile uint32_t* pool = Q.segA;
   volatile int* cnt = Q.cnt;
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) g_sel2_dbg[0] = __builtin_readcyclecounter();
+#endif
   for (int p = tid; p < n; p += NT) Q.bnd[p] = (p == 0) ? 1 : 0;
   for (int p = tid; p < kMaxSeg2; p += NT) { Q.segA[p] = 0u; Q.segB[p] = 0u; }
   if (tid < 8) Q.cnt[tid] = 0;
   __syncthreads();
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) g_sel2_dbg[1] = __builtin_readcyclecounter();
+#endif
   // ---- phase 1: long segments, level by level, all waves together (lists in segB, ping-pong halves)
   uint32_t* cur = Q.segB;
   uint32_t* nxt = Q.segB + kMaxSeg2 / 2;
@@ -467,6 +473,9 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
       __syncthreads();
     }
   }
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) g_sel2_dbg[2] = __builtin_readcyclecounter();
+#endif
   // ---- phase 2: the pool.  cnt[2] = head (next entry to take), cnt[3] = tail (next free slot), cnt[4] = segments
   //      published or in work.  An entry is valid once its word is non-zero (written after the slot was claimed).
   {
@@ -499,7 +508,13 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
         if (lane == 0) atomicSub(const_cast<int*>(&cnt[4]), 1);
         continue;
       }
+#ifdef VC2_SEL2_DEBUG
+      const unsigned long long dt0 = __builtin_readcyclecounter();
+#endif
       const int cut = sel2_partition<W, 1, 0, SOLO>(S, f0, l0, S.la + f0, S.lb + f0, lane);
+#ifdef VC2_SEL2_DEBUG
+      if (lane == 0) { g_sel2_dbg[16 + wave * 2] += __builtin_readcyclecounter() - dt0; g_sel2_dbg[17 + wave * 2] += 1; }
+#endif
       const bool left = cut - f0 > 16, right = l0 - cut > 16;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this partition's swaps before the publication
       if (lane == 0) {
@@ -518,7 +533,13 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
       if (guard == 8 * kMaxSeg2 - 1 && lane == 0) guard_hit(2);
     }
   }
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) g_sel2_dbg[3] = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) g_sel2_dbg[4] = __builtin_readcyclecounter();
+#endif
   // stable sort inside each leaf == __final_insertion_sort.  Leaf id = prefix count of the boundary flags; leaf
   // starts are scattered by id (into la, free now), so every element finds [ls, le) in two reads.
   {

@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from . import _ffi
-from ._ffi import DTYPE_CODE, check, lib, ptr, stream_ptr
+from ._ffi import DTYPE_CODE, check, lib, on_device, ptr, stream_ptr
 
 
 @dataclass
@@ -155,6 +155,19 @@ class ShardedCompressor:
         return _all_gather(t, self.group, self.world, buf)
 
     def enqueue(self, x_local: torch.Tensor) -> None:
+        st = self.stages
+        if isinstance(st, HipStages):
+            if x_local.dim() != 2 or tuple(x_local.shape) != (self.F * self.N, self.D) or x_local.dtype != st.dtype \
+                    or x_local.device != st.device:
+                raise RuntimeError(f"x_local must be a {st.dtype} [{self.F * self.N}, {self.D}] tensor on {st.device}, "
+                                   f"got {x_local.dtype} {tuple(x_local.shape)} on {x_local.device}")
+            if not x_local.is_contiguous():
+                x_local = x_local.contiguous()
+            with on_device(st.device):
+                return self._enqueue(x_local)
+        return self._enqueue(x_local)
+
+    def _enqueue(self, x_local: torch.Tensor) -> None:
         st = self.stages
         R_total = self.F_total * self.N
         stats_all = self._gather("stats", st.chan_stats(x_local))               # exchange 1: [W, 2, D] fp64

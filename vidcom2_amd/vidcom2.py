@@ -18,7 +18,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 
 from . import _ffi
-from ._ffi import DTYPE_CODE, MAP_GRID_VID, MAP_LINEAR, MAP_LOCAL, check, lib, ptr, require_device, stream_ptr
+from ._ffi import DTYPE_CODE, MAP_GRID_VID, MAP_LINEAR, MAP_LOCAL, check, lib, on_device, ptr, require_device, stream_ptr
 
 # vidcom2.py:7-13 -- 'mapper' selects the index mapping, 'tpf' the default tokens per frame
 # (None = provided per call through frame_token_len).
@@ -31,6 +31,28 @@ MODEL_SPECS: Dict[str, Dict[str, Any]] = {
 }
 _DYNAMIC_TPF = {"qwen2_vl", "qwen2_5_vl", "qwen3_vl"}
 _ALPHAS = [2 ** k for k in range(-3, 2)]          # vidcom2.py:54
+
+
+def _first_tensor(a):
+    if isinstance(a, torch.Tensor):
+        return a
+    if isinstance(a, (list, tuple)) and a and isinstance(a[0], torch.Tensor):
+        return a[0]
+    return None
+
+
+def _guarded(fn):
+    """Run `fn` with the device of its first tensor argument current (see _ffi.on_device)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = next((x for x in map(_first_tensor, args) if x is not None), None)
+        if t is None or t.device.type != "cuda":
+            return fn(*args, **kwargs)
+        with on_device(t.device):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _as_int(v) -> int:
@@ -81,17 +103,19 @@ class CompressPlan:
         self.ws = _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
         self.idx = torch.empty(cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(self.F, dtype=torch.int64, device=self.device)
-        self.kout = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.kout = torch.empty(2, dtype=torch.int64, device=self.device)    # both words written by every pass
         self.rows = torch.empty((cap, self.D), dtype=dtype, device=self.device) if gather else None
         self.v = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
         self.f = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
 
     def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None) -> None:
         src = flat if gather_src is None else gather_src
-        rc = lib().vc2_compress(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
-                                self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
-                                src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx), self.cap,
-                                ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f), stream_ptr(self.device))
+        with on_device(self.device):
+            rc = lib().vc2_compress(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
+                                    self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
+                                    src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
+                                    self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
+                                    stream_ptr(self.device))
         check(rc, "vc2_compress")
 
     def finish(self) -> CompressionResult:
@@ -103,6 +127,7 @@ class CompressPlan:
         return CompressionResult(rows, self.idx[:K], self.ks, int(K), self.v, self.f)
 
 
+@_guarded
 def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, mapper: str = "linear",
              grid_h: int = 0, img_feat: Optional[torch.Tensor] = None, want_scores: bool = False,
              gather: bool = True) -> CompressionResult:
@@ -122,6 +147,11 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
         src = _prep(img_feat, "img_feat")
         if src.dtype != x.dtype or src.shape[-1] != D:
             raise RuntimeError("img_feat must have the dtype and feature dim of flattened_feat")
+        need = (R // tpf) * int(grid_h) * (int(grid_h) + 1)
+        if src.dim() != 2 or src.shape[0] < need:
+            # the reference fails in img[_map_grid_vid(...)] (vidcom2.py:96) with an IndexError
+            raise IndexError(f"index {need - 1} is out of bounds for dimension 0 with size {src.shape[0]}"
+                             if src.dim() == 2 else "img_feat must be 2-D [rows, dim]")
     plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather)
     plan.enqueue(x, src)
     return plan.finish()
@@ -151,8 +181,8 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2
             j, pl, ps = pending.pop(0)
             with torch.cuda.stream(ps):
                 results[j] = pl.finish()
-        plan = CompressPlan(x.shape[0] // int(tpf), int(tpf), x.shape[1], x.dtype, dev, base_scale, gather=gather)
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(st):       # the plan's buffers are allocated (and owned) on the lane's stream
+            plan = CompressPlan(x.shape[0] // int(tpf), int(tpf), x.shape[1], x.dtype, dev, base_scale, gather=gather)
             plan.enqueue(x)
         pending.append((i, plan, st))
     for j, pl, ps in pending:
@@ -163,6 +193,7 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2
     return results
 
 
+@_guarded
 def vidcom2_compression(flattened_feat: torch.Tensor, model: str = "llava_ov", base_scale: float = 0.25,
                         frame_token_len: Optional[int] = None,
                         img_feat: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -186,6 +217,7 @@ def vidcom2_compression(flattened_feat: torch.Tensor, model: str = "llava_ov", b
 # stage functions (same decomposition as the reference)
 # ---------------------------------------------------------------------------------------------
 
+@_guarded
 def _channel_variance(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """x.var(dim=0, unbiased=False) (vidcom2.py:40): returns (var in T, fp32-widened copy)."""
     R, D = x.shape
@@ -197,6 +229,7 @@ def _channel_variance(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return var_T, var_f
 
 
+@_guarded
 def low_var_channel_order(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
     """Indices torch.topk(var, int(D*ratio), largest=False) returns on the CPU reference, in ITS order
     (ascending variance, libstdc++ nth_element + sort tie order), replayed on the device
@@ -213,6 +246,7 @@ def low_var_channel_order(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
     return order[:k].to(torch.int64)
 
 
+@_guarded
 def select_low_var_channels(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor:
     """Reference: vidcom2.py:38-43.  Returns x[:, idx] -- a copy, columns in topk order."""
     x = _prep(x, "x")
@@ -228,6 +262,7 @@ def select_low_var_channels(x: torch.Tensor, ratio: float = 0.5) -> torch.Tensor
     return out
 
 
+@_guarded
 def compute_gaussian_scores(x: torch.Tensor, tpf: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Reference: vidcom2.py:45-57.  x = channel-selected features [F*tpf, C]; returns (v, f) [F, tpf]."""
     x = _prep(x, "x")
@@ -248,23 +283,43 @@ def _multi_scale_gaussian(x: torch.Tensor, center: torch.Tensor, alphas: List[fl
     """Reference: vidcom2.py:59-62.  x T[F, N, C], center T[1, 1, C] or T[F, 1, C] (the two shapes
     compute_gaussian_scores uses, vidcom2.py:51-52) -> T[F, N].  The fused pass never calls this (it
     does not materialise x); it exists for callers of the helper itself."""
-    if x.dim() != 3 or center.dim() != 3 or center.shape[1] != 1 or center.shape[2] != x.shape[2] \
-            or center.shape[0] not in (1, x.shape[0]):
-        raise RuntimeError(f"_multi_scale_gaussian: x [F, N, C] with center [1, 1, C] or [F, 1, C] expected, got "
-                           f"{tuple(x.shape)} and {tuple(center.shape)}")
     alphas = [float(a) for a in alphas]
     if not alphas:
         return 0                     # Python's sum() over no terms, exactly like the reference
-    F, N, C = x.shape
-    xx = _prep(x, "x")
-    cc = _prep(center.to(x.dtype), "center")
-    out = torch.empty(F, N, dtype=x.dtype, device=x.device)
+    # (x - center) broadcasts like torch: any x [..., C] and any center broadcastable to it
+    out_shape = torch.broadcast_shapes(tuple(x.shape), tuple(center.shape))
+    if len(out_shape) < 1:
+        raise RuntimeError("_multi_scale_gaussian: x must have a channel dimension")
+    C = out_shape[-1]
+    xb = x.expand(out_shape)
+    cb = center.to(x.dtype).expand(out_shape)
+    lead = out_shape[:-1]
+    R = 1
+    for d in lead:
+        R *= int(d)
+    # centre layouts the kernel knows: one row, one row per "frame" (constant along the last leading dim), or one
+    # row per token (anything else)
+    if all(int(cb.stride(i)) == 0 or out_shape[i] == 1 for i in range(len(lead))):
+        F, N, cc = 1, R, cb[tuple(0 for _ in lead)].reshape(1, C)
+    elif len(lead) >= 2 and (int(cb.stride(len(lead) - 1)) == 0 or out_shape[len(lead) - 1] == 1):
+        N = int(out_shape[len(lead) - 1])
+        F = R // N
+        cc = cb.select(len(lead) - 1, 0).reshape(F, C)
+    else:
+        F, N, cc = R, 1, cb.reshape(R, C)
+    xx = _prep(xb.reshape(R, C), "x")
+    cc = _prep(cc, "center")
+    out = torch.empty(lead, dtype=x.dtype, device=x.device)
+    if R == 0:
+        return out
     arr = (ctypes.c_double * len(alphas))(*alphas)
-    check(lib().vc2_multi_scale_gaussian(ptr(xx), F, N, C, DTYPE_CODE[x.dtype], ptr(cc), cc.shape[0], arr,
-                                         len(alphas), ptr(out), stream_ptr(x.device)), "_multi_scale_gaussian")
+    with on_device(x.device):
+        check(lib().vc2_multi_scale_gaussian(ptr(xx), F, N, C, DTYPE_CODE[x.dtype], ptr(cc), cc.shape[0], arr,
+                                             len(alphas), ptr(out), stream_ptr(x.device)), "_multi_scale_gaussian")
     return out
 
 
+@_guarded
 def compute_scales(scores: torch.Tensor, base: float, temp: float = 0.01) -> torch.Tensor:
     """Reference: vidcom2.py:64-68.  scores T[F] -> scales T[F]."""
     s = _prep(scores, "scores")
@@ -288,17 +343,17 @@ def _select(scores: torch.Tensor, scales: torch.Tensor, tpf: int, map_mode: int,
     if sl.dtype != sc.dtype:
         sl = sl.to(sc.dtype)
     F, N = sc.shape
-    if int(tpf) != N:
-        raise NotImplementedError("select_outlier_indices: tpf must equal scores.shape[1]")
     extra = grid_h if map_mode == MAP_GRID_VID else 0
     cap = F * (N + extra)
     ws = torch.empty(F * N * 4 + F * 4 + 1024, dtype=torch.uint8, device=sc.device)
     ks = torch.empty(F, dtype=torch.int64, device=sc.device)
     offs = torch.empty(F + 1, dtype=torch.int64, device=sc.device)
     idx = torch.empty(cap, dtype=torch.int64, device=sc.device)
-    kout = torch.zeros(2, dtype=torch.int64, device=sc.device)
-    check(lib().vc2_select(ptr(sc), ptr(sl), F, N, DTYPE_CODE[sc.dtype], map_mode, grid_h, ptr(ws), ws.numel(),
-                           ptr(ks), ptr(offs), ptr(idx), cap, ptr(kout), stream_ptr(sc.device)), "vc2_select")
+    kout = torch.empty(2, dtype=torch.int64, device=sc.device)
+    with on_device(sc.device):
+        check(lib().vc2_select(ptr(sc), ptr(sl), F, N, int(tpf), DTYPE_CODE[sc.dtype], map_mode, grid_h, ptr(ws),
+                               ws.numel(), ptr(ks), ptr(offs), ptr(idx), cap, ptr(kout), stream_ptr(sc.device)),
+              "vc2_select")
     return idx, ks, offs, kout
 
 
@@ -307,6 +362,9 @@ def select_outlier_indices(scores: torch.Tensor, scales: torch.Tensor, tpf: int)
     reference's ``.tolist()``)."""
     idx, ks, _, kout = _select(scores, scales, _as_int(tpf), MAP_LOCAL)
     ks_host = ks.tolist()
+    N = scores.shape[1]
+    if any(k > N for k in ks_host):          # ks = round(scales * tpf) with tpf > N: torch.topk's own error (vidcom2.py:76)
+        raise RuntimeError("selected index k out of range")
     return list(torch.split(idx[: sum(ks_host)], ks_host))
 
 
@@ -323,6 +381,7 @@ def _cat_indices(indices: List[torch.Tensor]):
     return loc, ks.to(dev), offs.to(dev), ks_host
 
 
+@_guarded
 def _map_linear_offset(indices: List[torch.Tensor], tpf: int) -> torch.Tensor:
     """Reference: vidcom2.py:99-103."""
     loc, ks, offs, _ = _cat_indices(indices)
@@ -333,6 +392,7 @@ def _map_linear_offset(indices: List[torch.Tensor], tpf: int) -> torch.Tensor:
     return out
 
 
+@_guarded
 def _map_grid_vid(indices: List[torch.Tensor], h: int) -> torch.Tensor:
     """Reference: vidcom2.py:105-115 (per frame: kept tokens on the h x (h+1) grid, then its h newlines)."""
     loc, ks, offs, ks_host = _cat_indices(indices)
@@ -343,6 +403,7 @@ def _map_grid_vid(indices: List[torch.Tensor], h: int) -> torch.Tensor:
     return out
 
 
+@_guarded
 def _gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     src = _prep(src, "features")
     K = idx.numel()
@@ -356,6 +417,7 @@ def _gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_guarded
 def map_features(indices: List[torch.Tensor], flat: torch.Tensor, img: Optional[torch.Tensor],
                  spec: Dict[str, Any]) -> torch.Tensor:
     """Reference: vidcom2.py:80-97."""
