@@ -138,21 +138,30 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
                  int64_t* ks, int64_t* K_out, void* v_T, void* f_T, void* stream);
 
 /* ---- frame-sharded multi-GPU building blocks -------------------------
- * A rank holds frames [f0, f0+F_local) of a video with F_total frames.  Between the local
- * sweeps the Python layer all-gathers three small fp64/fp32 vectors over RCCL:
- *   1. per-rank column sums   stats[2][D]  (sum x, sum x^2)            -> vc2_chan_var_from_stats
- *   2. per-rank centre sums   csum[D]      (sum of normalised tokens)  -> vc2_scores_phase2
- *   3. per-frame uniqueness   s[F_local]                               -> vc2_select on F_total */
-int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes,
-                   double* stats /*[2][D]*/, void* stream);
-int vc2_chan_var_from_stats(const double* stats /*[P][2][D]*/, int64_t P, int64_t R_total, int64_t D,
-                            int dtype, void* var_T, float* var_f32, void* stream);
+ * A rank holds frames [f0, f0+F_local) of a video with F_total frames.  Between the local sweeps the Python
+ * layer all-gathers three small fp64 / fp32 arrays over RCCL.  Exchanges 1 and 2 carry CANONICAL partials -- per
+ * stat block of 8 frames (mean, M2), per group of 16 frames the sums of the normalised tokens -- that every rank then
+ * folds in the same fixed order, so the reduced bits do not depend on the world size (ranks holding a multiple of 16
+ * frames; otherwise equal up to fp64 rounding):
+ *   1. per stat block (mean, M2)   bstats[nb][2][D], nb = F_local / block_frames     -> vc2_chan_var_from_stats
+ *   2. per 16-frame group sums of x^   csum_parts[ceil(F_local/16)][C]                 -> vc2_scores_phase2
+ *   3. per-frame uniqueness   s[F_local]                                               -> vc2_select_sharded
+ * F_total (the WHOLE video's frame count) fixes how frames are cut into row groups / splits on every rank. */
+int vc2_stat_block_frames(void);     /* 8: the unsharded pass's stat block */
+/* block_frames: frames per stat block, 1..8; use 8 when F_local is a multiple of 8 (bit-identical to the unsharded
+ * pass), else the largest power of two dividing F_local -- the same value on every rank. */
+int vc2_chan_stats(const void* x, int64_t F, int64_t N, int64_t D, int dtype, int64_t F_total, int block_frames,
+                   void* ws, size_t ws_bytes, double* bstats /*[F / block_frames][2][D]*/, void* stream);
+/* bstats of ALL ranks concatenated in rank order; rows_per_block = block_frames * N (the last block holds the
+ * remainder). */
+int vc2_chan_var_from_stats(const double* bstats /*[NB][2][D]*/, int64_t NB, int64_t rows_per_block,
+                            int64_t R_total, int64_t D, int dtype, void* var_T, float* var_f32, void* stream);
 /* perm != NULL (with var_f32 = the widened variances vc2_chan_select consumed): in mode 1 spos[C] is PRODUCED by a
  * rider workgroup of sweep 2 (the ORDER replay of vc2_chan_select, off the critical path) and then used by the
  * fix-up kernels; perm == NULL: spos must already be valid (or NULL: mode 0 / cols == NULL). */
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
-                      int64_t C, int32_t* spos, const int32_t* perm, const float* var_f32, void* ws,
-                      size_t ws_bytes, double* csum /*[C]*/, void* stream);
+                      int64_t C, int32_t* spos, const int32_t* perm, const float* var_f32, int64_t F_total,
+                      void* ws, size_t ws_bytes, double* csum_parts /*[ceil(F/16)][C]*/, void* stream);
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                       int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,

@@ -1,0 +1,58 @@
+"""GPU: the reference's results at BASELINE.json's big configurations (tests/golden/big_cases.json, made by
+tests/golden/make_big_golden.py from the reference itself): cfg4 = 512 x 196 x 3584 bf16 -- unsharded AND as 8 / 4 / 2
+logical ranks of the frame-sharded path on one GPU --, extra seeds and distributions at the headline target shape
+and cfg3, and a full cfg5 clip.  Everything is compared bit for bit ("torch order" mode): budgets, kept indices,
+kept rows, both score tensors."""
+import os
+
+import pytest
+import torch
+
+import vidcom2_amd as vc
+from vidcom2_amd import _ffi, synth
+from conftest import DT, load_json
+
+pytestmark = pytest.mark.gpu
+BIG = load_json("big_cases.json")["cases"] if os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "big_cases.json")) else []
+
+
+def _id(c):
+    return f"{c['name']}-{c['dtype']}-{c['dist']}-s{c['seed']}"
+
+
+def _check(c, ks, gidx, rows, v=None, f=None):
+    assert ks == c["ks"], "budgets differ from the reference"
+    assert gidx.numel() == c["K"]
+    assert gidx[:8].tolist() == c["idx_head"] and gidx[-8:].tolist() == c["idx_tail"]
+    assert synth.sha256_tensor(gidx) == c["idx_sha256"], "kept indices differ from the reference"
+    assert synth.sha256_tensor(rows) == c["out_sha256"]
+    if v is not None:
+        assert synth.sha256_tensor(v) == c["v_sha256"] and synth.sha256_tensor(f) == c["f_sha256"]
+
+
+@pytest.mark.parametrize("c", BIG, ids=_id)
+def test_big_case_unsharded(c):
+    _ffi.set_mode("torch")
+    x = synth.make(c["F"], c["N"], c["D"], DT[c["dtype"]], c["seed"], c["dist"])
+    assert synth.sha256_tensor(x) == c["x_sha256"]
+    got = vc.compress(x.cuda(), c["N"], c["base"], want_scores=True)
+    _check(c, got.ks.cpu().tolist(), got.global_idx.cpu(), got.rows.cpu(), got.v_score.cpu(), got.f_score.cpu())
+
+
+@pytest.mark.parametrize("c", [c for c in BIG if c["name"] == "cfg4"], ids=_id)
+def test_cfg4_frame_sharded_is_world_size_invariant(c):
+    """BASELINE.json configs[3]: 512 frames sharded over 8 GPUs (64 frames each) -- here 8 / 4 / 2 / 1 logical ranks
+    on one GPU through the same HIP stage entry points the RCCL path calls; every world size must reproduce the
+    reference's bits."""
+    from test_sharded import _emulate_ranks_on_one_gpu
+    _ffi.set_mode("torch")
+    F, N, D = c["F"], c["N"], c["D"]
+    x = synth.make(F, N, D, DT[c["dtype"]], c["seed"], c["dist"]).cuda()
+    for P in (8, 4, 2, 1):
+        res, st = _emulate_ranks_on_one_gpu(x, F, N, D, DT[c["dtype"]], c["base"], P, torch.device("cuda:0"))
+        gidx = torch.cat([r.global_idx for r in res]).cpu()
+        ks = torch.cat([r.ks for r in res]).cpu().tolist()
+        rows = torch.cat([r.rows for r in res]).cpu()
+        _check(c, ks, gidx, rows)
+        del res, st
+        torch.cuda.empty_cache()

@@ -72,6 +72,8 @@ def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev):
     Fl = F // P
     shards = [x[p * Fl * N: (p + 1) * Fl * N].contiguous() for p in range(P)]
     st = [HipStages(Fl, N, D, dtype, dev, base) for _ in range(P)]
+    for s_ in st:
+        s_.F_total = F
     stats_all = torch.stack([s.chan_stats(xs).clone() for s, xs in zip(st, shards)])
     for s in st:
         s.select_channels(stats_all, F * N)
@@ -121,3 +123,48 @@ def test_sharded_compressor_single_process():
     r = sc(x)
     w = vc.compress(x, 196, 0.25)
     assert torch.equal(r.global_idx, w.global_idx) and torch.equal(r.ks, w.ks) and torch.equal(r.rows, w.rows)
+
+
+def _gpu_worker(rank, world, port, q):
+    """world_size-2 process group whose ranks share cuda:0 (RCCL refuses two ranks on one device -- 'Duplicate GPU
+    detected' -- so the collectives run on gloo, which stages device tensors through the host): the REAL HIP stages
+    driven by ShardedCompressor through a REAL collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        F, N, D, base = 16, 196, 1024, 0.25
+        dev = torch.device("cuda:0")
+        x = synth.make(F, N, D, torch.bfloat16, 2, "drift")
+        Fl = F // world
+        xl = x[rank * Fl * N: (rank + 1) * Fl * N].contiguous().to(dev)
+        sc = ShardedCompressor(Fl, N, D, torch.bfloat16, dev, base)
+        res = sc(xl)
+        torch.cuda.synchronize()
+        q.put((rank, res.global_idx.cpu().tolist(), res.ks.cpu().tolist(), synth.sha256_tensor(res.rows.cpu())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_processes_one_gpu_hip_stages_and_a_real_collective():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    F, N, D, base = 16, 196, 1024, 0.25
+    x = synth.make(F, N, D, torch.bfloat16, 2, "drift")
+    O.set_mode("torch")
+    ref = O.compress_indices(x, N, base)
+    O.set_mode("exact")
+    assert sum((g[2] for g in got), []) == ref["ks"].tolist()
+    assert sum((g[1] for g in got), []) == ref["global_idx"].tolist()
+    for r, gi, _, sha in got:
+        assert synth.sha256_tensor(x[torch.tensor(gi, dtype=torch.int64)]) == sha

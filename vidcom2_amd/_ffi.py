@@ -37,9 +37,10 @@ _SIGNATURES = {
     "vc2_gather_rows": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "vc2_compress": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
                      _vp, _vp, _vp, _vp],
-    "vc2_chan_stats": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp],
-    "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
-    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp, _vp],
+    "vc2_stat_block_frames": [],
+    "vc2_chan_stats": [_vp, _i64, _i64, _i64, _i32, _i64, _i32, _vp, _sz, _vp, _vp],
+    "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
+    "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp],
     "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp, _vp,
                           _vp, _vp, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
@@ -57,7 +58,7 @@ _SIGNATURES = {
     "vc2_last_error": [],
     "vc2_version": [],
 }
-_RESTYPES = {"vc2_kept_capacity": _i64, "vc2_last_error": ctypes.c_char_p, "vc2_version": ctypes.c_char_p}
+_RESTYPES = {"vc2_kept_capacity": _i64,  "vc2_last_error": ctypes.c_char_p, "vc2_version": ctypes.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

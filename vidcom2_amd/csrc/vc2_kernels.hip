@@ -64,22 +64,31 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // is well conditioned).  The 4 waves combine through LDS; one partial per (row group, column).
 constexpr int kStatsWaves = 4;
 
+// Row groups are CANONICAL: a group is one of `splits` pieces of one frame, the shift K of a group
+// is the first row of its STAT BLOCK (kStatBlockFrames frames), and the groups of a block are added in a fixed order
+// (k_stats_reduce) -- so the per-block (mean, M2) and everything reduced from them are the same bits whether the
+// video is processed whole or frame-sharded over 1, 2, 4 or 8 ranks.
+constexpr int kStatBlockFrames = 8;
+
 template <int DT, int VEC, int U>
 __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __restrict__ x, int64_t R,
-                                                                 int D, int CV, int rows_per_group,
+                                                                 int D, int CV, int N, int splits,
+                                                                 int rows_per_group, int block_frames,
                                                                  double* __restrict__ part) {
   __shared__ double sm[kStatsWaves][2 * VEC][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cv = blockIdx.x * 64 + lane;
   const bool active = cv < CV;
-  const int64_t r0 = int64_t(blockIdx.y) * rows_per_group;
-  const int64_t r1 = min(R, r0 + rows_per_group);
+  const int64_t frame = int64_t(blockIdx.y) / splits;
+  const int64_t r0 = frame * N + int64_t(blockIdx.y % splits) * rows_per_group;
+  const int64_t r1 = min(min(R, (frame + 1) * N), r0 + rows_per_group);
+  const int64_t rK = (frame / block_frames) * block_frames * N;               // the block's first row: the shift
   double s[VEC], q[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) { s[j] = 0.0; q[j] = 0.0; }
   if (active) {
     float kf[VEC];
-    unpack<DT, VEC>(load_raw<DT, VEC>(x, int64_t(cv) * VEC), kf);
+    unpack<DT, VEC>(load_raw<DT, VEC>(x, rK * D + int64_t(cv) * VEC), kf);
     double K[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) K[j] = double(kf[j]);
@@ -124,70 +133,65 @@ __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __r
   }
 }
 
-// Fixed-order reduce of the G row-group partials -> per-rank (mean, M2) in fp64, and (when
-// var_f32 != nullptr, single-rank case) the variance rounded fp64 -> fp32 -> T.
-// Workgroup = 64 columns x 16 partial lanes; lane gl sums partials gl, gl+16, ... then the 16 lane
-// sums are added in lane order (a fixed order: deterministic).
-constexpr int kRedGL = 16;
-
+// Level 1: per stat block b (kStatBlockFrames frames; the last one may be shorter) the fixed-order sum of its
+// groups' partials -> (mean_b, M2_b) in fp64.  bstats[b][2][D].  grid = (ceil(D/64), nb), 64 threads.
 template <int DT>
-__global__ __launch_bounds__(64 * kRedGL) void k_stats_reduce(const double* __restrict__ part, int G,
-                                                              const void* __restrict__ x, int64_t R, int D,
-                                                              double* __restrict__ stats, void* __restrict__ var_T,
-                                                              float* __restrict__ var_f32, int* __restrict__ counters) {
-  __shared__ double sm[2][kRedGL][64];
+__global__ __launch_bounds__(64) void k_block_stats(const double* __restrict__ part, int groups_per_block, int G,
+                                                    const void* __restrict__ x, int64_t R, int D, int N,
+                                                    int block_frames, double* __restrict__ bstats) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (c >= D) return;
+  const int g0 = b * groups_per_block, g1 = min(G, g0 + groups_per_block);
+  double s = 0.0, q = 0.0;
+  for (int g = g0; g < g1; ++g) {
+    s += part[(int64_t(g) * 2 + 0) * D + c];
+    q += part[(int64_t(g) * 2 + 1) * D + c];
+  }
+  const int64_t rK = int64_t(b) * block_frames * N;
+  const double n = double(min<int64_t>(R - rK, int64_t(block_frames) * N));
+  const double K = double(ldT<DT>(x, rK * D + c));
+  double m2 = q - s * s / n;
+  if (m2 < 0.0) m2 = 0.0;
+  bstats[(int64_t(b) * 2 + 0) * D + c] = K + s / n;
+  bstats[(int64_t(b) * 2 + 1) * D + c] = m2;
+}
+
+// Level 2: Chan et al. combination of the NB block statistics (every block n_each rows, the last one n_last), in a
+// FIXED shape -- 16 lanes, lane l folds blocks l, l + 16, ... in order, then the 16 lane aggregates are folded in
+// lane order -- so that the result depends on the blocks only, not on who computed them.
+// var = M2_total / R_total rounded fp64 -> fp32 -> T (vidcom2.py:40).
+constexpr int kRedGL = 16;
+struct ChanAgg { double n, mean, m2; };
+__device__ __forceinline__ void chan_fold(ChanAgg& a, double nb, double mb, double m2b) {
+  if (nb <= 0.0) return;
+  if (a.n <= 0.0) { a.n = nb; a.mean = mb; a.m2 = m2b; return; }
+  const double n = a.n + nb, d = mb - a.mean;
+  a.mean = a.mean + d * (nb / n);
+  a.m2 = a.m2 + m2b + d * d * (a.n * nb / n);
+  a.n = n;
+}
+template <int DT>
+__global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
+                                                                int64_t n_each, int64_t n_last, int D,
+                                                                void* __restrict__ var_T, float* __restrict__ var_f32,
+                                                                int* __restrict__ counters) {
+  __shared__ double sm[3][kRedGL][64];
   if (counters && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // strict-mode queues of this pass
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  double s = 0.0, q = 0.0;
-  if (c < D) {
-    for (int g = gl; g < G; g += kRedGL) {
-      s += part[(int64_t(g) * 2 + 0) * D + c];
-      q += part[(int64_t(g) * 2 + 1) * D + c];
-    }
-  }
-  sm[0][gl][cl] = s;
-  sm[1][gl][cl] = q;
+  ChanAgg a{0.0, 0.0, 0.0};
+  if (c < D)
+    for (int b = gl; b < NB; b += kRedGL)
+      chan_fold(a, double(b == NB - 1 ? n_last : n_each), bstats[(int64_t(b) * 2 + 0) * D + c],
+                bstats[(int64_t(b) * 2 + 1) * D + c]);
+  sm[0][gl][cl] = a.n; sm[1][gl][cl] = a.mean; sm[2][gl][cl] = a.m2;
   __syncthreads();
   if (gl != 0 || c >= D) return;
-  s = 0.0; q = 0.0;
+  ChanAgg t{0.0, 0.0, 0.0};
 #pragma unroll
-  for (int i = 0; i < kRedGL; ++i) { s += sm[0][i][cl]; q += sm[1][i][cl]; }
-  const double K = double(ldT<DT>(x, c));
-  const double n = double(R);
-  const double mean = K + s / n;
-  double m2 = q - s * s / n;
-  if (m2 < 0.0) m2 = 0.0;
-  if (stats) { stats[c] = mean; stats[D + c] = m2; }
-  if (var_f32) {
-    const float v = rnT<DT>(float(m2 / n));
-    var_f32[c] = v;
-    if (var_T) stT<DT>(var_T, c, v);
-  }
-}
-
-// Multi-rank combine (Chan et al.): stats[P][2][D] = per-rank (mean, M2), equal-size ranks are not
-// assumed: counts[p] rows each.  var = M2_total / R_total, rounded fp64 -> fp32 -> T.
-template <int DT>
-__global__ void k_var_from_stats(const double* __restrict__ stats, const int64_t* __restrict__ counts,
-                                 int P, int64_t n_each, int D, void* __restrict__ var_T,
-                                 float* __restrict__ var_f32) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  double ntot = 0.0, msum = 0.0;
-  for (int p = 0; p < P; ++p) {
-    const double n = counts ? double(counts[p]) : double(n_each);
-    ntot += n;
-    msum += n * stats[(int64_t(p) * 2 + 0) * D + c];
-  }
-  const double mean = msum / ntot;
-  double m2 = 0.0;
-  for (int p = 0; p < P; ++p) {
-    const double n = counts ? double(counts[p]) : double(n_each);
-    const double d = stats[(int64_t(p) * 2 + 0) * D + c] - mean;
-    m2 += stats[(int64_t(p) * 2 + 1) * D + c] + n * d * d;
-  }
-  const float v = rnT<DT>(float(m2 / ntot));
+  for (int i = 0; i < kRedGL; ++i) chan_fold(t, sm[0][i][cl], sm[1][i][cl], sm[2][i][cl]);
+  const float v = rnT<DT>(float(t.m2 / t.n));
   if (var_f32) var_f32[c] = v;
   if (var_T) stT<DT>(var_T, c, v);
 }
@@ -1711,16 +1715,18 @@ constexpr int64_t kMaxFramesTotal = 65536;   // frames of the WHOLE video in the
 struct Plan {
   int64_t F, N, D, R;
   int dt, ES, VEC, CV, TPB;     // VEC actually used (1 = scalar fallback), column vectors, threads
-  int G, rows_per_group;        // sweep-1 row groups
+  int G, rows_per_group;        // sweep-1 row groups (G = F * stat_splits), stat blocks
+  int stat_splits, NB, BF;      // groups per frame; stat blocks of BF (<= kStatBlockFrames) frames
+  int64_t F_total;              // frames of the WHOLE video (frame-sharded pass: canonical blockings depend on it)
   int S, rows_per_split;        // sweep-2 splits per frame
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
-  size_t o_part_stats, o_stats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
+  size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
       o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_cfixlist, o_vfixlist, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
   int cfix_cap, vstride;
 };
 
-int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
+int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total = 0, int block_frames = 0) {
   if (F <= 0 || N <= 0 || D <= 0) return fail(VC2_ERR_ARG, "F, N, D must be positive (got %lld, %lld, %lld)",
                                               (long long)F, (long long)N, (long long)D);
   if (dt < 0 || dt > 2) return fail(VC2_ERR_ARG, "unknown dtype code %d", dt);
@@ -1733,11 +1739,16 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
     return fail(VC2_ERR_UNSUPPORTED, "D=%lld needs %d column vectors per row; at most 1024 are supported "
                 "(D <= 8192 for 16-bit, <= 4096 for fp32, D %% %d == 0)", (long long)D, p->CV, full);
   p->TPB = int(cdiv(p->CV, 64) * 64);
-  const int64_t slabs = cdiv(p->CV, 64);
-  int64_t g = std::max<int64_t>(1, std::min<int64_t>(128, cdiv(640, slabs)));
-  p->rows_per_group = int(std::max<int64_t>(cdiv(p->R, g), 32));
-  p->G = int(cdiv(p->R, p->rows_per_group));
-  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, cdiv(512, F)));
+  p->F_total = F_total > 0 ? F_total : F;
+  // sweep-1 groups: `stat_splits` pieces per frame -- a function of the WHOLE video's frame count, so that every
+  // rank of a frame-sharded pass cuts its frames exactly like the unsharded pass does
+  p->stat_splits = int(std::max<int64_t>(1, std::min<int64_t>(cdiv(128, p->F_total), std::max<int64_t>(1, N / 32))));
+  p->rows_per_group = int(cdiv(N, p->stat_splits));
+  p->stat_splits = int(cdiv(N, p->rows_per_group));
+  p->G = int(F * p->stat_splits);
+  p->BF = block_frames > 0 ? std::min(block_frames, kStatBlockFrames) : kStatBlockFrames;
+  p->NB = int(cdiv(F, p->BF));
+  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, cdiv(512, p->F_total)));
   p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), std::min<int64_t>(N, 8 * kRowWaves)));
   p->S = int(cdiv(N, p->rows_per_split));
   {
@@ -1752,6 +1763,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p) {
   auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
   p->o_part_stats = take(size_t(p->G) * 2 * D * 8);
   p->o_stats = take(size_t(2) * D * 8);
+  p->o_bstats = take(size_t(F) * 2 * D * 8);                  // (room for blocks of one frame)
   p->o_var_f32 = take(size_t(D) * 4);
   p->o_var_T = take(size_t(D) * 4);
   p->o_mask = take(size_t(D));
@@ -1840,17 +1852,27 @@ int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
 }
 
 // sweep 1 -> (mean, M2) stats and/or var
-int launch_chan_stats(const Plan& p, const void* x, void* ws, double* stats, void* var_T, float* var_f32,
+// sweep 1 -> per stat block (mean, M2) in bstats[NB][2][D] (ws when bstats == nullptr), and -- var_f32 / var_T --
+// the variance of THESE rows reduced from them (single-rank case)
+int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, void* var_T, float* var_f32,
                       hipStream_t st, bool zero_queue_counters = false) {
   double* part = wsp<double>(ws, p.o_part_stats);
+  double* bs = bstats ? bstats : wsp<double>(ws, p.o_bstats);
+  if (p.G > 65535) return fail(VC2_ERR_UNSUPPORTED, "too many sweep-1 row groups (%d)", p.G);
   dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
   { ProfScope ps_(KID_STATS, st);
   VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8>), grid, dim3(kStatsWaves * 64), 0, st, x,
-                                          p.R, int(p.D), p.CV, p.rows_per_group, part)); }
+                                          p.R, int(p.D), p.CV, int(p.N), p.stat_splits, p.rows_per_group, p.BF, part)); }
   { ProfScope ps_(KID_STATS_REDUCE, st);
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_stats_reduce<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
-                                           0, st, part, p.G, x, p.R, int(p.D), stats, var_T, var_f32,
-                                           zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr)); }
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_block_stats<DT>), dim3(unsigned(cdiv(p.D, 64)), unsigned(p.NB)), dim3(64),
+                                           0, st, part, p.BF * p.stat_splits, p.G, x, p.R, int(p.D),
+                                           int(p.N), p.BF, bs));
+  if (var_f32 || var_T) {
+    const int64_t n_each = int64_t(p.BF) * p.N, n_last = p.R - int64_t(p.NB - 1) * n_each;
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
+                                             0, st, bs, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
+                                             zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr));
+  } }
   return check_launch("chan_stats");
 }
 
@@ -2140,23 +2162,28 @@ int64_t vc2_kept_capacity(int64_t F, int64_t N, double base_scale) {
   return int64_t(cap < full ? cap : full);
 }
 
-int vc2_chan_stats(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_t ws_bytes, double* stats,
-                   void* stream) {
-  if (!x || !stats) return fail(VC2_ERR_ARG, "null pointer");
+int vc2_stat_block_frames(void) { return kStatBlockFrames; }
+
+int vc2_chan_stats(const void* x, int64_t F, int64_t N, int64_t D, int dtype, int64_t F_total, int block_frames,
+                   void* ws, size_t ws_bytes, double* bstats, void* stream) {
+  if (!x || !bstats) return fail(VC2_ERR_ARG, "null pointer");
+  if (block_frames < 1 || block_frames > kStatBlockFrames) return fail(VC2_ERR_ARG, "block_frames must be 1..%d", kStatBlockFrames);
   Plan p;
-  int rc = make_plan(1, R, D, dtype, &p);   // stats do not depend on the frame structure
+  int rc = make_plan(F, N, D, dtype, &p, F_total, block_frames);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
-  return launch_chan_stats(p, x, ws, stats, nullptr, nullptr, static_cast<hipStream_t>(stream));
+  return launch_chan_stats(p, x, ws, bstats, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
-int vc2_chan_var_from_stats(const double* stats, int64_t P, int64_t R_total, int64_t D, int dtype, void* var_T,
-                            float* var_f32, void* stream) {
-  if (!stats || P <= 0 || D <= 0 || R_total <= 0 || R_total % P) return fail(VC2_ERR_ARG, "bad stats arguments");
+int vc2_chan_var_from_stats(const double* bstats, int64_t NB, int64_t rows_per_block, int64_t R_total, int64_t D,
+                            int dtype, void* var_T, float* var_f32, void* stream) {
+  if (!bstats || NB <= 0 || D <= 0 || R_total <= 0 || rows_per_block <= 0 || (NB - 1) * rows_per_block >= R_total ||
+      NB * rows_per_block < R_total)
+    return fail(VC2_ERR_ARG, "bad stats arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(D, 128))), dim3(128), 0, st,
-                                            stats, (const int64_t*)nullptr, int(P), R_total / P, int(D), var_T,
-                                            var_f32));
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(D, 64))), dim3(64 * kRedGL), 0, st,
+                                            bstats, int(NB), rows_per_block, R_total - (NB - 1) * rows_per_block, int(D),
+                                            var_T, var_f32, (int*)nullptr));
   return check_launch("var_from_stats");
 }
 
@@ -2164,7 +2191,7 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
                  float* var_f32, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
   Plan p;
-  int rc = make_plan(1, R, D, dtype, &p);
+  int rc = make_plan(1, R, D, dtype, &p);   // the variance does not depend on the frame structure
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   float* vf = var_f32 ? var_f32 : wsp<float>(ws, p.o_var_f32);
@@ -2208,13 +2235,13 @@ static int check_cols(const int32_t* cols, int64_t C, int64_t D) {
 }
 
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      int32_t* spos, const int32_t* perm, const float* var_f32, void* ws, size_t ws_bytes,
-                      double* csum, void* stream) {
+                      int32_t* spos, const int32_t* perm, const float* var_f32, int64_t F_total, void* ws,
+                      size_t ws_bytes, double* csum_parts, void* stream) {
   if (!x) return fail(VC2_ERR_ARG, "x is null");
   if (perm && !(var_f32 && cols && spos)) return fail(VC2_ERR_ARG, "the ORDER rider needs perm, var_f32, cols and spos");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
-  int rc = make_plan(F, N, D, dtype, &p);
+  int rc = make_plan(F, N, D, dtype, &p, F_total);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2225,8 +2252,9 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
     rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C)};
   rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider);
   if (rc) return rc;
-  if (csum) {
-    hipError_t e = hipMemcpyAsync(csum, wsp<double>(ws, p.o_csum), size_t(C) * 8, hipMemcpyDeviceToDevice, st);
+  if (csum_parts) {       // the fp64 sums of x^ per group of kCentreFL frames, in frame order: [ceil(F/16)][C]
+    hipError_t e = hipMemcpyAsync(csum_parts, wsp<double>(ws, p.o_csum_part), size_t(cdiv(F, kCentreFL)) * size_t(C) * 8,
+                                  hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "csum copy: %s", hipGetErrorString(e));
   }
   return VC2_OK;
@@ -2239,7 +2267,7 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if (!x || !csum_all || P <= 0 || csum_stride < C) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
-  int rc = make_plan(F, N, D, dtype, &p);
+  int rc = make_plan(F, N, D, dtype, &p, R_total / N);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2381,7 +2409,7 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
                 (long long)F_total);
   if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
   Plan p;
-  int rc = make_plan(F_local, N, D, dtype, &p);
+  int rc = make_plan(F_local, N, D, dtype, &p, F_total);
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);

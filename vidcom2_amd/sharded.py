@@ -4,10 +4,11 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank 
 [p*F_local, (p+1)*F_local) of ONE video.  The pass shards by frame with three tiny exchange steps --
 every message is <= a few hundred KB, i.e. latency-bound, so each is a single all-gather followed by
 a fixed-order local reduction (NOT an all-reduce: the fixed order makes every rank compute the same
-bits, and the same bits for every world size up to fp64 rounding of the partial sums):
+bits; the partials are CANONICAL -- cut at fixed frame boundaries and folded in one fixed order -- so the bits are also
+the same for every world size, and the same as the unsharded pass's, when each rank holds a multiple of 16 frames):
 
-  after sweep 1   per-rank channel statistics (mean, M2)  fp64 [2, D]   -> identical channel mask
-  after sweep 2   per-rank sums of normalised tokens       fp64 [D]      -> identical video centre
+  after sweep 1   per 8-frame block statistics (mean, M2)  fp64 [F_l/8, 2, D] -> identical channel mask
+  after sweep 2   per 16-frame sums of normalised tokens   fp64 [F_l/16, C]   -> identical video centre
   after sweep 3   per-frame uniqueness scores  -mean(v)    fp32 [F_local] -> global softmax budgets
                   (the RCCL all-gather BASELINE.json's north_star names)
 
@@ -47,11 +48,16 @@ class HipStages:
         self.code = DTYPE_CODE[dtype]
         L = lib()
         self.ws = _ffi.workspace(F, N, D, dtype, self.device)
-        self.stats = torch.empty((2, D), dtype=torch.float64, device=self.device)
-        self.csum = torch.zeros(D, dtype=torch.float64, device=self.device)   # first C entries are used
+        # canonical partials: per stat block of `bf` frames (mean, M2); per group of 16 frames the
+        # sums of the normalised tokens.  bf = 8 whenever F is a multiple of 8 (then the gathered blocks are exactly
+        # the unsharded pass's blocks and every world size reduces to the same bits)
+        self.bf = next(b for b in (8, 4, 2, 1) if F % b == 0)
+        self.stats = torch.empty((F // self.bf, 2, D), dtype=torch.float64, device=self.device)
+        self.C = int(D * 0.5)                                   # int(x.shape[-1] * ratio), vidcom2.py:41
+        self.csum = torch.zeros(((F + 15) // 16, self.C), dtype=torch.float64, device=self.device)
+        self.F_total = F                                        # set by ShardedCompressor (world * F)
         self.var_f32 = torch.empty(D, dtype=torch.float32, device=self.device)
         self.mask = torch.empty(D, dtype=torch.uint8, device=self.device)
-        self.C = int(D * 0.5)                                   # int(x.shape[-1] * ratio), vidcom2.py:41
         self.cols = torch.empty(D, dtype=torch.int32, device=self.device)
         self.perm = torch.empty(D, dtype=torch.int32, device=self.device)     # channels as nth_element left them
         self.spos = torch.empty(D, dtype=torch.int32, device=self.device)     # their positions in that order
@@ -76,15 +82,15 @@ class HipStages:
 
     def chan_stats(self, x):
         p = self._p
-        check(self._L.vc2_chan_stats(ptr(x), self.F * self.N, self.D, self.code, p["ws"], self._ws_n, p["stats"],
-                                     self._st()), "vc2_chan_stats")
+        check(self._L.vc2_chan_stats(ptr(x), self.F, self.N, self.D, self.code, self.F_total, self.bf, p["ws"],
+                                     self._ws_n, p["stats"], self._st()), "vc2_chan_stats")
         return self.stats
 
     def select_channels(self, stats_all, R_total):
         p, st = self._p, self._st()
-        P = stats_all.shape[0]
-        check(self._L.vc2_chan_var_from_stats(ptr(stats_all), P, R_total, self.D, self.code, None, p["var_f32"], st),
-              "vc2_chan_var_from_stats")
+        blocks = stats_all.reshape(-1, 2, self.D)               # [world * nb, 2, D], rank order = frame order
+        check(self._L.vc2_chan_var_from_stats(ptr(blocks), blocks.shape[0], self.bf * self.N, R_total, self.D, self.code,
+                                              None, p["var_f32"], st), "vc2_chan_var_from_stats")
         # the channel SET now; torch.topk's channel ORDER (needed only by the fix-up kernels of phase 1) is
         # replayed from `perm` by a rider workgroup of sweep 2 inside vc2_scores_phase1
         check(self._L.vc2_chan_select(p["var_f32"], self.D, self.C, p["mask"], p["cols"], p["perm"], None, None, None,
@@ -93,14 +99,16 @@ class HipStages:
     def phase1(self, x):
         p = self._p
         check(self._L.vc2_scores_phase1(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
-                                        p["perm"], p["var_f32"], p["ws"], self._ws_n, p["csum"], self._st()),
+                                        p["perm"], p["var_f32"], self.F_total, p["ws"], self._ws_n, p["csum"],
+                                        self._st()),
               "vc2_scores_phase1")
         return self.csum
 
     def phase2(self, x, csum_all, R_total):
         p = self._p
+        parts = csum_all.reshape(-1, csum_all.shape[-1])       # [world * groups, C], rank order = frame order
         check(self._L.vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
-                                        ptr(csum_all), csum_all.shape[0], csum_all.shape[1], R_total, p["ws"],
+                                        ptr(parts), parts.shape[0], parts.shape[1], R_total, p["ws"],
                                         self._ws_n, None, None, p["total"], p["s"], self._st()), "vc2_scores_phase2")
         return self.s
 
@@ -143,6 +151,8 @@ class ShardedCompressor:
         self.f0 = self.rank * self.F
         self.stages = stages if stages is not None else HipStages(self.F, self.N, self.D, dtype, device, base_scale,
                                                                   gather)
+        if isinstance(self.stages, HipStages):
+            self.stages.F_total = self.F_total
 
         self._gbuf = {}
 
