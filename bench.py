@@ -12,17 +12,20 @@ every run before timing).
 N = 1 : workload "target" = 128 frames x 196 tokens x 3584-d bf16, 25 % retain (the shape
         BASELINE.json's north-star target is quoted on); cfg2 (32x196x3584) is reported beside it.
 N > 1 : weak scaling -- every rank holds 128 frames of ONE long video of 128*N frames, frame-sharded
-        with three small RCCL all-gathers (channel stats, centre sums, per-frame uniqueness scores).
+        with three small RCCL all-gathers (stat blocks, centre sums, per-frame uniqueness scores).
 
-One JSON line on rank 0 (see the repo prompt for the contract), with two extra objects:
-  "roofline"     the dominant kernel's achieved algorithmic HBM rate (hipEvent-timed inside this run)
-  "cpu_baseline" the CPU oracle ("port") timed on this box's host cores on a bounded sample
+One JSON line on rank 0 (see the repo prompt for the contract), with extra objects:
+  "roofline"      the dominant kernel's achieved algorithmic HBM rate (hipEvent-timed inside this run)
+  "roofline_big"  the same for a > 256 MiB working set (cfg3), where the Infinity Cache cannot hold X
+  "cpu_baseline"  the reference CPU path on this box's host cores: kind "torch-restatement" (the same aten ops,
+                  oracle/torch_restatement.py) and, in "port", the C++/OpenMP oracle
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,6 +35,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+MALL_BYTES = 256 << 20    # Infinity Cache
 
 WORKLOADS = {
     # name: (F, N, D, dtype, base_scale)
@@ -56,7 +60,7 @@ def kernel_alg_bytes(name, F, N, D, es, K):
     return {
         "k_chan_stats": X,                       # sweep 1: read X once
         "k_norm_colsum": X + 4 * F * N,          # sweep 2: read X, write den
-        "k_dist": X + 12 * F * N,                # sweep 3: read X + den, write two distances
+        "k_dist": X + 12 * F * N,                # sweep 3: read X + den, write scores
         "k_gather_rows": 2 * K * D * es + 8 * K,  # read K rows + indices, write K rows
     }.get(name)
 
@@ -93,11 +97,39 @@ def time_steps(fn, steps, dist_on):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(x_cpu, N, base, budget_s=12.0):
-    """The CPU oracle (kind 'port': C++/OpenMP restatement of vidcom2.py, proven equal to the imported
-    reference on the golden fixtures) timed on this box's host cores on the same workload."""
+def median_step_ms(fn, steps):
+    """Median over `steps` individually event-timed passes (SURVEY.md §8d asks for the median; the contract's
+    ms_per_step above is the mean of the K-step block)."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return statistics.median(a.elapsed_time(b) for a, b in ev)
+
+
+def cpu_baselines(x_cpu, N, base, budget_s=10.0):
+    """The reference CPU path on this box's host cores, two ways, on full passes of the same workload:
+    'torch-restatement' -- the same aten ops in the same order (oracle/torch_restatement.py, pinned bit-exact against
+    the reference's fixtures) with torch's own threading; 'port' -- the C++/OpenMP oracle (oracle/vc2_oracle.cpp)."""
     import oracle
+    from oracle import torch_restatement as T
     cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    T.compress(x_cpu[: 8 * N], N, base)                 # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        rt = T.compress(x_cpu, N, base)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 10:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    out = {"value": x_cpu.shape[0] / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "torch-restatement",
+           "sample": f"{reps} full passes of the same workload ({x_cpu.shape[0]} tokens each), {dt * 1e3:.1f} ms/pass, "
+                     "torch CPU ops in the reference's order"}
     oracle.set_num_threads(cores)
     oracle.set_mode("torch")             # same semantics as the HIP path's default mode
     oracle.compress_indices(x_cpu[: 8 * N], N, base)   # warm (library load, page-in)
@@ -107,11 +139,42 @@ def cpu_baseline(x_cpu, N, base, budget_s=12.0):
         o = oracle.compress_indices(x_cpu, N, base)
         _ = x_cpu[o["global_idx"]]
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 20:
+        if time.perf_counter() - t0 > budget_s or reps >= 10:
             break
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": x_cpu.shape[0] / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} full passes of the same workload ({x_cpu.shape[0]} tokens each), {dt * 1e3:.1f} ms/pass"}, o
+    dt2 = (time.perf_counter() - t0) / reps
+    out["port"] = {"value": x_cpu.shape[0] / dt2, "unit": "tokens/s", "cores": cores, "kind": "port",
+                   "sample": f"{reps} full passes, {dt2 * 1e3:.1f} ms/pass, C++/OpenMP oracle in 'torch order' mode"}
+    # the two CPU statements and the reference agree: same kept indices
+    assert rt["ks"] == o["ks"].tolist() and torch.equal(rt["global_idx"], o["global_idx"]), "CPU baselines disagree"
+    return out, o
+
+
+def kernel_profile(step, steps, _ffi):
+    """us per launch of every kernel, hipEvents around each launch (the ORDER replay runs as its own kernel here)."""
+    _ffi.profile_enable(True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    prof = _ffi.profile_collect()
+    _ffi.profile_enable(False)
+    return {name: round(tot / cnt * 1e3, 2) for name, (tot, cnt) in prof.items()}
+
+
+def roofline_of(kern, F, N, D, es, K, workload, world):
+    sweeps = {n: kern[n] for n in ("k_chan_stats", "k_norm_colsum", "k_dist", "k_gather_rows") if n in kern}
+    if not sweeps:
+        return None
+    dom = max(sweeps, key=sweeps.get)
+    ab = kernel_alg_bytes(dom, F, N, D, es, K)
+    ach = ab / (sweeps[dom] * 1e-6) / 1e9
+    X = F * N * D * es
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, workload, world),
+            "alg_bytes_per_launch": ab, "avg_us": sweeps[dom],
+            "x_bytes": X, "x_fits_infinity_cache": bool(X < MALL_BYTES),
+            "note": ("X (%d MB) fits the 256 MiB Infinity Cache: sweeps 2-3 re-read it from there, so 'achieved' is an "
+                     "algorithmic rate that may exceed what HBM alone delivers" % (X >> 20)) if X < MALL_BYTES else
+                    ("X (%d MB) exceeds the 256 MiB Infinity Cache: every sweep streams from HBM" % (X >> 20))}
 
 
 def main():
@@ -121,7 +184,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the cfg2 side measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,8 +201,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        # lazy communicator creation on purpose: with `device_id=` (eager init) every pass that uses the library's
-        # side stream measured ~45 us slower on this stack (323 vs 278 us), with it the numbers match a plain process
+        # lazy communicator creation on purpose: with `device_id=` (eager init) every pass measured ~45 us slower on
+        # this stack in round 1; with it the numbers match a plain process
         torch.distributed.init_process_group("nccl")
 
     import vidcom2_amd as vc
@@ -170,12 +233,12 @@ def main():
         step = lambda: sc.enqueue(x)            # noqa: E731
         finish = sc.finish
 
-    # ---- parity gate: kept indices + budgets must equal the oracle's before anything is timed ------
+    # ---- parity gate: kept indices + budgets must equal the CPU reference path's before anything is timed ------
     cpu = None
     step()
     res = finish()
     if not dist_on and not args.no_cpu_baseline:
-        cpu, ref = cpu_baseline(x_cpu, N, base)
+        cpu, ref = cpu_baselines(x_cpu, N, base)
         ok = res.ks.cpu().tolist() == ref["ks"].tolist() and torch.equal(res.global_idx.cpu(), ref["global_idx"])
         if not ok:
             raise SystemExit("[bench] PARITY FAILURE: kept indices / budgets differ from the oracle")
@@ -193,24 +256,8 @@ def main():
     tokens_per_s = F_total * N / (elapsed / args.steps)
 
     # ---- roofline leg: same steps again with hipEvents around every kernel --------------------------
-    roof = None
-    kern = {}
-    _ffi.profile_enable(True)
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    prof = _ffi.profile_collect()
-    _ffi.profile_enable(False)
-    for name, (tot, cnt) in prof.items():
-        kern[name] = round(tot / cnt * 1e3, 2)          # us per launch
-    sweeps = {n: kern[n] for n in ("k_chan_stats", "k_norm_colsum", "k_dist", "k_gather_rows") if n in kern}
-    if sweeps:
-        dom = max(sweeps, key=sweeps.get)
-        ab = kernel_alg_bytes(dom, F, N, D, es, K)
-        ach = ab / (sweeps[dom] * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload, world),
-                "alg_bytes_per_launch": ab, "avg_us": sweeps[dom]}
+    kern = kernel_profile(step, args.steps, _ffi)
+    roof = roofline_of(kern, F, N, D, es, K, args.workload, world)
 
     out = {
         "metric": "video-tokens compressed/sec at 25% retain; kept-index bit-exact vs ref",
@@ -227,11 +274,44 @@ def main():
                           "frac_of_8TBs_per_gpu": round(alg_bytes_pass(F, N, D, es, base) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels_us": kern,
     }
-
     out["mode"] = _ffi.get_mode() + (" (bit-exact to the CPU reference: boundary-fragile tokens replay torch's fp32 "
                                      "accumulation order)" if _ffi.get_mode() == "torch" else "")
-    # ---- side measurement: the same pass with plain correctly-rounded reductions ("exact" mode) ---------
-    if not dist_on and not args.no_extra and dtype != torch.float32:
+    if not dist_on:
+        out["median_ms_per_step"] = round(median_step_ms(step, max(args.steps, 20)), 4)
+
+    extra = not dist_on and not args.no_extra
+    # ---- side: the pass replayed from a hipGraph (serving loops capture it once) ------------------------
+    if extra:
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                step()
+            for _ in range(args.warmup):
+                g.replay()
+            eg = time_steps(g.replay, args.steps, False)
+            out["hipgraph_replay"] = {"ms_per_step": round(eg / args.steps * 1e3, 4),
+                                      "tokens_per_s": round(F * N / (eg / args.steps), 1)}
+        except Exception as e:  # noqa: BLE001
+            out["hipgraph_replay"] = {"error": repr(e)[:200]}
+    # ---- side: one-shot call latency = the plugin API as the hooks call it (allocation + enqueue + the single
+    #      host sync + slicing), median of 20 ---------------------------------------------------------------
+    if extra:
+        lat = []
+        for _ in range(25):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = vc.vidcom2_compression(x, model="qwen2_5_vl", base_scale=base, frame_token_len=N)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e6)
+            del r
+        out["one_shot_call_us"] = round(statistics.median(lat[5:]), 1)
+    # ---- side: the same pass with plain correctly-rounded reductions ("exact" mode) ---------------------
+    if extra and dtype != torch.float32:
         _ffi.set_mode("exact")
         for _ in range(args.warmup):
             step()
@@ -240,8 +320,8 @@ def main():
         out["exact_mode"] = {"ms_per_step": round(e3 / args.steps * 1e3, 4),
                              "tokens_per_s": round(F * N / (e3 / args.steps), 1),
                              "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / (e3 / args.steps) / 1e9, 1)}
-    # ---- side measurement: cfg2 (LLaVA-OV shape) on one GPU -----------------------------------------
-    if not dist_on and not args.no_extra and args.workload == "target":
+    # ---- side: cfg2 (LLaVA-OV shape) on one GPU ------------------------------------------------------
+    if extra and args.workload == "target":
         F2, N2, D2, dt2, b2 = WORKLOADS["cfg2"]
         x2 = x[: F2 * N2]                       # first 32 frames of the same tensor
         p2 = vc.vidcom2.CompressPlan(F2, N2, D2, dt2, dev, b2)
@@ -249,14 +329,43 @@ def main():
             p2.enqueue(x2)
         e2 = time_steps(lambda: p2.enqueue(x2), args.steps, False)
         out["cfg2"] = {"workload": "32x196x3584 bf16 retain 0.25", "ms_per_step": round(e2 / args.steps * 1e3, 4),
+                       "median_ms_per_step": round(median_step_ms(lambda: p2.enqueue(x2), max(args.steps, 20)), 4),
                        "tokens_per_s": round(F2 * N2 / (e2 / args.steps), 1),
                        "pass_alg_GBs": round(alg_bytes_pass(F2, N2, D2, 2, b2) / (e2 / args.steps) / 1e9, 1)}
-
-    # ---- side measurement: two clips in flight, one stream each (serving / batched eval) --------------
-    # The single-workgroup selection replays leave the GPU mostly idle; a second clip on its own stream fills it.
-    if not dist_on and not args.no_extra and args.workload == "target":
-        # (the current stream plus ONE new one: each brings an internal side stream, and four streams is what the
-        # default four hardware queues run without multiplexing)
+    # ---- side: cfg3 (Qwen2.5-VL shape) ---------------------------------------------------------------
+    if extra and args.workload == "target":
+        F3, N3, D3, dt3, b3 = WORKLOADS["cfg3"]
+        x3 = synth.make(F3, N3, D3, dt3, seed=0, dist="drift").to(dev)
+        p3 = vc.vidcom2.CompressPlan(F3, N3, D3, dt3, dev, b3)
+        for _ in range(args.warmup):
+            p3.enqueue(x3)
+        e3 = time_steps(lambda: p3.enqueue(x3), args.steps, False)
+        out["cfg3"] = {"workload": "64x324x3584 bf16 retain 0.125", "ms_per_step": round(e3 / args.steps * 1e3, 4),
+                       "tokens_per_s": round(F3 * N3 / (e3 / args.steps), 1),
+                       "pass_alg_GBs": round(alg_bytes_pass(F3, N3, D3, 2, b3) / (e3 / args.steps) / 1e9, 1)}
+        del x3, p3
+    # ---- side: a working set beyond the 256 MiB Infinity Cache: 512 frames x 196 x 3584 bf16 = 360 MB of X (the
+    #      long-video config on ONE GPU; N(0,1) data made on the device -- a timing leg, parity is tested elsewhere)
+    if extra and args.workload == "target":
+        Fb = 512
+        xb = torch.randn(Fb * N, D, device=dev, dtype=torch.float32).to(dtype)
+        pb = vc.vidcom2.CompressPlan(Fb, N, D, dtype, dev, base)
+        pb.enqueue(xb)
+        Kb = pb.finish().K
+        for _ in range(5):
+            pb.enqueue(xb)
+        nb = max(10, args.steps // 2)
+        eb = time_steps(lambda: pb.enqueue(xb), nb, False)
+        kb = kernel_profile(lambda: pb.enqueue(xb), nb, _ffi)
+        out["roofline_big"] = roofline_of(kb, Fb, N, D, es, Kb, "long512", 1)
+        out["long512"] = {"workload": f"512x{N}x{D} {DT_NAME[dtype]} retain {base}, one GPU", "ms_per_step": round(eb / nb * 1e3, 4),
+                          "tokens_per_s": round(Fb * N / (eb / nb), 1),
+                          "pass_alg_GBs": round(alg_bytes_pass(Fb, N, D, es, base) / (eb / nb) / 1e9, 1),
+                          "pass_frac_of_8TBs": round(alg_bytes_pass(Fb, N, D, es, base) / (eb / nb) / 1e9 / HBM_PEAK_GBS, 4),
+                          "kernels_us": kb}
+        del xb, pb
+    # ---- side: two clips in flight, one stream each (serving / batched eval) --------------------------
+    if extra and args.workload == "target":
         streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
         plans = [plan, vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base)]
 

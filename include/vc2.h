@@ -169,7 +169,9 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
 
 /* Step 3 of the sharded path: s_all_f32[F_total] = the all-gathered per-frame uniqueness scores
  * (fp32-widened T values); budgets are computed over all F_total frames, selection + gather only for
- * this rank's frames [f0, f0+F_local).  idx_out holds LOCAL linear indices (f_local*N + n). */
+ * this rank's frames [f0, f0+F_local).  idx_out holds LOCAL linear indices (f_local*N + n).  K_out is int64[3] here:
+ * K_out[2] = the number of video-centre values within the replay margin of a T rounding boundary, which this path
+ * leaves at the exactly rounded mean (mode 1; the unsharded pass replays torch's summation order for them). */
 int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F_total, int64_t f0,
                        int64_t F_local, int64_t N, int64_t D, double base_scale, int dtype, void* ws,
                        size_t ws_bytes, int64_t* ks, int64_t* idx_out, int64_t cap, int64_t* K_out,

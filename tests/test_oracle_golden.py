@@ -138,3 +138,16 @@ def test_mappers_and_errors():
     img = synth.make(v["F"], v["h"] * (v["h"] + 1), v["D"], DT[v["dtype"]], v["img_seed"], "iid")
     out = O.vidcom2_compression(flat, model="llava_vid", base_scale=v["base"], img_feat=img)
     assert list(out.shape) == v["shape"] and synth.sha256_tensor(out) == v["out_sha256"]
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c["F"] * c["N"] * c["D"] <= 16 * 196 * 3584], ids=case_id)
+def test_torch_restatement_equals_reference(c):
+    """oracle/torch_restatement.py (the 'reference CPU path' leg of bench.py: the same aten ops in the same order,
+    restated from the algorithm) reproduces the reference's fixtures bit for bit -- every dtype, fp32 included."""
+    from oracle import torch_restatement as T
+    x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
+    r = T.compress(x, c["N"], c["base"])
+    assert r["chan_idx"].tolist() == c["chan_idx"] and r["ks"] == c["ks"]
+    assert r["global_idx"].tolist() == c["global_idx"]
+    assert synth.sha256_tensor(r["v"]) == c["v_sha256"] and synth.sha256_tensor(r["f"]) == c["f_sha256"]
+    assert synth.sha256_tensor(r["rows"]) == c["out_sha256"]

@@ -135,25 +135,32 @@ __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __r
 
 // Level 1: per stat block b (kStatBlockFrames frames; the last one may be shorter) the fixed-order sum of its
 // groups' partials -> (mean_b, M2_b) in fp64.  bstats[b][2][D].  grid = (ceil(D/64), nb), 64 threads.
+struct PartSrc {           // where the sweep-1 partials of a rank live (null part: none)
+  const double* part; const void* x; int64_t R; int groups_per_block; int G; int N; int block_frames;
+};
 template <int DT>
-__global__ __launch_bounds__(64) void k_block_stats(const double* __restrict__ part, int groups_per_block, int G,
-                                                    const void* __restrict__ x, int64_t R, int D, int N,
-                                                    int block_frames, double* __restrict__ bstats) {
+__device__ __forceinline__ void block_stat(const PartSrc& ps, int b, int c, int D, double& mean, double& m2) {
+  const int g0 = b * ps.groups_per_block, g1 = min(ps.G, g0 + ps.groups_per_block);
+  double s = 0.0, q = 0.0;
+  for (int g = g0; g < g1; ++g) {
+    s += ps.part[(int64_t(g) * 2 + 0) * D + c];
+    q += ps.part[(int64_t(g) * 2 + 1) * D + c];
+  }
+  const int64_t rK = int64_t(b) * ps.block_frames * ps.N;
+  const double n = double(min<int64_t>(ps.R - rK, int64_t(ps.block_frames) * ps.N));
+  const double K = double(ldT<DT>(ps.x, rK * D + c));
+  m2 = q - s * s / n;
+  if (m2 < 0.0) m2 = 0.0;
+  mean = K + s / n;
+}
+template <int DT>
+__global__ __launch_bounds__(64) void k_block_stats(PartSrc ps, int D, double* __restrict__ bstats) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   const int b = blockIdx.y;
   if (c >= D) return;
-  const int g0 = b * groups_per_block, g1 = min(G, g0 + groups_per_block);
-  double s = 0.0, q = 0.0;
-  for (int g = g0; g < g1; ++g) {
-    s += part[(int64_t(g) * 2 + 0) * D + c];
-    q += part[(int64_t(g) * 2 + 1) * D + c];
-  }
-  const int64_t rK = int64_t(b) * block_frames * N;
-  const double n = double(min<int64_t>(R - rK, int64_t(block_frames) * N));
-  const double K = double(ldT<DT>(x, rK * D + c));
-  double m2 = q - s * s / n;
-  if (m2 < 0.0) m2 = 0.0;
-  bstats[(int64_t(b) * 2 + 0) * D + c] = K + s / n;
+  double mean, m2;
+  block_stat<DT>(ps, b, c, D, mean, m2);
+  bstats[(int64_t(b) * 2 + 0) * D + c] = mean;
   bstats[(int64_t(b) * 2 + 1) * D + c] = m2;
 }
 
@@ -175,16 +182,21 @@ template <int DT>
 __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
                                                                 int64_t n_each, int64_t n_last, int D,
                                                                 void* __restrict__ var_T, float* __restrict__ var_f32,
-                                                                int* __restrict__ counters) {
+                                                                int* __restrict__ counters, PartSrc ps) {
+  // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
+  // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
   __shared__ double sm[3][kRedGL][64];
   if (counters && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // strict-mode queues of this pass
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   ChanAgg a{0.0, 0.0, 0.0};
   if (c < D)
-    for (int b = gl; b < NB; b += kRedGL)
-      chan_fold(a, double(b == NB - 1 ? n_last : n_each), bstats[(int64_t(b) * 2 + 0) * D + c],
-                bstats[(int64_t(b) * 2 + 1) * D + c]);
+    for (int b = gl; b < NB; b += kRedGL) {
+      double mb, m2b;
+      if (ps.part) block_stat<DT>(ps, b, c, D, mb, m2b);
+      else { mb = bstats[(int64_t(b) * 2 + 0) * D + c]; m2b = bstats[(int64_t(b) * 2 + 1) * D + c]; }
+      chan_fold(a, double(b == NB - 1 ? n_last : n_each), mb, m2b);
+    }
   sm[0][gl][cl] = a.n; sm[1][gl][cl] = a.mean; sm[2][gl][cl] = a.m2;
   __syncthreads();
   if (gl != 0 || c >= D) return;
@@ -1857,21 +1869,21 @@ int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
 int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, void* var_T, float* var_f32,
                       hipStream_t st, bool zero_queue_counters = false) {
   double* part = wsp<double>(ws, p.o_part_stats);
-  double* bs = bstats ? bstats : wsp<double>(ws, p.o_bstats);
   if (p.G > 65535) return fail(VC2_ERR_UNSUPPORTED, "too many sweep-1 row groups (%d)", p.G);
   dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
   { ProfScope ps_(KID_STATS, st);
   VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8>), grid, dim3(kStatsWaves * 64), 0, st, x,
                                           p.R, int(p.D), p.CV, int(p.N), p.stat_splits, p.rows_per_group, p.BF, part)); }
   { ProfScope ps_(KID_STATS_REDUCE, st);
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_block_stats<DT>), dim3(unsigned(cdiv(p.D, 64)), unsigned(p.NB)), dim3(64),
-                                           0, st, part, p.BF * p.stat_splits, p.G, x, p.R, int(p.D),
-                                           int(p.N), p.BF, bs));
+  const PartSrc src{part, x, p.R, p.BF * p.stat_splits, p.G, int(p.N), p.BF};
+  if (bstats)         // the frame-sharded pass needs the block statistics themselves (exchange 1)
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_block_stats<DT>), dim3(unsigned(cdiv(p.D, 64)), unsigned(p.NB)), dim3(64),
+                                             0, st, src, int(p.D), bstats));
   if (var_f32 || var_T) {
     const int64_t n_each = int64_t(p.BF) * p.N, n_last = p.R - int64_t(p.NB - 1) * n_each;
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
-                                             0, st, bs, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
-                                             zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr));
+                                             0, st, (const double*)nullptr, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
+                                             zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src));
   } }
   return check_launch("chan_stats");
 }
@@ -2183,7 +2195,7 @@ int vc2_chan_var_from_stats(const double* bstats, int64_t NB, int64_t rows_per_b
   hipStream_t st = static_cast<hipStream_t>(stream);
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(D, 64))), dim3(64 * kRedGL), 0, st,
                                             bstats, int(NB), rows_per_block, R_total - (NB - 1) * rows_per_block, int(D),
-                                            var_T, var_f32, (int*)nullptr));
+                                            var_T, var_f32, (int*)nullptr, PartSrc{}));
   return check_launch("var_from_stats");
 }
 
@@ -2271,9 +2283,15 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if (rc) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const ChanSet cs0 = make_chanset(p, cols, spos, C);
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
                                             csum_all, int(P), csum_stride, int(C), R_total, (double*)nullptr,
-                                            wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket)));
+                                            wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket), cs0.strict,
+                                            (cs0.strict && dtype != VC2_F32) ? wsp<int>(ws, p.o_ticket) + 5 : (int*)nullptr,
+                                            wsp<int>(ws, p.o_vfixlist), (int*)nullptr));
+  // (ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary: this pass
+  // keeps the exactly rounded mean there -- the unsharded pass replays torch's summation order --, and
+  // vc2_select_sharded reports the count in K_out[2])
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, make_chanset(p, cols, spos, C), ws, v_T, f_T, total, s, st);
@@ -2426,6 +2444,11 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
                        idx_out, cap, K_out, BudgetSrc{scales, nullptr, 0, nullptr, base_scale, 0.01, nullptr}, st);
   }
   if (rc) return rc;
+  {   // K_out[2] = number of video-centre columns left at the exactly rounded mean (see vc2_scores_phase2)
+    if (hipMemsetAsync(K_out + 2, 0, 8, st) != hipSuccess ||
+        hipMemcpyAsync(K_out + 2, wsp<int>(ws, p.o_ticket) + 5, 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(VC2_ERR_LAUNCH, "status copy failed");
+  }
   if (out_rows && gather_src)
     rc = launch_gather_rows(gather_src, F_local * N, D, p.ES, idx_out, K_out, cap, out_rows, st);
   return rc;

@@ -67,7 +67,7 @@ class HipStages:
         self.cap = min(F * N, int(L.vc2_kept_capacity(F + 1, N, base_scale)))
         self.idx = torch.empty(self.cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(F, dtype=torch.int64, device=self.device)
-        self.kout = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self.kout = torch.zeros(4, dtype=torch.int64, device=self.device)     # K, capacity overflow, fragile centre columns
         self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
 
         # device pointers of the fixed buffers, resolved once: the per-pass host work is five C calls plus
@@ -120,9 +120,15 @@ class HipStages:
               "vc2_select_sharded")
 
     def result(self, f0):
-        K, overflow = self.kout.tolist()                    # the path's single host sync
+        K, overflow, vc_fragile, _ = self.kout.tolist()     # the path's single host sync
         if overflow:
             raise RuntimeError(f"vidcom2_amd: kept-token capacity {self.cap} exceeded (K={K})")
+        self.vc_fragile = int(vc_fragile)
+        if vc_fragile and _ffi.get_mode() == "torch":
+            import warnings
+            warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within 16 fp32-ulps of a "
+                          "rounding boundary; this path keeps the exactly rounded mean there, the reference's fp32 summation "
+                          "order could round the other way (the unsharded pass replays it).", RuntimeWarning, stacklevel=2)
         li = self.idx[:K]
         return ShardResult(self.rows[:K] if self.rows is not None else None, li, li + f0 * self.N, self.ks, int(K))
 
