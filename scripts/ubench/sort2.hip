@@ -8,7 +8,7 @@
 using namespace vc2;
 
 template <int NW, int SOLO, int COOP>
-__global__ __launch_bounds__(64 * NW) void k_sort(const uint32_t* gw, int n, int reps, unsigned long long* out, int* order) {
+__global__ __launch_bounds__(64 * NW) void k_sort(const uint32_t* gw, int n, int reps, unsigned long long* out, int* order, int ta, int tb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Sel2<uint32_t> S = sel2_carve<uint32_t>(smem, n + 1);
   unsigned char* p = smem + (sel2_bytes(n + 1, 4) + 15) / 16 * 16;
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64 * NW) void k_sort(const uint32_t* gw, int n, int
     for (int i = tid; i < n; i += 64 * NW) S.w[i] = gw[i];
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
-    introsort2<uint32_t, NW, SOLO, COOP>(S, Q, n, ord, tid);
+    introsort2<uint32_t, NW, SOLO, COOP>(S, Q, n, ord, tid, ta, tb);
     const unsigned long long t1 = __builtin_readcyclecounter();
     acc += t1 - t0;
     __syncthreads();
@@ -54,23 +54,21 @@ int main() {
   hipMemcpy(d, w.data(), 4096 * 4, hipMemcpyHostToDevice);
   unsigned long long h[2];
   size_t smem = sel2_bytes(n + 1, 4) + sort2_bytes(n + 1) + (n + 1) * 4 + 256;
-  for (int rep = 0; rep < 1; ++rep) {
+  auto run = [&](int nw, int part, int parts) {
+    unsigned long long z[128] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(vc2::g_sel2_dbg), z, sizeof(z));
+    const int ta = int(int64_t(n) * part / parts), tb = int(int64_t(n) * (part + 1) / parts);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_sort<16, 2, 2>), dim3(1), dim3(1024), smem, 0, d, n, 20, dout, dord);
+    if (nw == 16) hipLaunchKernelGGL((k_sort<16, 2, 2>), dim3(1), dim3(1024), smem, 0, d, n, 20, dout, dord, ta, tb);
+    else hipLaunchKernelGGL((k_sort<4, 4, 4>), dim3(1), dim3(256), smem, 0, d, n, 20, dout, dord, ta, tb);
     hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     hipMemcpy(h, dout, 8, hipMemcpyDeviceToHost);
-    printf("introsort2 NW=16 n=%d: %llu cycles per sort; wall %.1f us per rep (incl. reload)\n", n, h[0], ms * 1000 / 20);
-    { unsigned long long z[128] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(vc2::g_sel2_dbg), z, sizeof(z)); }
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_sort<4, 4, 4>), dim3(1), dim3(256), smem, 0, d, n, 20, dout, dord);
-    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
-    hipMemcpy(h, dout, 8, hipMemcpyDeviceToHost);
-    printf("introsort2 NW=4  n=%d: %llu cycles per sort; wall %.1f us per rep (incl. reload)\n", n, h[0], ms * 1000 / 20);
-  }
-  { unsigned long long dbg[128]; hipMemcpyFromSymbol(dbg, HIP_SYMBOL(vc2::g_sel2_dbg), sizeof(dbg));
-    printf("last sort (NW=4): init %llu  phase1 %llu  phase2 %llu  (barrier %llu)\n", dbg[1]-dbg[0], dbg[2]-dbg[1], dbg[3]-dbg[2], dbg[4]-dbg[3]);
-    for (int w = 0; w < 16; ++w) printf("  wave %2d: partition cycles (all reps, both launches) %8llu in %4llu partitions\n", w, dbg[16+2*w], dbg[17+2*w]); }
+    unsigned long long dbg[128]; hipMemcpyFromSymbol(dbg, HIP_SYMBOL(vc2::g_sel2_dbg), sizeof(dbg));
+    unsigned long long pc = 0, pn = 0; for (int w = 0; w < 16; ++w) { pc += dbg[16 + 2 * w]; pn += dbg[17 + 2 * w]; }
+    printf("introsort2 NW=%2d slice %d/%d: %6llu cycles per sort (wall %.1f us/rep) | init %llu phase1 %llu phase2 %llu final %llu | pool partitions %llu, %llu cycles each\n",
+           nw, part, parts, h[0], ms * 1000 / 20, dbg[1]-dbg[0], dbg[2]-dbg[1], dbg[3]-dbg[2], dbg[5]-dbg[4], pn / 20, pn ? pc / pn : 0);
+  };
+  run(16, 0, 1); run(16, 0, 1); run(16, 1, 4); run(16, 3, 8); run(4, 0, 1); run(4, 1, 4); run(4, 3, 8); run(4, 7, 16);
   hipLaunchKernelGGL((k_small<0>), dim3(1), dim3(64), sel2_bytes(4096, 4), 0, d, 4096, 0, 40, 50, dout);
   hipMemcpy(h, dout, 16, hipMemcpyDeviceToHost); printf("partition E=1  len 40 : %llu cycles (cut %llu)\n", h[0], h[1]);
   hipLaunchKernelGGL((k_small<0>), dim3(1), dim3(64), sel2_bytes(4096, 4), 0, d, 4096, 100, 120, 50, dout);

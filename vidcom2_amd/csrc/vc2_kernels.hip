@@ -285,7 +285,7 @@ template <typename W, int NW, int SOLO, int COOP>
 __device__ __forceinline__ void chan_order_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
                                                 const int* __restrict__ perm, const int* __restrict__ cols,
                                                 int* __restrict__ order, int* __restrict__ opos,
-                                                int* __restrict__ spos) {
+                                                int* __restrict__ spos, int part, int nparts) {
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
@@ -299,16 +299,23 @@ __device__ __forceinline__ void chan_order_body(unsigned char* smem, const float
   __syncthreads();
   const bool partial = int64_t(k) * 64 <= int64_t(D) && k < D;
   if (partial) {
+    if (part != 0) return;                                                     // (serial: one workgroup does it all)
     if (tid == 0) s2_sort_heap(S.w, 0, k);                                     // partial_sort = heap_select + sort_heap
     __syncthreads();
     for (int q = tid; q < k; q += NT) ord[q] = T::idx(S.w[q]);
   } else {
-    introsort2<W, NW, SOLO, COOP>(S, Q, k - 1, ord, tid);                      // std::sort(q, q + k - 1)
-    if (tid == 0) ord[k - 1] = T::idx(S.w[k - 1]);                             // the nth_element pivot stays last
+    // workgroup `part` of `nparts` answers for the slice [ta, tb) of std::sort(q, q + k - 1) (see introsort2)
+    const int n = k - 1;
+    const int ta = int(int64_t(n) * part / nparts), tb = int(int64_t(n) * (part + 1) / nparts);
+    for (int q = tid; q < k; q += NT) ord[q] = -1;
+    __syncthreads();
+    introsort2<W, NW, SOLO, COOP>(S, Q, n, ord, tid, ta, tb);
+    if (tid == 0 && part == nparts - 1) ord[k - 1] = T::idx(S.w[k - 1]);       // the nth_element pivot stays last
   }
   __syncthreads();
   for (int q = tid; q < k; q += NT) {
     const int c = ord[q];
+    if (c < 0) continue;                                                       // another workgroup's position
     if (order) order[q] = c;
     if (cols && opos) { const int cp = int(cpos[c]); opos[q] = cp; if (spos) spos[cp] = q; }
   }
@@ -316,9 +323,17 @@ __device__ __forceinline__ void chan_order_body(unsigned char* smem, const float
 __host__ inline size_t chan_order_lds(int D, int k, int wbytes) {
   return (sel2_bytes(k, wbytes) + 15) / 16 * 16 + (sort2_bytes(k) + 15) / 16 * 16 + size_t(k) * 4 + size_t(D) * 2 + 64;
 }
-struct OrderArgs {          // the ORDER job (all null: none)
-  const float* var_f32; const int* perm; const int* cols; int* order; int* opos; int* spos; int D; int k;
+struct OrderArgs {          // the ORDER job (all null: none), done by `parts` workgroups side by side
+  const float* var_f32; const int* perm; const int* cols; int* order; int* opos; int* spos; int D; int k; int parts;
 };
+// workgroups for the ORDER job: slices of >= 128 positions (a slice costs its workgroup the partitions above it)
+#ifndef VC2_RIDER_PARTS
+#define VC2_RIDER_PARTS 8      // rider workgroups of sweep 2 (4 waves each)
+#endif
+#ifndef VC2_ORDER_PARTS
+#define VC2_ORDER_PARTS 4      // workgroups of the stand-alone k_chan_order (16 waves each)
+#endif
+__host__ inline int order_parts(int k, int max_parts) { return std::max(1, std::min(max_parts, (k - 1) / 128)); }
 
 __global__ __launch_bounds__(kSelNT) void k_chan_order(OrderArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -326,9 +341,11 @@ __global__ __launch_bounds__(kSelNT) void k_chan_order(OrderArgs a) {
   int bad = 0;
   for (int i = threadIdx.x; i < a.k; i += kSelNT) bad |= key_fits_u32(a.var_f32[a.perm[i]]) ? 0 : 1;
   if (__syncthreads_or(bad))
-    chan_order_body<uint64_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos);
+    chan_order_body<uint64_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
+                                        int(blockIdx.x), int(gridDim.x));
   else
-    chan_order_body<uint32_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos);
+    chan_order_body<uint32_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
+                                        int(blockIdx.x), int(gridDim.x));
 }
 
 template <int DT>
@@ -664,11 +681,12 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
   // (RIDER = 0 instantiations carry no ORDER code: it is only ever attached in "torch order" mode.)
-  const int nrider = (RIDER && rider.perm) ? 1 : 0;
+  const int nrider = (RIDER && rider.perm) ? rider.parts : 0;
   if constexpr (RIDER != 0) {
-    if (nrider && blockIdx.x == 0) {
+    if (int(blockIdx.x) < nrider) {
       chan_order_body<uint32_t, kRowWaves, 4, 4>(smem, rider.var_f32, rider.D, rider.k, rider.perm, rider.cols,
-                                                 rider.order, rider.opos, rider.spos);   // (16-bit variances: 32-bit words)
+                                                 rider.order, rider.opos, rider.spos,    // (16-bit variances: 32-bit words)
+                                                 int(blockIdx.x), nrider);
       return;
     }
   }
@@ -825,91 +843,15 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   }
 }
 
-struct CFixEntry { int f; int c; };      // queued (frame, compact column) pair
-// (queued video-centre columns: expected a handful; the list holds every column, it cannot overflow)
+constexpr int kCentreFL = 16;           // frames per centre group (csum_part rows; exchange 2 of the sharded pass)
 
-// centres (compact channel space): frame_center[f][p] = mean_T(sum_n x^) and per-frame-group column
-// sums (fp64, fixed order).  grid = (ceil(C/64), ceil(F/16)); workgroup = 64 columns x 16 frames.
-constexpr int kCentreFL = 16;
-
-// Strict mode: rows whose norm k_norm_fix corrected (corr list, normally empty) swap their x^ contribution.
-template <int DT>
-__global__ __launch_bounds__(64 * kCentreFL) void k_centres(const double* __restrict__ part, int F, int S,
-                                                             int N, int C, float* __restrict__ fc,
-                                                             double* __restrict__ csum_part,
-                                                             const void* __restrict__ x, int D,
-                                                             const int* __restrict__ cols,
-                                                             const int* __restrict__ corr_count,
-                                                             const NormCorr* __restrict__ corr, int strict,
-                                                             int* __restrict__ cfix_count,
-                                                             CFixEntry* __restrict__ cfix_list, int cfix_cap) {
-  __shared__ double sm[kCentreFL][64];
-  const int cl = threadIdx.x & 63, fl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int f = blockIdx.y * kCentreFL + fl;
-  double sf = 0.0;
-  if (c < C && f < F) {
-    for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
-    const int nc = corr_count ? *corr_count : 0;               // (<= rows: the list holds one entry per row)
-    for (int e = 0; e < nc; ++e) {
-      if (corr[e].frame == f) {
-        const int row = corr[e].row;
-        const float v = ldT<DT>(x, int64_t(row) * D + (cols ? cols[c] : c));
-        const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_old)));
-        const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_new)));
-        sf += double(xn) - double(xo);
-      }
-    }
-    fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
-    if (strict == 1 && cfix_count && mean_near_T_boundary<DT>(float(sf) / float(N))) {
-      const int j = atomicAdd(cfix_count, 1);
-      if (j < cfix_cap) { cfix_list[j].f = f; cfix_list[j].c = c; }
-    }
-  }
-  sm[fl][cl] = sf;
-  __syncthreads();
-  if (fl == 0 && c < C) {
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < kCentreFL; ++i) t += sm[i][cl];
-    csum_part[int64_t(blockIdx.y) * C + c] = t;
-  }
-}
-
-// video centre from NP partial sums (frame groups of one rank, or the all-gathered per-rank sums):
-// csum_out[c] = sum_p parts[p*stride + c] (fp64) and/or vc[c] = mean_T(that, R_total)  (vidcom2.py:51)
-template <int DT>
-__global__ void k_vid_centre(const double* __restrict__ parts, int NP, int64_t stride, int C, int64_t R_total,
-                             double* __restrict__ csum_out, float* __restrict__ vc, int* __restrict__ ticket,
-                             int strict = 0, int* __restrict__ vfix_count = nullptr,
-                             int* __restrict__ vfix_list = nullptr, int* __restrict__ vticket = nullptr) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && ticket) { ticket[0] = 0; ticket[1] = 0; }   // [1] k_dist's strict-mode fix-up queue length ([0] spare)
-  if (vticket && c < C) vticket[c] = 0;                     // per-entry arrival counters of k_centre_fix
-  if (c >= C) return;
-  double t = 0.0;
-  for (int p = 0; p < NP; ++p) t += parts[int64_t(p) * stride + c];
-  if (csum_out) csum_out[c] = t;
-  if (vc) {
-    vc[c] = mean_T<DT>(t, R_total);
-    if (strict == 1 && vfix_count && mean_near_T_boundary<DT>(float(t) / float(R_total))) {
-      const int j = atomicAdd(vfix_count, 1);
-      vfix_list[j] = c;                                         // (each column at most once: j < C)
-    }
-  }
-}
-
-// ---- strict mode, half precision: replay torch's fp32 outer-sum cascade for the queued centre means ------
+// ---- "torch order" mode, half precision: torch's fp32 outer-sum cascade for boundary-near centre means -----------
 // SumKernel.cpp multi_row_sum over n elements: blocks of 16 added sequentially (acc0), block sums added into
 // acc1, acc1 dumped into acc2 every 256 elements, acc2 into acc3 every 4096; finally
 // ((tail + acc1) + acc2) + acc3.  (level_power = max(4, ceil_log2(n) / 4) is 4 for n <= 2^19.)
 // Every block / group sum is an independent sequential chain.  Work item = one level-1 group (16 blocks = 256
-// rows) of one queued column, done by one wave: 16 lanes each add one block's 16 values in order, then the 16
-// block sums are added in order.  A frame-centre entry (N rows, usually one group) is finished by its wave
-// alone; the ~100 groups of a video-centre entry are spread over the grid (the 25088 strided 2-byte loads of
-// one column would take one CU ~40 us) and the last wave to arrive -- agent-scope release / acquire on a
-// per-entry ticket, CDNA guide G16 -- combines them.
-constexpr int kCFixWaves = 4;
+// rows) of one column, done by 16 lanes: each adds one block's 16 values in order, then the 16 block sums are
+// added in order.
 constexpr int kCFixSolo = 512;       // level-1 groups a single wave may hold (rows <= 131072)
 
 template <int DT>
@@ -997,74 +939,169 @@ __device__ float wave_column_solo(float* l1s, bool simple, const void* __restric
   return s;
 }
 
-// counts[0] / flist: queued frame-centre entries; counts[1] / vlist: queued video-centre columns.
-// all != 0 (debug mode 2): every (frame, column) pair and every video column instead of the queues.
+// ---- centres (vidcom2.py:51-52): two kernels between sweep 2 and sweep 3 ---------------------------------------
+// k_frame_centres   workgroup = 64 columns (compact channel space) x 16 frames: frame sums (the S partials of
+//                   sweep 2 in order, norm corrections applied) -> frame_center[f][c] = mean_T; the 16 frame sums
+//                   added in frame order -> csum_part[g][c] (exchange 2 of the frame-sharded pass);
+// k_video_centre    workgroup = 64 columns x 16 waves: the group sums added in group order -> vid_center[c] = mean_T.
+// "torch order" mode, half precision: a mean within kFragileUlpsMean fp32-ulps of a T rounding boundary goes on a
+// workgroup-local list and is replayed in torch's outer-sum cascade by the same workgroup -- frame entries one wave
+// each, a video-centre column by all 16 waves (four of its ~100 level-1 groups per wave at a time, wave 0 combines).
+// No global queues, no tickets, no separate fix-up kernel.
+constexpr int kCen2List = 1024;
+
 template <int DT>
-__global__ __launch_bounds__(kCFixWaves * 64) void k_centre_fix(const void* __restrict__ x, int F, int N, int D,
-                                                                int C, const int* __restrict__ cols,
-                                                                const int* __restrict__ spos,
-                                                                const float* __restrict__ den,
-                                                                const int* __restrict__ counts,
-                                                                const CFixEntry* __restrict__ flist, int fcap,
-                                                                const int* __restrict__ vlist, int all, int do_vid,
-                                                                float* __restrict__ vscratch, int vstride,
-                                                                int* __restrict__ vticket,
-                                                                float* __restrict__ fc, float* __restrict__ vc) {
-  __shared__ float l1s_all[kCFixWaves][kCFixSolo];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* l1s = l1s_all[wave];
-  const int64_t R = int64_t(F) * N;
+__global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int N,
+                                                                   int C, float* __restrict__ fc,
+                                                                   double* __restrict__ csum_part,
+                                                                   const void* __restrict__ x, int D,
+                                                                   const int* __restrict__ cols,
+                                                                   const int* __restrict__ spos,
+                                                                   const float* __restrict__ den,
+                                                                   const int* __restrict__ corr_count,
+                                                                   const NormCorr* __restrict__ corr, int strict,
+                                                                   int* __restrict__ vtick) {
+  __shared__ double sm[kCentreFL][64];
+  __shared__ float l1s_all[kCentreFL][kCFixSolo];
+  __shared__ uint32_t flist[kCen2List];            // local frame * 64 + local column
+  __shared__ int count;
+  const int tid = threadIdx.x, cl = tid & 63, fl = tid >> 6, lane = cl, wave = fl;
+  const int c = blockIdx.x * 64 + cl;
+  const int g = blockIdx.y;
+  const int f = g * kCentreFL + fl;
+  const bool replay = strict != 0 && DT != VC2_F32;
+  const bool all = strict >= 2;
+  if (tid == 0) {
+    count = 0;
+    if (g == 0) vtick[blockIdx.x] = 0;             // k_video_centre's arrival ticket of this column block
+  }
+  __syncthreads();
+  double sf = 0.0;
+  if (c < C && f < F) {
+    for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
+    const int nc = corr_count ? *corr_count : 0;
+    for (int e = 0; e < nc; ++e) {                              // rows whose norm k_norm_fix corrected (normally none)
+      if (corr[e].frame == f) {
+        const float v = ldT<DT>(x, int64_t(corr[e].row) * D + (cols ? cols[c] : c));
+        const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_old)));
+        const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_new)));
+        sf += double(xn) - double(xo);
+      }
+    }
+    fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
+    if (replay && (all || mean_near_T_boundary<DT>(float(sf) / float(N)))) {
+      const int j = atomicAdd(&count, 1);
+      if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
+    }
+  }
+  sm[fl][cl] = sf;
+  __syncthreads();
+  if (fl == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kCentreFL; ++i) t += sm[i][cl];
+    csum_part[int64_t(g) * C + c] = t;
+  }
+  if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
+  // ---- the boundary-near frame means in torch's cascade order: one wave per entry (the list holds every pair of the
+  //      workgroup: 16 x 64 = kCen2List)
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
-  const int nf = all ? F * C : min(counts[0], fcap);
-  int nv = !do_vid ? 0 : (all ? C : min(counts[1], C));
-  if (R > (int64_t(1) << 19)) nv = 0;                         // level_power 5: not replayed (exact mean kept)
+  const int nf = min(count, kCen2List);
+  for (int e = wave; e < nf; e += kCentreFL) {
+    const int ff = g * kCentreFL + int(flist[e] >> 6), cc = blockIdx.x * 64 + int(flist[e] & 63u);
+    const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
+    const float s = wave_column_solo<DT>(l1s_all[wave], sp < simple_end, x, D, col, den, int64_t(ff) * N, N, lane);
+    if (lane == 0) fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
+  }
+}
+
+// parts[NP][stride]: the 16-frame group sums of one rank, or the all-gathered ones of every rank (frame order).
+// Workgroup (bx, y) = one wave; lane = column bx*64 + lane.  Every y computes the same means and the same set of
+// boundary-near columns; y = 0 stores the means.  replay_rows = 1 (single rank: x / den hold ALL R rows): the ~R/256
+// level-1 groups of a flagged column are spread over the gridDim.y waves of its column block -- one CU ingests a
+// strided column at ~50 GB/s, 25088 rows would take it ~35 us -- which leave them in l1g[column][group]; the last
+// wave to arrive (agent-scope release / acquire around the block's ticket) finishes the cascade and stores the
+// replayed mean.  replay_rows = 0 (frame-sharded pass): the flagged columns are only counted (fragile_count).
+template <int DT>
+__global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ parts, int NP, int64_t stride, int C,
+                                                      int64_t R, float* __restrict__ vc, const void* __restrict__ x,
+                                                      int D, const int* __restrict__ cols,
+                                                      const int* __restrict__ spos, const float* __restrict__ den,
+                                                      int strict, int replay_rows, int* __restrict__ fragile_count,
+                                                      float* __restrict__ l1g, int vstride, int* __restrict__ vtick) {
+  __shared__ float l1s[2052];                        // level-1 groups of one column (R <= 2^19 rows)
+  const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = gridDim.y;
+  const bool replay = strict != 0 && DT != VC2_F32;
+  const bool all = strict >= 2;
+  const int c = bx * 64 + lane;
+  bool flag = false;
+  const int cl = c < C ? c : C - 1;
+  const int my_col = cols ? cols[cl] : cl, my_sp = spos ? spos[cl] : cl;   // (in flight with the partial sums)
+  if (c < C) {
+    double t = 0.0;
+    for (int p0 = 0; p0 < NP; p0 += 8) {            // eight loads in flight, added in part order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = parts[int64_t(min(p0 + u, NP - 1)) * stride + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (p0 + u < NP) t += v[u];
+    }
+    if (y == 0) vc[c] = mean_T<DT>(t, R);
+    flag = replay && R <= (int64_t(1) << 19) && (all || mean_near_T_boundary<DT>(float(t) / float(R)));
+  }
+  if (!replay) return;
+  const uint64_t flagged = __ballot(flag);
+  if (!flagged) return;
+  if (y == 0 && lane == 0 && fragile_count) atomicAdd(fragile_count, __popcll(flagged));
+  if (!replay_rows) return;
+  const int group = C >= 8 ? 32 : 4;
+  const int simple_end = (C / group) * group;
   const int64_t nbv = R >> 4;
   const int G1v = int((nbv + 15) >> 4);
-  const bool multi = !all && G1v > 1;
-  const int64_t items = int64_t(nf) + (multi ? int64_t(nv) * G1v : int64_t(nv));
-  const int64_t nw = int64_t(gridDim.x) * kCFixWaves;
-  for (int64_t it = int64_t(blockIdx.x) * kCFixWaves + wave; it < items; it += nw) {
-    if (it < nf) {                                            // ---- frame-centre entry, one wave
-      int f, c;
-      if (all) { f = int(it / C); c = int(it % C); } else { f = flist[it].f; c = flist[it].c; }
-      const int col = cols ? cols[c] : c, sp = spos ? spos[c] : c;
-      if (((N >> 4) + 15) >> 4 > kCFixSolo) continue;
-      const float s = wave_column_solo<DT>(l1s, sp < simple_end, x, D, col, den, int64_t(f) * N, N, lane);
-      if (lane == 0) fc[int64_t(f) * C + c] = rnT<DT>(s / float(N));
+  const int sub = lane >> 4, li = lane & 15;
+  for (uint64_t m = flagged; m; m &= m - 1) {
+    const int vl = __builtin_ctzll(m), cc = bx * 64 + vl;
+    const int col = __shfl(my_col, vl, 64), sp = __shfl(my_sp, vl, 64);
+    if (sp >= simple_end) {                       // row_sum's four interleaved chains (C % 32 tail): y = 0 alone
+      if (y == 0 && int((((R >> 2) >> 4) + 15) >> 4) <= kCFixSolo) {
+        const float s = wave_column_solo<DT>(l1s, false, x, D, col, den, 0, R, lane);
+        if (lane == 0) vc[cc] = rnT<DT>(s / float(R));
+      }
       continue;
     }
-    const int64_t j = it - nf;
-    const int v = multi ? int(j / G1v) : int(j);
-    const int g = multi ? int(j % G1v) : 0;
-    const int c = all ? v : vlist[v];
-    const int col = cols ? cols[c] : c, sp = spos ? spos[c] : c;
-    const bool simple = sp < simple_end;
-    if (!multi || !simple) {                                  // ---- video-centre column, one wave
-      if (g != 0) continue;
-      if ((simple ? G1v : int((((R >> 2) >> 4) + 15) >> 4)) > kCFixSolo) continue;
-      const float s = wave_column_solo<DT>(l1s, simple, x, D, col, den, 0, R, lane);
-      if (lane == 0) vc[c] = rnT<DT>(s / float(R));
-      continue;
+    for (int g4 = y * 4; g4 < G1v; g4 += Y * 4) {   // four level-1 groups at once, 16 lanes each
+      const int g1 = g4 + sub;
+      const int nbl = g1 < G1v ? int(min<int64_t>(16, nbv - (int64_t(g1) << 4))) : 0;
+      float a = 0.f;
+      if (li < nbl) {
+        const int64_t e0 = ((int64_t(g1) << 4) + li) << 4;
+        float vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) vv[u] = xhat_at<DT>(x, e0 + u, D, col, den);
+        a = vv[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) a += vv[u];
+      }
+      float sgrp = __shfl(a, lane & 48, 64);         // the block sums of my group, added in block order
+      for (int u = 1; u < 16; ++u) { const float t = __shfl(a, (lane & 48) + u, 64); if (u < nbl) sgrp += t; }
+      if (li == 0 && g1 < G1v) l1g[int64_t(cc) * vstride + g1] = sgrp;
     }
-    // ---- one level-1 group of a video-centre column; the last wave to finish combines
-    const float l1 = wave_l1_group<DT>(x, D, col, den, 0, 1, int64_t(g) << 4,
-                                       int(min<int64_t>(16, nbv - (int64_t(g) << 4))), lane);
-    int last = 0;
-    if (lane == 0) {
-      vscratch[int64_t(v) * vstride + g] = l1;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int t0 = __hip_atomic_fetch_add(vticket + v, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = (t0 == G1v - 1) ? 1 : 0;
-      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    last = __shfl(last, 0, 64);
-    if (last) {
-      const float* l1p = vscratch + int64_t(v) * vstride;
-      const float s = wave_cascade_final<DT>(l1p, nbv, x, D, col, den, 0, 1, R, lane);
-      if (lane == 0) vc[c] = rnT<DT>(s / float(R));
-    }
+  }
+  __threadfence();                                   // release my groups ...
+  int last = 0;
+  if (lane == 0) last = atomicAdd(&vtick[bx], 1) == Y - 1;
+  if (!__shfl(last, 0, 64)) return;
+  __threadfence();                                   // ... acquire everyone else's
+  for (uint64_t m = flagged; m; m &= m - 1) {
+    const int vl = __builtin_ctzll(m), cc = bx * 64 + vl;
+    const int col = __shfl(my_col, vl, 64), sp = __shfl(my_sp, vl, 64);
+    if (sp >= simple_end) continue;
+    for (int g1 = lane; g1 < G1v; g1 += 64) l1s[g1] = l1g[int64_t(cc) * vstride + g1];
+    wave_lds_fence();
+    const float s = wave_cascade_final<DT>(l1s, nbv, x, D, col, den, 0, 1, R, lane);
+    wave_lds_fence();
+    if (lane == 0) vc[cc] = rnT<DT>(s / float(R));
   }
 }
 
@@ -1734,8 +1771,8 @@ struct Plan {
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_cfixlist, o_vfixlist, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
-  int cfix_cap, vstride;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
+  int vstride;
 };
 
 int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total = 0, int block_frames = 0) {
@@ -1801,9 +1838,6 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_ticket = take(64);
   p->o_nfixlist = take(size_t(p->R) * 4);
   p->o_corr = take(size_t(p->R) * sizeof(NormCorr));
-  p->cfix_cap = int(std::min<int64_t>(F * D, int64_t(1) << 30));     // every (frame, column) pair: cannot overflow
-  p->o_cfixlist = take(size_t(p->cfix_cap) * sizeof(CFixEntry));
-  p->o_vfixlist = take(size_t(D) * 4);
   p->vstride = int(cdiv(cdiv(std::min<int64_t>(p->R, int64_t(1) << 19), 16), 16) + 1);
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
   p->o_vticket = take(size_t(D) * 4);
@@ -1921,7 +1955,7 @@ int launch_chan_order(const OrderArgs& oa, hipStream_t st) {
   const size_t smem = chan_order_lds(oa.D, oa.k, 8);
   { int rca = allow_big_lds(&k_chan_order, smem, "k_chan_order"); if (rca) return rca; }
   { ProfScope ps_(KID_CHAN_ORDER, st);
-  hipLaunchKernelGGL(k_chan_order, dim3(1), dim3(kSelNT), smem, st, oa); }
+  hipLaunchKernelGGL(k_chan_order, dim3(unsigned(order_parts(oa.k, VC2_ORDER_PARTS))), dim3(kSelNT), smem, st, oa); }
   return check_launch("chan_order");
 }
 
@@ -1957,7 +1991,7 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
   if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>, smem, "k_norm_colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.F * p.S + (rider.perm ? 1 : 0))),
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.F * p.S + (rider.perm ? rider.parts : 0))),
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.rows_per_split,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
@@ -2022,7 +2056,6 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   const int C = cs.C;
   double* part = wsp<double>(ws, p.o_part_col);
   double* cpart = wsp<double>(ws, p.o_csum_part);
-  const int FG = int(cdiv(p.F, kCentreFL));
   const int npl = int(cdiv(C, 64));
   OrderArgs ride = rider;
   if (ride.perm && (p.VEC == 1 || !fast_acc(p, cs) || g_prof)) {   // no rider on this sweep variant (or per-kernel
@@ -2030,6 +2063,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
     if (rc) return rc;
     ride = OrderArgs{};
   }
+  if (ride.perm) ride.parts = order_parts(ride.k, VC2_RIDER_PARTS);
   { ProfScope ps_(KID_NORM_COLSUM, st);
   int rc = VC2_OK;
   VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, ride, st));
@@ -2041,36 +2075,21 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
     if (rc) return rc;
   }
   { ProfScope ps_(KID_CENTRES, st);
-  const bool replay = cs.strict && p.dt != VC2_F32;           // half-precision centre means in torch's order
-  int* cfix_count = replay ? wsp<int>(ws, p.o_ticket) + 4 : (int*)nullptr;
-  CFixEntry* cfix_list = wsp<CFixEntry>(ws, p.o_cfixlist);
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
+  const int FG = int(cdiv(p.F, kCentreFL));
+  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
                                            dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, int(p.N), C,
-                                           wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols,
+                                           wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
+                                           wsp<float>(ws, p.o_den),
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
-                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, cfix_count, cfix_list,
-                                           p.cfix_cap));
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))),
-                                           dim3(128), 0, st, cpart, FG, int64_t(C), C, p.R,
-                                           single_rank ? (double*)nullptr : wsp<double>(ws, p.o_csum),
-                                           single_rank ? wsp<float>(ws, p.o_vc) : (float*)nullptr,
-                                           wsp<int>(ws, p.o_ticket), cs.strict,
-                                           replay ? cfix_count + 1 : (int*)nullptr, wsp<int>(ws, p.o_vfixlist),
-                                           replay ? wsp<int>(ws, p.o_vticket) : (int*)nullptr));
+                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket)));
+  if (single_rank) {
+    const int G1v = int(cdiv(p.R >> 4, 16));
+    const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 4))));
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y)), dim3(64), 0,
+                                             st, cpart, FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
+                                             cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1, (int*)nullptr,
+                                             wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket)));
   }
-  if (cs.strict && p.dt != VC2_F32) {
-    ProfScope ps_(KID_CENTRE_FIX, st);
-    int* cfix_count = wsp<int>(ws, p.o_ticket) + 4;
-    CFixEntry* cfix_list = wsp<CFixEntry>(ws, p.o_cfixlist);
-    const int all = cs.strict >= 2 ? 1 : 0;
-    const int64_t pairs = (p.F + (single_rank ? 1 : 0)) * int64_t(C);
-    const unsigned grid = unsigned(all ? std::min<int64_t>(cdiv(pairs, kCFixWaves), 8192) : 512);
-    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_centre_fix<DT>), dim3(grid), dim3(kCFixWaves * 64), 0, st, x,
-                                             int(p.F), int(p.N), int(p.D), C, cs.cols, cs.spos,
-                                             wsp<float>(ws, p.o_den), cfix_count, cfix_list, p.cfix_cap,
-                                             wsp<int>(ws, p.o_vfixlist), all, single_rank ? 1 : 0,
-                                             wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
-                                             wsp<float>(ws, p.o_fc), wsp<float>(ws, p.o_vc)));
   }
   return check_launch("scores phase 1");
 }
@@ -2219,7 +2238,7 @@ int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_chan_select(var_f32, D, k, mask, cols, perm, st);
   if (rc || !(order || opos || spos)) return rc;
-  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k)}, st);
+  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k), 1}, st);
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -2261,7 +2280,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   const ChanSet cs = make_chanset(p, cols, spos, C);
   OrderArgs rider{};
   if (perm && cs.strict)      // torch.topk's ORDER of the channels (-> spos), replayed by a rider workgroup of sweep 2
-    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C)};
+    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1};
   rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider);
   if (rc) return rc;
   if (csum_parts) {       // the fp64 sums of x^ per group of kCentreFL frames, in frame order: [ceil(F/16)][C]
@@ -2284,11 +2303,10 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
-  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vid_centre<DT>), dim3(unsigned(cdiv(C, 128))), dim3(128), 0, st,
-                                            csum_all, int(P), csum_stride, int(C), R_total, (double*)nullptr,
-                                            wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket), cs0.strict,
-                                            (cs0.strict && dtype != VC2_F32) ? wsp<int>(ws, p.o_ticket) + 5 : (int*)nullptr,
-                                            wsp<int>(ws, p.o_vfixlist), (int*)nullptr));
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
+                                            csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
+                                            int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
+                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr));
   // (ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary: this pass
   // keeps the exactly rounded mean there -- the unsharded pass replays torch's summation order --, and
   // vc2_select_sharded reports the count in K_out[2])
@@ -2392,7 +2410,7 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   // torch.topk's ORDER of the selected channels (needed only by the "torch order" fix-ups, which run after sweep 2)
   // is replayed by a rider workgroup of sweep 2 itself
   OrderArgs rider{};
-  if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc)};
+  if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc), 1};
   if ((rc = launch_phase1(p, x, cs, ws, true, st, rider))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* scales = wsp<float>(ws, p.o_scales_f32);

@@ -415,7 +415,12 @@ __device__ __forceinline__ uint32_t seg_pack(int first, int last, int depth) {  
 // waves poll.  No level barriers -- 178 partitions at k = 1792 spread evenly over the waves instead of the slowest
 // subtree of every level adding up.
 template <typename W, int NW, int SOLO, int COOP>
-__device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, int* __restrict__ out_order, int tid) {
+__device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, int* __restrict__ out_order, int tid,
+                                           int ta = 0, int tb = 0x7FFFFFFF) {
+  // [ta, tb): the positions THIS workgroup answers for.  A partition's two sides are independent, so R workgroups
+  // replay the same sort side by side: each follows only the segments that reach into its own slice (the few
+  // partitions above them are repeated by everybody -- same input, same result), ranks the positions of its slice
+  // and stores those.  Segments that straddle a slice boundary are sorted by both neighbours.
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
   const int lane = tid & 63, wave = tid >> 6;
@@ -458,7 +463,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
             const int lens[2] = {cut - first, last - cut};
             const int fs[2] = {first, cut}, ls[2] = {cut, last};
             for (int c = 0; c < 2; ++c) {
-              if (lens[c] <= 16) continue;
+              if (lens[c] <= 16 || fs[c] >= tb || ls[c] <= ta) continue;
               const uint32_t ch = seg_pack(fs[c], ls[c], depth - 1);
               if (lens[c] > sel2_capacity(1, SOLO)) { const int j = Q.cnt[ci ^ 1]; nxt[j] = ch; Q.cnt[ci ^ 1] = j + 1; }
               else { const int j = Q.cnt[3]; Q.segA[j] = ch; Q.cnt[3] = j + 1; Q.cnt[4] += 1; }
@@ -515,7 +520,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
 #ifdef VC2_SEL2_DEBUG
       if (lane == 0) { g_sel2_dbg[16 + wave * 2] += __builtin_readcyclecounter() - dt0; g_sel2_dbg[17 + wave * 2] += 1; }
 #endif
-      const bool left = cut - f0 > 16, right = l0 - cut > 16;
+      const bool left = cut - f0 > 16 && f0 < tb && cut > ta, right = l0 - cut > 16 && cut < tb && l0 > ta;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this partition's swaps before the publication
       if (lane == 0) {
         Q.bnd[cut] = 1;
@@ -565,7 +570,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
     }
     if (tid == 0) S.la[all] = uint16_t(n);                    // sentinel end
     __syncthreads();
-    for (int p = tid; p < n; p += NT) {
+    for (int p = max(ta, 0) + tid; p < min(n, tb); p += NT) {
       const int lid = S.lb[p];
       const int ls = S.la[lid], le = S.la[lid + 1];
       const uint32_t kp = T::key(S.w[p]);
@@ -579,6 +584,9 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
     }
   }
   __syncthreads();
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) g_sel2_dbg[5] = __builtin_readcyclecounter();
+#endif
 }
 
 }  // namespace vc2
