@@ -65,8 +65,8 @@ int main() {
     hipMemcpy(h, dout, 8, hipMemcpyDeviceToHost);
     unsigned long long dbg[128]; hipMemcpyFromSymbol(dbg, HIP_SYMBOL(vc2::g_sel2_dbg), sizeof(dbg));
     unsigned long long pc = 0, pn = 0; for (int w = 0; w < 16; ++w) { pc += dbg[16 + 2 * w]; pn += dbg[17 + 2 * w]; }
-    printf("introsort2 NW=%2d slice %d/%d: %6llu cycles per sort (wall %.1f us/rep) | init %llu phase1 %llu phase2 %llu final %llu | pool partitions %llu, %llu cycles each\n",
-           nw, part, parts, h[0], ms * 1000 / 20, dbg[1]-dbg[0], dbg[2]-dbg[1], dbg[3]-dbg[2], dbg[5]-dbg[4], pn / 20, pn ? pc / pn : 0);
+    printf("introsort2 NW=%2d slice %d/%d: %6llu cycles per sort (wall %.1f us/rep) | init %llu levels %llu final %llu | levels %llu coop %llu (%llu cyc) wave0 dealt %llu (%llu cyc)\n",
+           nw, part, parts, h[0], ms * 1000 / 20, dbg[1]-dbg[0], dbg[2]-dbg[1], dbg[5]-dbg[2], dbg[6], dbg[7], dbg[8], dbg[9], dbg[10]);
   };
   run(16, 0, 1); run(16, 0, 1); run(16, 1, 4); run(16, 3, 8); run(4, 0, 1); run(4, 1, 4); run(4, 3, 8); run(4, 7, 16);
   hipLaunchKernelGGL((k_small<0>), dim3(1), dim3(64), sel2_bytes(4096, 4), 0, d, 4096, 0, 40, 50, dout);

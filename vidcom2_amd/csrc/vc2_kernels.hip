@@ -215,9 +215,16 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
 // vc2_select2.h) and writes the ascending list of kept channels the scoring sweeps consume, plus -- perm -- the kept
 // channels in the order nth_element left them.  torch.topk(sorted=True)'s ORDER of those channels (std::sort on that
 // permutation; only the "torch order" replays and the select_low_var_channels API need it) is a second, separate
-// piece of work, chan_order_body: either its own kernel, or a RIDER workgroup of sweep 2 (k_norm_colsum), where it
-// costs nothing -- it finishes long before the sweep does and its consumers run after the sweep.
-constexpr int kSelNT = 1024;        // k_chan_select / k_chan_order: 16 waves (the rider in sweep 2 has 4)
+// piece of work, chan_order_body, done by several workgroups side by side (slices of the sorted order, see
+// introsort2): either its own kernel, or RIDER workgroups of sweep 2 (k_norm_colsum) -- its consumers run after
+// the sweep.
+#ifndef VC2_SEL_NT
+#define VC2_SEL_NT 1024
+#endif
+constexpr int kSelNT = VC2_SEL_NT;  // k_chan_select
+constexpr int kSelCoop = kSelNT >= 1024 ? 2 : (kSelNT >= 512 ? 4 : 8);     // quads per thread at D = 8192
+constexpr int kSelSolo = kSelNT >= 1024 ? 2 : 4;
+constexpr int kOrdNT = 256;         // k_chan_order: 4 waves per slice, like the rider workgroups of sweep 2
 
 // block-wide exclusive prefix of a small count (thread-contiguous chunks), fixed order; NW waves
 template <int NW>
@@ -243,8 +250,8 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   Sel2<W> S = sel2_carve<W>(smem, D);
   for (int i = tid; i < D; i += kSelNT) S.w[i] = T::pack(topk_key(var_f32[i]), i);
   __syncthreads();
-  if (k >= D) { if (perm) introselect2<W, NW, 2, 2>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
-  else topk_smallest2<W, NW, 2, 2>(S, D, k, tid);
+  if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
+  else topk_smallest2<W, NW, kSelSolo, kSelCoop>(S, D, k, tid);
   __syncthreads();
   if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
   // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction)
@@ -331,20 +338,20 @@ struct OrderArgs {          // the ORDER job (all null: none), done by `parts` w
 #define VC2_RIDER_PARTS 8      // rider workgroups of sweep 2 (4 waves each)
 #endif
 #ifndef VC2_ORDER_PARTS
-#define VC2_ORDER_PARTS 4      // workgroups of the stand-alone k_chan_order (16 waves each)
+#define VC2_ORDER_PARTS 8      // workgroups of the stand-alone k_chan_order
 #endif
 __host__ inline int order_parts(int k, int max_parts) { return std::max(1, std::min(max_parts, (k - 1) / 128)); }
 
-__global__ __launch_bounds__(kSelNT) void k_chan_order(OrderArgs a) {
+__global__ __launch_bounds__(kOrdNT) void k_chan_order(OrderArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NW = kSelNT / 64;
+  constexpr int NW = kOrdNT / 64;
   int bad = 0;
-  for (int i = threadIdx.x; i < a.k; i += kSelNT) bad |= key_fits_u32(a.var_f32[a.perm[i]]) ? 0 : 1;
+  for (int i = threadIdx.x; i < a.k; i += kOrdNT) bad |= key_fits_u32(a.var_f32[a.perm[i]]) ? 0 : 1;
   if (__syncthreads_or(bad))
-    chan_order_body<uint64_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
+    chan_order_body<uint64_t, NW, 4, 8>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
                                         int(blockIdx.x), int(gridDim.x));
   else
-    chan_order_body<uint32_t, NW, 2, 2>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
+    chan_order_body<uint32_t, NW, 4, 8>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
                                         int(blockIdx.x), int(gridDim.x));
 }
 
@@ -943,11 +950,11 @@ __device__ float wave_column_solo(float* l1s, bool simple, const void* __restric
 // k_frame_centres   workgroup = 64 columns (compact channel space) x 16 frames: frame sums (the S partials of
 //                   sweep 2 in order, norm corrections applied) -> frame_center[f][c] = mean_T; the 16 frame sums
 //                   added in frame order -> csum_part[g][c] (exchange 2 of the frame-sharded pass);
-// k_video_centre    workgroup = 64 columns x 16 waves: the group sums added in group order -> vid_center[c] = mean_T.
+// k_video_centre    one wave = 64 columns: the group sums added in group order -> vid_center[c] = mean_T.
 // "torch order" mode, half precision: a mean within kFragileUlpsMean fp32-ulps of a T rounding boundary goes on a
 // workgroup-local list and is replayed in torch's outer-sum cascade by the same workgroup -- frame entries one wave
-// each, a video-centre column by all 16 waves (four of its ~100 level-1 groups per wave at a time, wave 0 combines).
-// No global queues, no tickets, no separate fix-up kernel.
+// each (video-centre columns: see k_video_centre).
+// No global queues, no separate fix-up kernel.
 constexpr int kCen2List = 1024;
 
 template <int DT>
@@ -1955,7 +1962,7 @@ int launch_chan_order(const OrderArgs& oa, hipStream_t st) {
   const size_t smem = chan_order_lds(oa.D, oa.k, 8);
   { int rca = allow_big_lds(&k_chan_order, smem, "k_chan_order"); if (rca) return rca; }
   { ProfScope ps_(KID_CHAN_ORDER, st);
-  hipLaunchKernelGGL(k_chan_order, dim3(unsigned(order_parts(oa.k, VC2_ORDER_PARTS))), dim3(kSelNT), smem, st, oa); }
+  hipLaunchKernelGGL(k_chan_order, dim3(unsigned(order_parts(oa.k, VC2_ORDER_PARTS))), dim3(kOrdNT), smem, st, oa); }
   return check_launch("chan_order");
 }
 
@@ -2058,7 +2065,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   double* cpart = wsp<double>(ws, p.o_csum_part);
   const int npl = int(cdiv(C, 64));
   OrderArgs ride = rider;
-  if (ride.perm && (p.VEC == 1 || !fast_acc(p, cs) || g_prof)) {   // no rider on this sweep variant (or per-kernel
+  if (ride.perm && (p.VEC == 1 || !fast_acc(p, cs) || g_prof || ride.k > 4096)) {   // no rider on this sweep variant (or per-kernel
     int rc = launch_chan_order(ride, st);                          // timing wanted): the ORDER job as its own kernel
     if (rc) return rc;
     ride = OrderArgs{};

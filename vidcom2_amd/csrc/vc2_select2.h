@@ -385,203 +385,138 @@ __device__ __forceinline__ void topk_smallest2(const Sel2<W>& S, int n, int k, i
 // ---- std::sort(first, first + n) replay (the `sorted=True` half of torch.topk, TopKImpl.h) ---------------
 // __introsort_loop: every segment longer than 16 is partitioned (the same __unguarded_partition_pivot) and both
 // halves recurse with depth_limit - 1; at depth 0 a segment is heap-sorted instead.  Segments of one recursion
-// level are independent: the workgroup walks the tree level by level -- segments longer than one wave's
-// capacity by all waves together, the others one wave per segment.  __final_insertion_sort then equals a STABLE sort inside every
-// leaf segment (elements never cross a cut and the insertion uses a strict compare), done by rank counting.
-// out_order[p] = original index at sorted position p.
-constexpr int kMaxSeg2 = 1024;
+// level are independent, so the workgroup walks the tree LEVEL BY LEVEL (one barrier per level): segments longer
+// than kCoopMin by all waves together, one after the other; the rest dealt round-robin to the waves, each alone.
+// __final_insertion_sort then equals a STABLE sort inside every leaf (<= 16 elements; elements never cross a cut
+// and the insertion uses a strict compare); because everything left of a leaf is <= and everything right of it is
+// >= its elements, the final position of element p is p + #{q in (p, p+16): key_q < key_p} - #{q in (p-16, p):
+// key_q > key_p} -- no leaf bookkeeping at all.
+// Slices: a partition's two sides are independent, so R workgroups replay the same sort side by side.  Workgroup r
+// answers for the positions [ta, tb): it follows only the segments that reach into its slice (the few partitions
+// above them are repeated by everybody -- same input, same result), ranks the positions of its slice and stores
+// those.  Segments that straddle a slice boundary are sorted by both neighbours.
+// out_order[p] = original index at sorted position p (written for the positions the slice's elements land on).
+constexpr int kMaxSeg2 = 512;            // segments (> 16 elements) of one level: n <= 8192
 struct SortScratch2 {
-  uint32_t* segA;   // [kMaxSeg2] phase 1: this level's long segments; phase 2: the work pool
-  uint32_t* segB;   // [kMaxSeg2] phase 1: the next level's
-  int* cnt;         // [8]: [0],[1] entries of list A / B; [2] pool head; [3] pool tail; [4] segments not yet finished
-  uint8_t* bnd;     // [n] 1 = a leaf starts here
+  uint32_t* segA;   // [kMaxSeg2] segment lists of even levels
+  uint32_t* segB;   // [kMaxSeg2] ... of odd levels
+  int* cnt;         // [4]: entries of the list of level L in cnt[L % 3]
 };
-__host__ __device__ inline size_t sort2_bytes(int n) { return size_t(kMaxSeg2) * 8 + 32 + size_t(n) + 16; }
+__host__ __device__ inline size_t sort2_bytes(int /*n*/) { return size_t(kMaxSeg2) * 8 + 16; }
 __device__ __forceinline__ SortScratch2 sort2_carve(unsigned char* p) {
   SortScratch2 Q;
   Q.segA = reinterpret_cast<uint32_t*>(p);
   Q.segB = Q.segA + kMaxSeg2;
   Q.cnt = reinterpret_cast<int*>(Q.segB + kMaxSeg2);
-  Q.bnd = reinterpret_cast<uint8_t*>(Q.cnt + 8);
   return Q;
 }
-__device__ __forceinline__ uint32_t seg_pack(int first, int last, int depth) {      // never 0 (last >= 17)
-  return uint32_t(first) | (uint32_t(last) << 13) | (uint32_t(depth) << 26);
+__device__ __forceinline__ uint32_t seg_pack(int first, int last, int depth) {
+  return uint32_t(first) | (uint32_t(last) << 13) | (uint32_t(depth) << 26);   // last <= 8191, depth <= 26
 }
 
-// Two phases.  (1) While segments longer than one wave's capacity exist (the top 1-3 levels), the workgroup walks
-// the tree level by level and partitions them with all waves together.  (2) Everything else goes into a work POOL
-// in LDS: a wave takes a segment, partitions it, keeps the left child for itself and publishes the right one; idle
-// waves poll.  No level barriers -- 178 partitions at k = 1792 spread evenly over the waves instead of the slowest
-// subtree of every level adding up.
 template <typename W, int NW, int SOLO, int COOP>
 __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, int* __restrict__ out_order, int tid,
                                            int ta = 0, int tb = 0x7FFFFFFF) {
-  // [ta, tb): the positions THIS workgroup answers for.  A partition's two sides are independent, so R workgroups
-  // replay the same sort side by side: each follows only the segments that reach into its own slice (the few
-  // partitions above them are repeated by everybody -- same input, same result), ranks the positions of its slice
-  // and stores those.  Segments that straddle a slice boundary are sorted by both neighbours.
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
+  constexpr int kCoopMin = NW > 1 ? 256 : 0x7FFFFFFF;           // longer segments: all waves together
+  static_assert(NW == 1 || kCoopMin <= sel2_capacity(1, SOLO), "a dealt segment must fit one wave");
   const int lane = tid & 63, wave = tid >> 6;
-  volatile uint32_t* pool = Q.segA;
   volatile int* cnt = Q.cnt;
 #ifdef VC2_SEL2_DEBUG
   if (tid == 0) g_sel2_dbg[0] = __builtin_readcyclecounter();
 #endif
-  for (int p = tid; p < n; p += NT) Q.bnd[p] = (p == 0) ? 1 : 0;
-  for (int p = tid; p < kMaxSeg2; p += NT) { Q.segA[p] = 0u; Q.segB[p] = 0u; }
-  if (tid < 8) Q.cnt[tid] = 0;
+  if (tid == 0) {
+    cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
+    if (n > 16) { Q.segA[0] = seg_pack(0, n, 2 * (31 - __clz(n))); cnt[0] = 1; }
+  }
   __syncthreads();
 #ifdef VC2_SEL2_DEBUG
   if (tid == 0) g_sel2_dbg[1] = __builtin_readcyclecounter();
 #endif
-  // ---- phase 1: long segments, level by level, all waves together (lists in segB, ping-pong halves)
-  uint32_t* cur = Q.segB;
-  uint32_t* nxt = Q.segB + kMaxSeg2 / 2;
-  int ci = 0;
-  if (tid == 0 && n > 16) {
-    const uint32_t root = seg_pack(0, n, 2 * (31 - __clz(n)));
-    if (NW > 1 && n > sel2_capacity(1, SOLO)) { cur[0] = root; Q.cnt[0] = 1; }
-    else { Q.segA[0] = root; Q.cnt[3] = 1; Q.cnt[4] = 1; }
-  }
-  __syncthreads();
-  if constexpr (NW > 1) {
-    for (int level = 0; level < 64; ++level) {
-      const int ns = Q.cnt[ci];
-      if (ns == 0) break;
+  int c_cur = 0, c_nxt = 1, c_free = 2;
+#ifdef VC2_SEL2_DEBUG
+  int dbg_levels = 0, dbg_coop = 0, dbg_dealt = 0; unsigned long long dbg_tc = 0, dbg_td = 0;
+#endif
+  for (int level = 0; level < 64; ++level) {
+    const uint32_t* cur = (level & 1) ? Q.segB : Q.segA;
+    uint32_t* nxt = (level & 1) ? Q.segA : Q.segB;
+    const int ns = min(int(cnt[c_cur]), kMaxSeg2);
+    if (ns == 0) break;
+    if (tid == 0) cnt[c_free] = 0;                              // (the list two levels on; last read one level ago)
+    auto push_children = [&](int first, int cut, int last, int depth) {     // one thread
+      const int fs[2] = {first, cut}, ls[2] = {cut, last};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (ls[c] - fs[c] <= 16 || fs[c] >= tb || ls[c] <= ta) continue;    // a leaf, or outside my slice
+        const int j = atomicAdd(const_cast<int*>(&cnt[c_nxt]), 1);
+        if (j < kMaxSeg2) nxt[j] = seg_pack(fs[c], ls[c], depth - 1); else guard_hit(4);
+      }
+    };
+    if constexpr (NW > 1) {                                     // the long segments, all waves together
       for (int si = 0; si < ns; ++si) {
         const uint32_t sg = cur[si];
         const int first = int(sg & 0x1FFFu), last = int((sg >> 13) & 0x1FFFu), depth = int(sg >> 26);
-        int cut = first;
-        if (depth != 0) cut = sel2_partition<W, NW, 1, COOP>(S, first, last, S.la + first, S.lb + first, tid);
-        if (tid == 0) {
-          if (depth == 0) {                                     // depth limit: hand it to the pool (heapsort there)
-            const int j = Q.cnt[3]; Q.segA[j] = sg; Q.cnt[3] = j + 1; Q.cnt[4] += 1;
-          } else {
-            Q.bnd[cut] = 1;
-            const int lens[2] = {cut - first, last - cut};
-            const int fs[2] = {first, cut}, ls[2] = {cut, last};
-            for (int c = 0; c < 2; ++c) {
-              if (lens[c] <= 16 || fs[c] >= tb || ls[c] <= ta) continue;
-              const uint32_t ch = seg_pack(fs[c], ls[c], depth - 1);
-              if (lens[c] > sel2_capacity(1, SOLO)) { const int j = Q.cnt[ci ^ 1]; nxt[j] = ch; Q.cnt[ci ^ 1] = j + 1; }
-              else { const int j = Q.cnt[3]; Q.segA[j] = ch; Q.cnt[3] = j + 1; Q.cnt[4] += 1; }
-            }
-          }
-        }
-      }
-      __syncthreads();
-      if (tid == 0) Q.cnt[ci] = 0;
-      ci ^= 1;
-      uint32_t* t = cur; cur = nxt; nxt = t;
-      __syncthreads();
-    }
-  }
+        if (last - first <= kCoopMin || depth == 0) continue;
 #ifdef VC2_SEL2_DEBUG
-  if (tid == 0) g_sel2_dbg[2] = __builtin_readcyclecounter();
+        const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
-  // ---- phase 2: the pool.  cnt[2] = head (next entry to take), cnt[3] = tail (next free slot), cnt[4] = segments
-  //      published or in work.  An entry is valid once its word is non-zero (written after the slot was claimed).
-  {
-    uint32_t mine = 0u;                                          // the segment this wave continues with (0: none)
-    for (int guard = 0; guard < 8 * kMaxSeg2; ++guard) {
-      if (mine == 0u) {
-        int got = -1, done = 0;
-        if (lane == 0) {
-          for (int spin = 0; spin < (1 << 20); ++spin) {
-            const int h = cnt[2];
-            if (h < cnt[3]) { if (atomicCAS(const_cast<int*>(&cnt[2]), h, h + 1) == h) { got = h; break; } }
-            else if (cnt[4] == 0) { done = 1; break; }
-            else __builtin_amdgcn_s_sleep(2);
-          }
-          if (got >= 0) { for (int spin = 0; spin < (1 << 20) && pool[got] == 0u; ++spin) __builtin_amdgcn_s_sleep(1); }
-          if (got < 0 && !done) { guard_hit(3); done = 1; }
-        }
-        got = __builtin_amdgcn_readfirstlane(got);
-        done = __builtin_amdgcn_readfirstlane(done);
-        if (done) break;
-        mine = __builtin_amdgcn_readfirstlane(int(pool[got]));
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the publisher's swaps are visible
+        const int cut = sel2_partition<W, NW, 1, COOP>(S, first, last, S.la + first, S.lb + first, tid);
+#ifdef VC2_SEL2_DEBUG
+        dbg_tc += __builtin_readcyclecounter() - c0; ++dbg_coop;
+#endif
+        if (tid == 0) push_children(first, cut, last, depth);
       }
-      const int f0 = int(mine & 0x1FFFu), l0 = int((mine >> 13) & 0x1FFFu), d0 = int(mine >> 26);
-      mine = 0u;
-      if (d0 == 0) {                                              // __partial_sort(first, last, last): heapsort
-        if (lane == 0) { s2_heap_select(S.w, f0, l0, l0); s2_sort_heap(S.w, f0, l0); }
-        for (int p = f0 + lane; p < l0; p += 64) Q.bnd[p] = 1;               // already final: one leaf per element
-        wave_lds_order();
-        if (lane == 0) atomicSub(const_cast<int*>(&cnt[4]), 1);
+    }
+    int dealt = 0;
+    for (int si = 0; si < ns; ++si) {                           // the others: one wave each
+      const uint32_t sg = cur[si];
+      const int first = int(sg & 0x1FFFu), last = int((sg >> 13) & 0x1FFFu), depth = int(sg >> 26);
+      if (NW > 1 && last - first > kCoopMin && depth != 0) continue;
+      if ((dealt++ % NW) != wave) continue;
+      if (depth == 0) {                                         // __partial_sort(first, last, last): heapsort
+        if (lane == 0) { s2_heap_select(S.w, first, last, last); s2_sort_heap(S.w, first, last); }
         continue;
       }
-#ifdef VC2_SEL2_DEBUG
+#if defined(VC2_SEL2_DEBUG) && VC2_SEL2_DEBUG >= 2
       const unsigned long long dt0 = __builtin_readcyclecounter();
 #endif
-      const int cut = sel2_partition<W, 1, 0, SOLO>(S, f0, l0, S.la + f0, S.lb + f0, lane);
 #ifdef VC2_SEL2_DEBUG
+      const unsigned long long d0 = __builtin_readcyclecounter();
+#endif
+      const int cut = sel2_partition<W, 1, 0, SOLO>(S, first, last, S.la + first, S.lb + first, lane);
+#ifdef VC2_SEL2_DEBUG
+      dbg_td += __builtin_readcyclecounter() - d0; ++dbg_dealt;
+#endif
+#if defined(VC2_SEL2_DEBUG) && VC2_SEL2_DEBUG >= 2
       if (lane == 0) { g_sel2_dbg[16 + wave * 2] += __builtin_readcyclecounter() - dt0; g_sel2_dbg[17 + wave * 2] += 1; }
 #endif
-      const bool left = cut - f0 > 16 && f0 < tb && cut > ta, right = l0 - cut > 16 && cut < tb && l0 > ta;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this partition's swaps before the publication
-      if (lane == 0) {
-        Q.bnd[cut] = 1;
-        if (left && right) {                                      // publish the right child, keep the left one
-          const int j = atomicAdd(const_cast<int*>(&cnt[3]), 1);
-          atomicAdd(const_cast<int*>(&cnt[4]), 1);
-          if (j < kMaxSeg2) pool[j] = seg_pack(cut, l0, d0 - 1); else guard_hit(4);
-        } else if (!left && !right) {
-          atomicSub(const_cast<int*>(&cnt[4]), 1);
-        }
-      }
-      if (left) mine = seg_pack(f0, cut, d0 - 1);
-      else if (right) mine = seg_pack(cut, l0, d0 - 1);
-      wave_lds_order();
-      if (guard == 8 * kMaxSeg2 - 1 && lane == 0) guard_hit(2);
+      if (lane == 0) push_children(first, cut, last, depth);
     }
+    __syncthreads();
+    const int t = c_cur; c_cur = c_nxt; c_nxt = c_free; c_free = t;
+    if (level == 63 && tid == 0) guard_hit(2);
+#ifdef VC2_SEL2_DEBUG
+    ++dbg_levels;
+#endif
   }
 #ifdef VC2_SEL2_DEBUG
-  if (tid == 0) g_sel2_dbg[3] = __builtin_readcyclecounter();
+  if (tid == 0) { g_sel2_dbg[2] = __builtin_readcyclecounter(); g_sel2_dbg[6] = dbg_levels; g_sel2_dbg[7] = dbg_coop; g_sel2_dbg[8] = dbg_tc;
+                  g_sel2_dbg[9] = dbg_dealt; g_sel2_dbg[10] = dbg_td; }
 #endif
-  __syncthreads();
-#ifdef VC2_SEL2_DEBUG
-  if (tid == 0) g_sel2_dbg[4] = __builtin_readcyclecounter();
-#endif
-  // stable sort inside each leaf == __final_insertion_sort.  Leaf id = prefix count of the boundary flags; leaf
-  // starts are scattered by id (into la, free now), so every element finds [ls, le) in two reads.
-  {
-    const int Ept = (n + NT - 1) / NT;
-    const int b = tid * Ept, e = min(n, b + Ept);
-    uint32_t c = 0;
-    for (int p = b; p < e; ++p) c += Q.bnd[p];
-    const uint32_t incl = wave_incl_scan_u32(c);
-    uint32_t pre = 0u, all = incl;
-    if constexpr (NW > 1) {
-      if (lane == 63) S.xch[wave] = incl;
-      __syncthreads();
-      all = 0u;
+  // __final_insertion_sort == a stable rank inside the 31-wide window (see above)
+  for (int p = max(ta, 0) + tid; p < min(n, tb); p += NT) {
+    const W wp = S.w[p];
+    const uint32_t kp = T::key(wp);
+    int r = p;
 #pragma unroll
-      for (int v = 0; v < NW; ++v) { const uint32_t t = S.xch[v]; if (v < wave) pre += t; all += t; }
-    } else {
-      all = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+    for (int d = 1; d < 16; ++d) {
+      const int ql = p - d, qr = p + d;
+      const uint32_t kl = T::key(S.w[ql >= 0 ? ql : 0]), kr = T::key(S.w[qr < n ? qr : n - 1]);
+      r -= (ql >= 0 && kl > kp) ? 1 : 0;
+      r += (qr < n && kr < kp) ? 1 : 0;
     }
-    uint32_t id = pre + incl - c;                             // leaves before position b
-    for (int p = b; p < e; ++p) {
-      if (Q.bnd[p]) { S.la[id] = uint16_t(p); ++id; }
-      S.lb[p] = uint16_t(id - 1);                             // leaf id of position p
-    }
-    if (tid == 0) S.la[all] = uint16_t(n);                    // sentinel end
-    __syncthreads();
-    for (int p = max(ta, 0) + tid; p < min(n, tb); p += NT) {
-      const int lid = S.lb[p];
-      const int ls = S.la[lid], le = S.la[lid + 1];
-      const uint32_t kp = T::key(S.w[p]);
-      int r = ls;
-#pragma unroll 4
-      for (int q = ls; q < le; ++q) {
-        const uint32_t kq = T::key(S.w[q]);
-        r += (kq < kp || (kq == kp && q < p)) ? 1 : 0;
-      }
-      out_order[r] = T::idx(S.w[p]);
-    }
+    out_order[r] = T::idx(wp);
   }
   __syncthreads();
 #ifdef VC2_SEL2_DEBUG
