@@ -137,6 +137,35 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
                  void* ws, size_t ws_bytes, void* out_rows, int64_t* idx_out, int64_t cap,
                  int64_t* ks, int64_t* K_out, void* v_T, void* f_T, void* stream);
 
+/* The same pass with `tail_rows` extra rows (T[tail_rows, D], e.g. LLaVA's image_newline embedding,
+ * reference models/llava.py:160-168) written right behind the K kept rows by the gather launch itself:
+ * out_rows is T[cap + tail_rows, D] and rows [0, K + tail_rows) are valid afterwards. */
+int vc2_compress_tail(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale,
+                      int map_mode, int64_t grid_h, const void* gather_src, int64_t gather_rows,
+                      void* ws, size_t ws_bytes, void* out_rows, int64_t* idx_out, int64_t cap,
+                      int64_t* ks, int64_t* K_out, void* v_T, void* f_T, const void* tail, int64_t tail_rows,
+                      void* stream);
+
+/* ---- hook-side fusion: kept rows written once, at their final positions ------------
+ * vc2_gather_scatter: up to 8 tensors T[src_rows[t], D] share ONE index list:
+ *     dsts[t][dst_pos ? dst_pos[j] : dst_row0 + j] = srcs[t][idx ? idx[j] : j]      for j < n
+ * n = min(n_dev[0], n_max) when n_dev (device) is given, else n_max; `tail_rows` rows of `tail` are appended to dsts[0]
+ * behind the gathered ones (dst_row0 + n ...).  srcs / dsts / src_rows / dst_rows are HOST arrays of n_src entries.
+ * Replaces flat[global_idx] + torch.cat(newline) (vidcom2.py:91, models/llava.py:160-168), inputs_embeds[:, keep]
+ * (models/qwen2_5_vl.py:162-182) and the N+1 gathers of Qwen3-VL's deep-stack (models/qwen3_vl.py:140-165).
+ * status (optional device word): |= 2 if a row index fell outside its tensor (such rows are skipped).
+ * vc2_keep_positions (models/qwen2_5_vl.py:153-160): keep_out = ascending positions s in [0, S) with
+ * !video_mask[s] or (ordinal of s among the video positions) in kept[0..K) (ascending); K = min(K_dev[0], K_max) or
+ * K_max; vis_rows_out (optional, needs visual_mask) = ordinals, among the positions flagged in visual_mask, of the
+ * kept ones; counts_out (optional, device int64[2]) = {len(keep_out), len(vis_rows_out)}. */
+int vc2_gather_scatter(const void* const* srcs, const int64_t* src_rows, void* const* dsts, const int64_t* dst_rows,
+                       int n_src, int64_t D, int dtype, const int64_t* idx, const int64_t* n_dev, int64_t n_max,
+                       const int64_t* dst_pos, int64_t dst_row0, const void* tail, int64_t tail_rows,
+                       int32_t* status, void* stream);
+int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept, const int64_t* K_dev,
+                       int64_t K_max, const uint8_t* visual_mask, int64_t* keep_out, int64_t* vis_rows_out,
+                       int64_t* counts_out, void* stream);
+
 /* ---- frame-sharded multi-GPU building blocks -------------------------
  * A rank holds frames [f0, f0+F_local) of a video with F_total frames.  Between the local sweeps the Python
  * layer all-gathers three small fp64 / fp32 arrays over RCCL.  Exchanges 1 and 2 carry CANONICAL partials -- per
@@ -203,12 +232,6 @@ int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws
 /* Diagnostic (SYNCHRONISES): every loop of the selection replay is bounded; out8 = how often each bound actually
  * expired since the last reset (all zero on a healthy run; the test-suite asserts it). */
 int vc2_selftest_counters(int32_t* out8_host, int reset);
-
-/* ---- host helper -------------------------------------------------------------------- */
-/* torch.topk(v, k, largest=False, sorted=sorted) ORDER on host memory (ATen TopKImpl.h:
- * libstdc++ partial_sort / nth_element + sort).  Used only by the standalone
- * select_low_var_channels API, whose return value exposes the reference's column order. */
-int vc2_host_topk_order(const float* v_host, int64_t n, int64_t k, int sorted, int64_t* idx_host);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import oracle as O
 import vidcom2_amd as vc
 from vidcom2_amd import _ffi, synth
 
-from conftest import DT, ROOT, load_core_cases, load_topk_kat
+from conftest import DT, ROOT, load_core_cases
 
 
 def _header_symbols():
@@ -80,19 +80,6 @@ def test_kept_capacity_bounds_every_fixture():
         cap = L.vc2_kept_capacity(c["F"], c["N"], c["base"])
         assert c["K"] <= cap <= c["F"] * c["N"]
     assert L.vc2_kept_capacity(128, 196, 0.25) < 0.3 * 128 * 196
-
-
-@pytest.mark.parametrize("i", range(0, 315, 3))
-def test_host_topk_order_kat(i):
-    v, k, srt, dn, want = TOPK[i]
-    t = torch.from_numpy(v.copy()).to(DT[dn]).float().contiguous()
-    out = torch.empty(k, dtype=torch.int64)
-    rc = _ffi.lib().vc2_host_topk_order(ctypes.c_void_p(t.data_ptr()), t.numel(), k, int(srt),
-                                        ctypes.c_void_p(out.data_ptr()))
-    assert rc == 0 and out.tolist() == want.tolist()
-
-
-TOPK = load_topk_kat()
 
 
 def test_synth_is_deterministic():

@@ -1,0 +1,112 @@
+"""f1: vc2_gather_scatter / vc2_keep_positions / vc2_compress_tail against their torch formulations
+(the statements they replace in the hooks: vidcom2.py:91, models/llava.py:160-168, models/qwen2_5_vl.py:153-182,
+models/qwen3_vl.py:140-165).  Pure copies and index arithmetic: bit-exact."""
+import pytest
+import torch
+
+from vidcom2_amd import synth
+
+pytestmark = pytest.mark.gpu
+DTS = [torch.bfloat16, torch.float16, torch.float32]
+
+
+def _rand(rows, D, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(rows, D, generator=g).to(dt).cuda()
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("D", [64, 3584, 100, 7])          # 7 / 100: rows that are not multiples of 16 bytes
+def test_gather_scatter_matches_indexing(dt, D):
+    from vidcom2_amd.fused import gather_scatter
+    g = torch.Generator().manual_seed(D)
+    srcs = [_rand(300, D, dt, 10 + t) for t in range(3)]
+    idx = torch.randint(0, 300, (123,), generator=g).cuda()
+    out = gather_scatter(srcs, idx)
+    for s, o in zip(srcs, out):
+        assert torch.equal(o, s[idx])
+    # tail rows land behind the gathered rows of the FIRST tensor only
+    tail = _rand(2, D, dt, 99)
+    out = gather_scatter(srcs, idx, tail=tail)
+    assert torch.equal(out[0], torch.cat((srcs[0][idx], tail))) and torch.equal(out[1], srcs[1][idx])
+    # scatter to given positions of a caller-provided buffer; untouched rows stay as they were
+    pos = torch.randperm(400, generator=g)[:123].cuda()
+    dsts = [torch.full((400, D), 3.0, dtype=dt, device="cuda") for _ in srcs]
+    gather_scatter(srcs, idx, dst_pos=pos, dsts=dsts)
+    for s, d in zip(srcs, dsts):
+        want = torch.full((400, D), 3.0, dtype=dt, device="cuda")
+        want[pos] = s[idx]
+        assert torch.equal(d, want)
+
+
+def test_gather_scatter_device_count_identity_and_status():
+    from vidcom2_amd.fused import gather_scatter
+    src = _rand(50, 32, torch.bfloat16, 1)
+    n_dev = torch.tensor([17], dtype=torch.int64, device="cuda")
+    tail = _rand(1, 32, torch.bfloat16, 2)
+    dst = torch.zeros((41, 32), dtype=torch.bfloat16, device="cuda")
+    gather_scatter([src], None, n=40, n_dev=n_dev, dsts=[dst], tail=tail)          # idx None: rows 0..n-1
+    assert torch.equal(dst[:17], src[:17]) and torch.equal(dst[17], tail[0]) and not dst[18:].any()
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    bad = torch.tensor([0, 50, 3, -1], dtype=torch.int64, device="cuda")
+    out = torch.zeros((4, 32), dtype=torch.bfloat16, device="cuda")
+    gather_scatter([src], bad, dsts=[out], status=status)
+    assert status.item() == 2 and torch.equal(out[0], src[0]) and torch.equal(out[2], src[3]) and not out[1].any()
+    with pytest.raises(ValueError):
+        gather_scatter([src] * 9)
+    with pytest.raises(RuntimeError):
+        gather_scatter([src, _rand(50, 16, torch.bfloat16, 3)])
+    with pytest.raises(RuntimeError, match="CPU"):
+        gather_scatter([src.cpu()])
+
+
+@pytest.mark.parametrize("S,seed", [(1, 0), (37, 1), (1024, 2), (1025, 3), (20000, 4), (131072, 5)])
+def test_keep_positions_matches_torch(S, seed):
+    from vidcom2_amd.fused import keep_positions
+    g = torch.Generator().manual_seed(seed)
+    vm = torch.rand(S, generator=g) < 0.7
+    im = (~vm) & (torch.rand(S, generator=g) < 0.2)                 # image tokens: visual but not video
+    n_video = int(vm.sum())
+    K = n_video // 3
+    kept = torch.sort(torch.randperm(max(n_video, 1), generator=g)[:K]).values
+    flags = ~vm
+    flags[vm.nonzero().squeeze(-1)[kept]] = True
+    want_keep = flags.nonzero().squeeze(-1)
+    vis = vm | im
+    want_rows = flags[vis].nonzero().squeeze(-1)
+    keep, rows = keep_positions(vm.cuda(), kept.cuda(), n_video, vis.cuda(), int(vis.sum()))
+    assert torch.equal(keep.cpu(), want_keep) and torch.equal(rows.cpu(), want_rows)
+    keep2, rows2 = keep_positions(vm.cuda()[None], kept.cuda())                  # counts taken on the device
+    assert torch.equal(keep2.cpu(), want_keep) and rows2 is None
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_compress_with_tail_equals_compress_then_cat(dt):
+    import vidcom2_amd as V
+    x = synth.make(6, 196, 256, dt, 5).reshape(-1, 256).cuda()
+    nl = _rand(1, 256, dt, 8)
+    a = V.compress(x, 196, 0.25)
+    b = V.compress(x, 196, 0.25, tail=nl)
+    assert b.K == a.K and b.rows.shape[0] == a.K + 1
+    assert torch.equal(b.rows, torch.cat((a.rows, nl))) and torch.equal(a.global_idx, b.global_idx)
+
+
+def test_newline_fusion_returns_the_gather_buffer():
+    """The LLaVA one_token branch: rows.flatten -> torch.cat((rows, newline[None])) costs no second copy."""
+    from vidcom2_amd.models.llava import _CompressOnFlatten
+    import vidcom2_amd as V
+    D = 128
+    feats = synth.make(4, 196, D, torch.bfloat16, 3).reshape(4, 196, D).cuda()
+    nl = _rand(1, D, torch.bfloat16, 4)[0]
+    t = feats.as_subclass(_CompressOnFlatten)
+    t._vc2_newline = nl
+    rows = t.flatten(0, 1)
+    out = torch.cat((rows, nl[None].to(rows.device)), dim=0)
+    assert type(out) is torch.Tensor and out.data_ptr() == rows.data_ptr() and out.shape[0] == rows.shape[0] + 1
+    want = V.vidcom2_compression(feats.flatten(0, 1))
+    assert torch.equal(out, torch.cat((want, nl[None])))
+    # any other use behaves like a plain tensor
+    other = _rand(1, D, torch.bfloat16, 5)
+    o2 = torch.cat((rows, other), dim=0)
+    assert type(o2) is torch.Tensor and torch.equal(o2, torch.cat((want, other)))
+    assert type(rows + 1) is torch.Tensor and type(rows[:3]) is torch.Tensor

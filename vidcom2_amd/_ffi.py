@@ -37,6 +37,10 @@ _SIGNATURES = {
     "vc2_gather_rows": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "vc2_compress": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
                      _vp, _vp, _vp, _vp],
+    "vc2_compress_tail": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
+                          _vp, _vp, _vp, _vp, _i64, _vp],
+    "vc2_gather_scatter": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
+    "vc2_keep_positions": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "vc2_stat_block_frames": [],
     "vc2_chan_stats": [_vp, _i64, _i64, _i64, _i32, _i64, _i32, _vp, _sz, _vp, _vp],
     "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
@@ -48,7 +52,6 @@ _SIGNATURES = {
     "vc2_multi_scale_gaussian": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, ctypes.POINTER(ctypes.c_double), _i32, _vp, _vp],
     "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
     "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
-    "vc2_host_topk_order": [_vp, _i64, _i64, _i32, _vp],
     "vc2_set_mode": [_i32],
     "vc2_get_mode": [],
     "vc2_profile_enable": [_i32],

@@ -1729,24 +1729,110 @@ __global__ void k_map_indices(const int64_t* __restrict__ local, const int64_t* 
   }
 }
 
-// kept-row gather: dst[j,:] = src[idx[j],:], 16 B per lane; one workgroup per output row.
-__global__ __launch_bounds__(256) void k_gather_rows(const unsigned char* __restrict__ src,
-                                                     int64_t src_rows, int64_t row_bytes,
-                                                     const int64_t* __restrict__ idx,
-                                                     const int64_t* __restrict__ K_dev, int64_t cap,
-                                                     unsigned char* __restrict__ dst) {
-  const int64_t K = min(K_dev[0], cap);
-  for (int64_t j = blockIdx.x; j < K; j += gridDim.x) {
-    const int64_t r = idx[j];
-    if (r < 0 || r >= src_rows) continue;
-    const unsigned char* s = src + r * row_bytes;
-    unsigned char* d = dst + j * row_bytes;
-    if ((row_bytes & 15) == 0) {
-      const int64_t nv = row_bytes >> 4;
-      for (int64_t t = threadIdx.x; t < nv; t += blockDim.x)
-        reinterpret_cast<uint4*>(d)[t] = reinterpret_cast<const uint4*>(s)[t];
-    } else {
-      for (int64_t t = threadIdx.x; t < row_bytes; t += blockDim.x) d[t] = s[t];
+// Row gather / scatter (vidcom2.py:91,96 and the splice that follows it in the hooks): up to kGSMaxSrc tensors with
+// the SAME row length share one index list -- dst_t[dst_pos[j]] = src_t[idx[j]] for j < n -- and `tail_rows` extra
+// rows (the LLaVA newline embedding) land right behind the gathered ones in dst_0, all in one launch, so every kept
+// row is written once, at its final position.  One workgroup per (row, tensor), 16 B per lane; n is read on the
+// device when the selection kernel of the same stream produced it.  A row outside its tensor is skipped and reported
+// (bit 1 of *status).
+constexpr int kGSMaxSrc = 8;
+struct GSArgs {
+  const unsigned char* src[kGSMaxSrc];
+  unsigned char* dst[kGSMaxSrc];
+  int64_t src_rows[kGSMaxSrc], dst_rows[kGSMaxSrc];
+  int64_t row_bytes;
+  const int64_t* idx;        // [n] source rows (null: j)
+  const int64_t* n_dev;      // n on the device (null: n_max)
+  int64_t n_max;
+  const int64_t* dst_pos;    // [n] destination rows (null: dst_row0 + j)
+  int64_t dst_row0;
+  const unsigned char* tail; // rows appended to dst[0] behind the gathered ones (null: none)
+  int64_t tail_rows;
+  int* status;               // null, or a device word: |= 2 when a row index is out of range
+};
+__device__ __forceinline__ void copy_row(const unsigned char* __restrict__ s, unsigned char* __restrict__ d,
+                                         int64_t row_bytes) {
+  if ((row_bytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+    const int64_t nv = row_bytes >> 4;
+    for (int64_t t = threadIdx.x; t < nv; t += blockDim.x)
+      reinterpret_cast<uint4*>(d)[t] = reinterpret_cast<const uint4*>(s)[t];
+  } else {
+    for (int64_t t = threadIdx.x; t < row_bytes; t += blockDim.x) d[t] = s[t];
+  }
+}
+__global__ __launch_bounds__(256) void k_gather_rows(GSArgs a) {
+  const int t = blockIdx.y;
+  const int64_t n = a.n_dev ? min(a.n_dev[0], a.n_max) : a.n_max;
+  const int64_t total = n + (t == 0 ? a.tail_rows : 0);
+  for (int64_t j = blockIdx.x; j < total; j += gridDim.x) {
+    if (j < n) {
+      const int64_t r = a.idx ? a.idx[j] : j;
+      const int64_t d = a.dst_pos ? a.dst_pos[j] : a.dst_row0 + j;
+      if (r < 0 || r >= a.src_rows[t] || d < 0 || d >= a.dst_rows[t]) {
+        if (a.status && threadIdx.x == 0) atomicOr(a.status, 2);
+        continue;
+      }
+      copy_row(a.src[t] + r * a.row_bytes, a.dst[t] + d * a.row_bytes, a.row_bytes);
+    } else {                                                   // (t == 0) the tail rows, behind the last gathered one
+      const int64_t d = a.dst_row0 + j;
+      if (d >= a.dst_rows[0]) { if (a.status && threadIdx.x == 0) atomicOr(a.status, 2); continue; }
+      copy_row(a.tail + (j - n) * a.row_bytes, a.dst[0] + d * a.row_bytes, a.row_bytes);
+    }
+  }
+}
+
+// Sequence positions a pruned prefill keeps (hooks, reference models/qwen2_5_vl.py:153-160): every position that is
+// not a video token, plus the video tokens whose ordinal is in `kept` (ascending).  keep_out = those positions in
+// order; vis_rows_out (optional) = for the positions flagged in visual_mask, the ordinals (among them) that are
+// kept -- the rows Qwen3-VL's deep-stack tensors keep (qwen3_vl.py:141-149).  counts_out = {n_keep, n_vis_rows}.
+// One workgroup of 1024 threads, thread-contiguous chunks, two block scans.
+constexpr int kKeepNT = 1024;
+__global__ __launch_bounds__(kKeepNT) void k_keep_positions(const uint8_t* __restrict__ video_mask, int64_t S,
+                                                            const int64_t* __restrict__ kept,
+                                                            const int64_t* __restrict__ K_dev, int64_t K_max,
+                                                            const uint8_t* __restrict__ visual_mask,
+                                                            int64_t* __restrict__ keep_out,
+                                                            int64_t* __restrict__ vis_rows_out,
+                                                            int64_t* __restrict__ counts_out) {
+  __shared__ uint32_t xch[16];
+  constexpr int NW = kKeepNT / 64;
+  const int tid = threadIdx.x;
+  const int64_t K = K_dev ? min(K_dev[0], K_max) : K_max;
+  const int64_t E = (S + kKeepNT - 1) / kKeepNT;
+  const int64_t b = min(S, tid * E), e = min(S, b + E);
+  uint32_t nv = 0;
+  for (int64_t p = b; p < e; ++p) nv += video_mask[p] ? 1u : 0u;
+  uint32_t tot;
+  const int64_t ord0 = block_excl_scan<NW>(nv, xch, tot);        // video ordinal of my first video token
+  __syncthreads();
+  int64_t q;                                                     // first entry of kept[] that is >= ord0
+  { int64_t lo = 0, hi = K; while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (kept[m] < ord0) lo = m + 1; else hi = m; } q = lo; }
+  // pass 1: how many positions / visual rows do I keep, how many visual positions precede mine
+  uint32_t nk = 0, nvis = 0, nvk = 0;
+  {
+    int64_t o = ord0, qq = q;
+    for (int64_t p = b; p < e; ++p) {
+      bool keep = true;
+      if (video_mask[p]) { while (qq < K && kept[qq] < o) ++qq; keep = qq < K && kept[qq] == o; ++o; }
+      nk += keep ? 1u : 0u;
+      if (visual_mask && visual_mask[p]) { ++nvis; nvk += keep ? 1u : 0u; }
+    }
+  }
+  const int64_t k0 = block_excl_scan<NW>(nk, xch, tot);
+  const uint32_t tot_k = tot;
+  __syncthreads();
+  const int64_t v0 = block_excl_scan<NW>(nvis, xch, tot);
+  __syncthreads();
+  const int64_t vk0 = block_excl_scan<NW>(nvk, xch, tot);
+  const uint32_t tot_vk = tot;
+  if (tid == 0 && counts_out) { counts_out[0] = tot_k; counts_out[1] = tot_vk; }
+  {
+    int64_t o = ord0, qq = q, kk = k0, vv = v0, vk = vk0;
+    for (int64_t p = b; p < e; ++p) {
+      bool keep = true;
+      if (video_mask[p]) { while (qq < K && kept[qq] < o) ++qq; keep = qq < K && kept[qq] == o; ++o; }
+      if (keep && keep_out) keep_out[kk++] = p;
+      if (visual_mask && visual_mask[p]) { if (keep && vis_rows_out) vis_rows_out[vk++] = vv; ++vv; }
     }
   }
 }
@@ -2154,14 +2240,23 @@ int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_s
   return check_launch("select");
 }
 
-int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, const int64_t* idx,
-                       const int64_t* K_dev, int64_t cap, void* dst, hipStream_t st) {
-  if (cap <= 0) return VC2_OK;
-  const unsigned grid = unsigned(std::min<int64_t>(cap, 16384));
+int launch_gather(const GSArgs& a, int n_src, hipStream_t st) {
+  const int64_t rows = a.n_max + a.tail_rows;
+  if (rows <= 0 || n_src <= 0) return VC2_OK;
+  const unsigned grid = unsigned(std::min<int64_t>(rows, 16384));
   ProfScope ps_(KID_GATHER_ROWS, st);
-  hipLaunchKernelGGL(k_gather_rows, dim3(grid), dim3(256), 0, st, static_cast<const unsigned char*>(src),
-                     src_rows, D * ES, idx, K_dev, cap, static_cast<unsigned char*>(dst));
+  hipLaunchKernelGGL(k_gather_rows, dim3(grid, unsigned(n_src)), dim3(256), 0, st, a);
   return check_launch("gather_rows");
+}
+int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, const int64_t* idx,
+                       const int64_t* K_dev, int64_t cap, void* dst, hipStream_t st, const void* tail = nullptr,
+                       int64_t tail_rows = 0) {
+  GSArgs a{};
+  a.src[0] = static_cast<const unsigned char*>(src); a.dst[0] = static_cast<unsigned char*>(dst);
+  a.src_rows[0] = src_rows; a.dst_rows[0] = cap + tail_rows;
+  a.row_bytes = D * ES; a.idx = idx; a.n_dev = K_dev; a.n_max = cap;
+  a.tail = static_cast<const unsigned char*>(tail); a.tail_rows = tail ? tail_rows : 0;
+  return launch_gather(a, 1, st);
 }
 
 }  // namespace
@@ -2384,6 +2479,37 @@ int vc2_map_indices(const int64_t* local_idx, const int64_t* ks, const int64_t* 
   return check_launch("map_indices");
 }
 
+int vc2_gather_scatter(const void* const* srcs, const int64_t* src_rows, void* const* dsts, const int64_t* dst_rows,
+                       int n_src, int64_t D, int dtype, const int64_t* idx, const int64_t* n_dev, int64_t n_max,
+                       const int64_t* dst_pos, int64_t dst_row0, const void* tail, int64_t tail_rows, int32_t* status,
+                       void* stream) {
+  if (!srcs || !dsts || !src_rows || !dst_rows) return fail(VC2_ERR_ARG, "null pointer");
+  if (n_src < 1 || n_src > kGSMaxSrc) return fail(VC2_ERR_ARG, "n_src=%d outside [1, %d]", n_src, kGSMaxSrc);
+  if (dtype < 0 || dtype > 2 || D <= 0 || n_max < 0 || tail_rows < 0 || (tail_rows > 0 && !tail))
+    return fail(VC2_ERR_ARG, "bad gather_scatter arguments");
+  GSArgs a{};
+  for (int t = 0; t < n_src; ++t) {
+    if (!srcs[t] || !dsts[t]) return fail(VC2_ERR_ARG, "null tensor %d", t);
+    a.src[t] = static_cast<const unsigned char*>(srcs[t]); a.dst[t] = static_cast<unsigned char*>(dsts[t]);
+    a.src_rows[t] = src_rows[t]; a.dst_rows[t] = dst_rows[t];
+  }
+  a.row_bytes = D * (dtype == VC2_F32 ? 4 : 2);
+  a.idx = idx; a.n_dev = n_dev; a.n_max = n_max; a.dst_pos = dst_pos; a.dst_row0 = dst_row0;
+  a.tail = static_cast<const unsigned char*>(tail); a.tail_rows = tail ? tail_rows : 0; a.status = status;
+  return launch_gather(a, n_src, static_cast<hipStream_t>(stream));
+}
+
+int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept, const int64_t* K_dev, int64_t K_max,
+                       const uint8_t* visual_mask, int64_t* keep_out, int64_t* vis_rows_out, int64_t* counts_out,
+                       void* stream) {
+  if (!video_mask || S <= 0 || K_max < 0 || (K_max > 0 && !kept))      // (keep_out may be null when nothing is kept)
+    return fail(VC2_ERR_ARG, "bad keep_positions arguments");
+  if (S > (int64_t(1) << 31) - 1) return fail(VC2_ERR_UNSUPPORTED, "S=%lld positions", (long long)S);
+  hipLaunchKernelGGL(k_keep_positions, dim3(1), dim3(kKeepNT), 0, static_cast<hipStream_t>(stream), video_mask, S, kept,
+                     K_dev, K_max, visual_mask, keep_out, vis_rows_out, counts_out);
+  return check_launch("keep_positions");
+}
+
 int vc2_gather_rows(const void* src, int64_t src_rows, int64_t D, int dtype, const int64_t* idx,
                     const int64_t* K_dev, int64_t cap, void* dst, void* stream) {
   if (!src || !idx || !K_dev || !dst) return fail(VC2_ERR_ARG, "null pointer");
@@ -2395,7 +2521,16 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
                  int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
                  void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
                  void* stream) {
+  return vc2_compress_tail(x, F, N, D, dtype, base_scale, map_mode, grid_h, gather_src, gather_rows, ws, ws_bytes,
+                           out_rows, idx_out, cap, ks, K_out, v_T, f_T, nullptr, 0, stream);
+}
+
+int vc2_compress_tail(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale, int map_mode,
+                      int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
+                      void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
+                      const void* tail, int64_t tail_rows, void* stream) {
   if (!x || !idx_out || !ks || !K_out) return fail(VC2_ERR_ARG, "null pointer");
+  if (tail_rows < 0 || (tail_rows > 0 && !tail)) return fail(VC2_ERR_ARG, "tail_rows without tail");
   if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
   if (map_mode == VC2_MAP_GRID_VID && (grid_h <= 0 || grid_h * grid_h != N))
     return fail(VC2_ERR_ARG, "grid_vid mapping needs N == grid_h^2");
@@ -2438,7 +2573,7 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
   }
   if (rc) return rc;
   if (out_rows && gather_src)
-    rc = launch_gather_rows(gather_src, gather_rows, D, p.ES, idx_out, K_out, cap, out_rows, st);
+    rc = launch_gather_rows(gather_src, gather_rows, D, p.ES, idx_out, K_out, cap, out_rows, st, tail, tail_rows);
   return rc;
 }
 
@@ -2581,24 +2716,5 @@ int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {
   return 0;
 }
 #endif
-
-int vc2_host_topk_order(const float* v, int64_t n, int64_t k, int sorted, int64_t* idx) {
-  if (!v || !idx || n < 0 || k < 0 || k > n) return fail(VC2_ERR_ARG, "bad topk arguments");
-  if (k == 0) return VC2_OK;
-  using elem_t = std::pair<float, int64_t>;
-  std::vector<elem_t> q(static_cast<size_t>(n));
-  for (int64_t j = 0; j < n; ++j) q[size_t(j)] = {v[j], j};
-  auto less = [](const elem_t& a, const elem_t& b) {
-    return ((!std::isnan(a.first) && std::isnan(b.first)) || (a.first < b.first));
-  };
-  if (k * 64 <= n) {
-    std::partial_sort(q.begin(), q.begin() + k, q.end(), less);
-  } else {
-    std::nth_element(q.begin(), q.begin() + (k - 1), q.end(), less);
-    if (sorted) std::sort(q.begin(), q.begin() + (k - 1), less);
-  }
-  for (int64_t j = 0; j < k; ++j) idx[j] = q[size_t(j)].second;
-  return VC2_OK;
-}
 
 }  // extern "C"

@@ -1,0 +1,136 @@
+"""Hook-side fusion: kept rows written once, directly at their final positions.
+
+Host mirror of `vc2_gather_scatter` / `vc2_keep_positions` (include/vc2.h).  They replace, in the hooks,
+
+* `flat[global_idx]` followed by `torch.cat((rows, image_newline[None]))` (reference vidcom2.py:91 and
+  models/llava.py:160-168): one launch writes the K kept rows and the newline row behind them
+  (`CompressPlan(..., tail_rows=1)` does this inside the pass itself);
+* `inputs_embeds[:, keep_token_indices, :]` (models/qwen2_5_vl.py:153-182): `keep_positions` builds the kept
+  sequence positions on the device (no `nonzero` round trips), `gather_scatter` copies text and kept video rows in
+  one launch;
+* the N+1 gathers of Qwen3-VL's deep-stack (models/qwen3_vl.py:140-165): several tensors, one index list, one launch.
+
+Device tensors only: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ._ffi import DTYPE_CODE, check, lib, on_device, ptr, require_device, stream_ptr
+
+__all__ = ["gather_scatter", "keep_positions"]
+
+MAX_SOURCES = 8
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _i64_array(vs: Sequence[int]):
+    return (ctypes.c_int64 * len(vs))(*[int(v) for v in vs])
+
+
+def gather_scatter(srcs: Sequence[torch.Tensor], idx: Optional[torch.Tensor] = None, n: Optional[int] = None,
+                   n_dev: Optional[torch.Tensor] = None, dst_pos: Optional[torch.Tensor] = None,
+                   dsts: Optional[Sequence[torch.Tensor]] = None, dst_row0: int = 0,
+                   tail: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """dsts[t][dst_pos[j] or dst_row0 + j] = srcs[t][idx[j] or j] for j < n, every tensor in ONE launch; `tail`
+    rows ([m, D]) are appended to dsts[0] behind the gathered ones.
+
+    srcs: 2-D tensors [rows_t, D] of one dtype / feature size.  n defaults to len(idx) (or rows of srcs[0]); n_dev
+    (device int64[1]) caps it on the device.  dsts default to fresh [n + m, D] (first) / [n, D] tensors.
+    """
+    srcs = list(srcs)
+    if not 1 <= len(srcs) <= MAX_SOURCES:
+        raise ValueError(f"gather_scatter takes 1..{MAX_SOURCES} tensors, got {len(srcs)}")
+    x0 = srcs[0]
+    require_device(x0, "srcs[0]")
+    if x0.dtype not in DTYPE_CODE:
+        raise TypeError(f"unsupported dtype {x0.dtype} (fp32 / bf16 / fp16 only)")
+    D = x0.shape[-1]
+    for i, s in enumerate(srcs):
+        if s.dim() != 2 or s.shape[1] != D or s.dtype != x0.dtype or s.device != x0.device:
+            raise RuntimeError(f"srcs[{i}]: expected a [rows, {D}] {x0.dtype} tensor on {x0.device}, got "
+                               f"{tuple(s.shape)} {s.dtype} on {s.device}")
+    srcs = [s if s.is_contiguous() else s.contiguous() for s in srcs]
+    if idx is not None:
+        if idx.dtype != torch.int64 or idx.device != x0.device or idx.dim() != 1:
+            raise RuntimeError("idx must be a 1-D int64 tensor on the tensors' device")
+        idx = idx.contiguous()
+    if n is None:
+        n = int(idx.numel()) if idx is not None else int(x0.shape[0])
+    n = int(n)
+    if idx is not None and n > idx.numel():
+        raise IndexError(f"n={n} exceeds len(idx)={idx.numel()}")
+    if dst_pos is not None:
+        if dst_pos.dtype != torch.int64 or dst_pos.device != x0.device or dst_pos.numel() < n:
+            raise RuntimeError("dst_pos must be an int64 tensor of at least n entries on the tensors' device")
+        dst_pos = dst_pos.contiguous()
+    m = 0
+    if tail is not None:
+        if tail.dim() == 1:
+            tail = tail[None]
+        if tail.dim() != 2 or tail.shape[1] != D or tail.dtype != x0.dtype or tail.device != x0.device:
+            raise RuntimeError(f"tail must be [m, {D}] {x0.dtype} on {x0.device}")
+        tail = tail.contiguous()
+        m = int(tail.shape[0])
+    if dsts is None:
+        if dst_pos is not None:
+            raise ValueError("dst_pos needs caller-provided dsts")
+        dsts = [torch.empty((dst_row0 + n + (m if t == 0 else 0), D), dtype=x0.dtype, device=x0.device)
+                for t in range(len(srcs))]
+    else:
+        dsts = list(dsts)
+        if len(dsts) != len(srcs):
+            raise ValueError("one destination per source")
+        for i, d in enumerate(dsts):
+            if d.dim() != 2 or d.shape[1] != D or d.dtype != x0.dtype or d.device != x0.device or not d.is_contiguous():
+                raise RuntimeError(f"dsts[{i}] must be a contiguous [rows, {D}] {x0.dtype} tensor on {x0.device}")
+    with on_device(x0.device):
+        rc = lib().vc2_gather_scatter(_ptr_array(srcs), _i64_array([s.shape[0] for s in srcs]), _ptr_array(dsts),
+                                      _i64_array([d.shape[0] for d in dsts]), len(srcs), D, DTYPE_CODE[x0.dtype],
+                                      ptr(idx), ptr(n_dev), n, ptr(dst_pos), int(dst_row0), ptr(tail), m, ptr(status),
+                                      stream_ptr(x0.device))
+    check(rc, "vc2_gather_scatter")
+    return dsts
+
+
+def keep_positions(video_mask: torch.Tensor, kept: torch.Tensor, n_video: Optional[int] = None,
+                   visual_mask: Optional[torch.Tensor] = None,
+                   n_visual: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Sorted sequence positions a pruned prefill keeps: every non-video position plus the video tokens whose
+    ordinal is in `kept` (sorted int64).  With `visual_mask` also the rows the deep-stack tensors keep (ordinals among
+    the visual positions).  n_video / n_visual = number of True entries of video_mask / visual_mask (known to the
+    hooks: the row counts of the video embeds / deep-stack tensors); each one omitted costs a sync."""
+    vm = video_mask.reshape(-1)
+    vm = vm.view(torch.uint8) if vm.dtype == torch.bool else vm.to(torch.uint8)
+    vm = vm.contiguous()
+    require_device(vm, "video_mask")
+    S = int(vm.numel())
+    kept = kept.to(device=vm.device, dtype=torch.int64).contiguous()
+    K = int(kept.numel())
+    if n_video is None:
+        n_video = int(vm.sum().item())
+    n_keep = S - int(n_video) + K
+    keep = torch.empty(n_keep, dtype=torch.int64, device=vm.device)
+    vis = vis_rows = None
+    if visual_mask is not None:
+        vis = visual_mask.reshape(-1)
+        vis = (vis.view(torch.uint8) if vis.dtype == torch.bool else vis.to(torch.uint8)).contiguous()
+        if vis.numel() != S or vis.device != vm.device:
+            raise RuntimeError("visual_mask must cover the same positions as video_mask")
+        vis_rows = torch.empty(S, dtype=torch.int64, device=vm.device)
+    counts = torch.empty(2, dtype=torch.int64, device=vm.device)
+    with on_device(vm.device):
+        rc = lib().vc2_keep_positions(ptr(vm), S, ptr(kept), None, K, ptr(vis), ptr(keep), ptr(vis_rows), ptr(counts),
+                                      stream_ptr(vm.device))
+    check(rc, "vc2_keep_positions")
+    if vis_rows is not None:
+        # video tokens are visual tokens: the kept visual rows are the non-video visual ones plus the K kept
+        n_rows = int(counts[1].item()) if n_visual is None else int(n_visual) - int(n_video) + K
+        vis_rows = vis_rows[:n_rows]
+    return keep, vis_rows

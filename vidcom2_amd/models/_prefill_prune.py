@@ -44,6 +44,22 @@ def _prune_attention(attn, keep: torch.Tensor):
     return attn
 
 
+def _fusable(embeds, kept, video_embeds, deep) -> bool:
+    """The device kernels take one GPU, fp32 / bf16 / fp16 rows and (deep-stack) up to 8 same-shaped tensors."""
+    if not (embeds.is_cuda and torch.is_tensor(kept) and kept.is_cuda and torch.is_tensor(video_embeds)):
+        return False
+    if embeds.dtype not in (torch.float32, torch.bfloat16, torch.float16) or embeds.dim() != 3:
+        return False
+    if deep is not None:
+        deep = list(deep)
+        if len(deep) > 8 or any((not torch.is_tensor(d)) or d.dim() != 2 or d.device != embeds.device
+                                or d.dtype != deep[0].dtype or d.shape != deep[0].shape for d in deep):
+            return False
+        if deep and deep[0].dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            return False
+    return True
+
+
 class _LanguageModelShim:
     """Stands in for `self.language_model` during one forward; everything but the call itself
     (attributes, sub-modules, config) is the real module's."""
@@ -63,11 +79,26 @@ class _LanguageModelShim:
             kept = self._choose(st.video_embeds)
             if kept is not None:
                 vm = st.video_mask[0].to(embeds.device)
-                video_pos = vm.nonzero(as_tuple=False).squeeze(-1)
-                keep_flags = ~vm
-                keep_flags[video_pos[kept]] = True
-                keep = keep_flags.nonzero(as_tuple=False).squeeze(-1)
-                kwargs["inputs_embeds"] = embeds[:, keep, :]
+                vpm = kwargs.get("visual_pos_masks")
+                deep = kwargs.get("deepstack_visual_embeds") if torch.is_tensor(vpm) else None
+                fused = _fusable(embeds, kept, st.video_embeds, deep)
+                vis_rows = None
+                if fused:
+                    # device-side keep list + ONE launch for text rows and kept video rows (vc2_keep_positions,
+                    # vc2_gather_scatter): no nonzero() round trips
+                    from ..fused import gather_scatter, keep_positions
+                    n_video = int(st.video_embeds.shape[0])
+                    want_vis = deep is not None and len(deep) > 0
+                    keep, vis_rows = keep_positions(vm, kept, n_video, vpm[0].to(embeds.device) if want_vis else None,
+                                                    int(deep[0].shape[0]) if want_vis else None)
+                    keep_flags = None
+                    kwargs["inputs_embeds"] = gather_scatter([embeds[0]], keep)[0][None]
+                else:
+                    video_pos = vm.nonzero(as_tuple=False).squeeze(-1)
+                    keep_flags = ~vm
+                    keep_flags[video_pos[kept]] = True
+                    keep = keep_flags.nonzero(as_tuple=False).squeeze(-1)
+                    kwargs["inputs_embeds"] = embeds[:, keep, :]
                 if torch.is_tensor(kwargs.get("input_ids")):
                     kwargs["input_ids"] = kwargs["input_ids"][:, keep]
                 if "attention_mask" in kwargs:
@@ -96,12 +127,18 @@ class _LanguageModelShim:
                     kwargs["cache_position"] = cp[: keep.numel()]       # prefill: slots 0 .. S'-1 of the KV cache
                 # Qwen3-VL deepstack: per-layer features of the visual tokens, row i <-> i-th True of the mask
                 # (models/qwen3_vl.py:141-149, 200-226 of the reference)
-                vpm = kwargs.get("visual_pos_masks")
                 if torch.is_tensor(vpm):
-                    rows = keep_flags[vpm[0].to(keep_flags.device)]
-                    deep = kwargs.get("deepstack_visual_embeds")
-                    if deep is not None:
-                        kwargs["deepstack_visual_embeds"] = [d[rows.to(d.device)] for d in deep]
+                    if vis_rows is not None:
+                        # the deep-stack tensors share ONE index list: one launch for all of them
+                        kwargs["deepstack_visual_embeds"] = gather_scatter(list(deep), vis_rows)
+                    else:
+                        if keep_flags is None:
+                            keep_flags = torch.zeros(vm.numel(), dtype=torch.bool, device=keep.device)
+                            keep_flags[keep] = True
+                        rows = keep_flags[vpm[0].to(keep_flags.device)]
+                        deep_any = kwargs.get("deepstack_visual_embeds")
+                        if deep_any is not None:
+                            kwargs["deepstack_visual_embeds"] = [d[rows.to(d.device)] for d in deep_any]
                     kwargs["visual_pos_masks"] = vpm[:, keep.to(vpm.device)]
                 st.kept_video, st.keep_token_indices, st.pruned = kept, keep, True
         return self._real(*args, **kwargs)

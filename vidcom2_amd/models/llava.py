@@ -31,6 +31,29 @@ from ._intercept import original_method, retention_ratio, shadow
 __all__ = ["cus_prepare_inputs_labels_for_multimodal"]
 
 
+class _NewlineFused(torch.Tensor):
+    """The K kept rows as a view of a `[K + 1, D]` buffer whose last row already holds the model's newline
+    embedding (written by the gather launch, `vc2_compress_tail`).  The caller's next statement is
+    `torch.cat((rows, self.model.image_newline[None].to(rows.device)), dim=0)` (models/llava.py:160-168 of the
+    reference): that exact call returns the buffer -- no second copy of the kept rows.  Anything else sees a plain
+    tensor."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.cat and args and isinstance(args[0], (tuple, list)) and len(args[0]) == 2:
+            rows, nl = args[0]
+            dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
+            fused = getattr(rows, "_vc2_fused", None)
+            if (isinstance(rows, cls) and fused is not None and dim == 0 and torch.is_tensor(nl)
+                    and not isinstance(nl, cls) and nl.shape == (1, rows.shape[1]) and nl.dtype == rows.dtype
+                    and nl.device == rows.device and nl.data_ptr() == fused[1]):
+                return fused[0]
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return out.as_subclass(torch.Tensor) if isinstance(out, cls) else out
+
+
 class _CompressOnFlatten(torch.Tensor):
     """Pooled video features `[F, N, D]` whose `.flatten(0, 1)` is the compressed token list."""
 
@@ -40,6 +63,15 @@ class _CompressOnFlatten(torch.Tensor):
         plain = self.as_subclass(torch.Tensor)
         flat = plain.flatten(*args, **kwargs)
         if args == (0, 1) and not kwargs and plain.dim() == 3:
+            newline = getattr(self, "_vc2_newline", None)
+            if newline is not None and flat.is_cuda and newline.device == flat.device and newline.dtype == flat.dtype \
+                    and newline.dim() == 1 and newline.shape[0] == flat.shape[1] and newline.is_contiguous():
+                # kept rows + the newline row behind them in ONE gather launch
+                from ..vidcom2 import MODEL_SPECS, compress
+                res = compress(flat, MODEL_SPECS["llava_ov"]["tpf"], retention_ratio(), tail=newline[None])
+                rows = res.rows[: res.K].as_subclass(_NewlineFused)
+                rows._vc2_fused = (res.rows, newline.data_ptr())
+                return rows
             return vidcom2_compression(flat, base_scale=retention_ratio())
         return flat
 
@@ -74,8 +106,14 @@ def cus_prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, atte
         elif newline == "one_token" and "unpad" in merge_type:
             pool_inner = self.get_2dPool
 
+            inner_model = getattr(self, "model", None)
+            newline_vec = getattr(inner_model, "image_newline", None) if inner_model is not None else None
+
             def get_2dPool(image_feature, *args, **kwargs):
-                return pool_inner(image_feature, *args, **kwargs).as_subclass(_CompressOnFlatten)
+                out = pool_inner(image_feature, *args, **kwargs).as_subclass(_CompressOnFlatten)
+                if torch.is_tensor(newline_vec):
+                    out._vc2_newline = newline_vec.detach()
+                return out
 
             patches["get_2dPool"] = get_2dPool
 

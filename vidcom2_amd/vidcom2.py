@@ -88,7 +88,8 @@ class CompressPlan:
     """
 
     def __init__(self, F: int, N: int, D: int, dtype, device, base_scale: float = 0.25,
-                 mapper: str = "linear", grid_h: int = 0, want_scores: bool = False, gather: bool = True):
+                 mapper: str = "linear", grid_h: int = 0, want_scores: bool = False, gather: bool = True,
+                 tail_rows: int = 0):
         if mapper not in ("linear", "grid_vid"):
             raise ValueError(f"unknown mapper {mapper!r}")
         self.F, self.N, self.D, self.dtype, self.device = int(F), int(N), int(D), dtype, torch.device(device)
@@ -104,18 +105,27 @@ class CompressPlan:
         self.idx = torch.empty(cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(self.F, dtype=torch.int64, device=self.device)
         self.kout = torch.empty(2, dtype=torch.int64, device=self.device)    # both words written by every pass
-        self.rows = torch.empty((cap, self.D), dtype=dtype, device=self.device) if gather else None
+        # tail_rows: extra rows (LLaVA's newline embedding) the gather launch appends behind the kept ones
+        self.tail_rows = int(tail_rows) if gather else 0
+        self.rows = torch.empty((cap + self.tail_rows, self.D), dtype=dtype, device=self.device) if gather else None
         self.v = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
         self.f = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
 
-    def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None) -> None:
+    def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None,
+                tail: Optional[torch.Tensor] = None) -> None:
         src = flat if gather_src is None else gather_src
+        if self.tail_rows:
+            if tail is None or tail.shape != (self.tail_rows, self.D) or tail.dtype != self.dtype \
+                    or tail.device != self.device:
+                raise RuntimeError(f"tail must be [{self.tail_rows}, {self.D}] {self.dtype} on {self.device}")
+            tail = tail.contiguous()
         with on_device(self.device):
-            rc = lib().vc2_compress(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
-                                    self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
-                                    src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
-                                    self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
-                                    stream_ptr(self.device))
+            rc = lib().vc2_compress_tail(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
+                                         self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
+                                         src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
+                                         self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
+                                         ptr(tail if self.tail_rows else None), self.tail_rows,
+                                         stream_ptr(self.device))
         check(rc, "vc2_compress")
 
     def finish(self) -> CompressionResult:
@@ -123,15 +133,17 @@ class CompressPlan:
         if overflow:
             raise RuntimeError(f"vidcom2_amd: kept-token capacity {self.cap} exceeded (K={K}); "
                                "vc2_kept_capacity bound violated -- please report")
-        rows = self.rows[:K] if self.rows is not None else None
+        rows = self.rows[:K + self.tail_rows] if self.rows is not None else None      # (kept rows, then the tail)
         return CompressionResult(rows, self.idx[:K], self.ks, int(K), self.v, self.f)
 
 
 @_guarded
 def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, mapper: str = "linear",
              grid_h: int = 0, img_feat: Optional[torch.Tensor] = None, want_scores: bool = False,
-             gather: bool = True) -> CompressionResult:
-    """One whole pass: feature tensor resident in HBM -> kept rows + indices + budgets."""
+             gather: bool = True, tail: Optional[torch.Tensor] = None) -> CompressionResult:
+    """One whole pass: feature tensor resident in HBM -> kept rows + indices + budgets.
+    tail ([m, D], e.g. LLaVA's newline embedding): written behind the kept rows by the gather launch itself;
+    `rows` is then [K + m, D]."""
     x = _prep(flattened_feat, "flattened_feat")
     if x.dim() != 2:
         raise RuntimeError(f"flattened_feat must be 2-D [frames*tokens, dim], got {tuple(x.shape)}")
@@ -152,8 +164,11 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
             # the reference fails in img[_map_grid_vid(...)] (vidcom2.py:96) with an IndexError
             raise IndexError(f"index {need - 1} is out of bounds for dimension 0 with size {src.shape[0]}"
                              if src.dim() == 2 else "img_feat must be 2-D [rows, dim]")
-    plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather)
-    plan.enqueue(x, src)
+    if tail is not None:
+        tail = _prep(tail if tail.dim() == 2 else tail[None], "tail")
+    plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather,
+                        tail_rows=0 if tail is None else tail.shape[0])
+    plan.enqueue(x, src, tail)
     return plan.finish()
 
 
