@@ -137,14 +137,35 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
                  void* ws, size_t ws_bytes, void* out_rows, int64_t* idx_out, int64_t cap,
                  int64_t* ks, int64_t* K_out, void* v_T, void* f_T, void* stream);
 
-/* The same pass with `tail_rows` extra rows (T[tail_rows, D], e.g. LLaVA's image_newline embedding,
- * reference models/llava.py:160-168) written right behind the K kept rows by the gather launch itself:
- * out_rows is T[cap + tail_rows, D] and rows [0, K + tail_rows) are valid afterwards. */
-int vc2_compress_tail(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale,
+/* The same pass with
+ *  - `tail_rows` extra rows (T[tail_rows, D], e.g. LLaVA's image_newline embedding, reference
+ *    models/llava.py:160-168) written right behind the K kept rows by the gather launch itself: out_rows is
+ *    T[cap + tail_rows, D] and rows [0, K + tail_rows) are valid afterwards;
+ *  - flags & VC2_FLAG_HAVE_STATS: sweep 1 is skipped -- ws already holds the channel-statistics partials of x,
+ *    left there by vc2_pool_stats on the same stream (same F, N, D, dtype). */
+#define VC2_FLAG_HAVE_STATS 1
+int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale,
                       int map_mode, int64_t grid_h, const void* gather_src, int64_t gather_rows,
                       void* ws, size_t ws_bytes, void* out_rows, int64_t* idx_out, int64_t cap,
                       int64_t* ks, int64_t* K_out, void* v_T, void* f_T, const void* tail, int64_t tail_rows,
-                      void* stream);
+                      int flags, void* stream);
+
+/* ---- upstream fusion: LLaVA's get_2dPool (llava/model/llava_arch.py:171-190) + sweep 1 -------
+ * xin T[F, H*W, D] (the projector output, token-major) -> x_out T[F, h*w, D] = its 2x2 pool, and the sweep-1
+ * channel-statistics partials of x_out in ws (workspace of vc2_workspace_bytes(F, h*w, D)): the pooled tensor is
+ * written once and vc2_compress_ex(..., VC2_FLAG_HAVE_STATS) reads it only twice more.
+ *   VC2_POOL_AVG       avg_pool2d(kernel 2, stride 2): h = H/2, w = W/2; bit-exact to torch (fp32 sum in window order, / 4)
+ *   VC2_POOL_MAX       max_pool2d(2): bit-exact (NaN propagates like torch)
+ *   VC2_POOL_BILINEAR  interpolate(size=ceil(H/2) x ceil(W/2), mode="bilinear", align_corners=False): ATen's source
+ *                      index / lambda arithmetic and its SCALAR loop's fma order; ATen's vector loop (C >= 16 on x86)
+ *                      contracts differently, so outputs can differ from torch in the last fp32 bit before the
+ *                      rounding to T (measured: ~1e-4 of bf16 outputs by one bf16 ulp).  Not used by default. */
+#define VC2_POOL_AVG 1
+#define VC2_POOL_MAX 2
+#define VC2_POOL_BILINEAR 3
+int vc2_pool_out_tokens(int64_t H, int64_t W, int mode, int64_t* h_out, int64_t* w_out);
+int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, int dtype, int mode, void* ws,
+                   size_t ws_bytes, void* x_out, void* stream);
 
 /* ---- hook-side fusion: kept rows written once, at their final positions ------------
  * vc2_gather_scatter: up to 8 tensors T[src_rows[t], D] share ONE index list:

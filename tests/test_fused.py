@@ -110,3 +110,97 @@ def test_newline_fusion_returns_the_gather_buffer():
     o2 = torch.cat((rows, other), dim=0)
     assert type(o2) is torch.Tensor and torch.equal(o2, torch.cat((want, other)))
     assert type(rows + 1) is torch.Tensor and type(rows[:3]) is torch.Tensor
+
+
+# ---- f3: get_2dPool fused with sweep 1 ------------------------------------------------------------------------
+def _torch_pool(x, H, W, mode):
+    """What LLaVA's get_2dPool computes (llava_arch.py:171-190), on the CPU with torch's own kernels."""
+    import math
+    import torch.nn.functional as Fn
+    F, _, D = x.shape
+    t = x.cpu().view(F, H, W, D).permute(0, 3, 1, 2).contiguous()
+    if mode == "average":
+        t = Fn.avg_pool2d(t, 2)
+    elif mode == "max":
+        t = Fn.max_pool2d(t, 2)
+    else:
+        t = Fn.interpolate(t, size=[math.ceil(H / 2), math.ceil(W / 2)], mode="bilinear")
+    return t.permute(0, 2, 3, 1).reshape(F, -1, D)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("mode", ["average", "max"])
+@pytest.mark.parametrize("H,D", [(27, 256), (28, 3584), (6, 100)])
+def test_pool_stats_bits_match_torch_pooling(dt, mode, H, D):
+    from vidcom2_amd.fused import pool_stats
+    g = torch.Generator().manual_seed(H + D)
+    x = torch.randn(5, H * H, D, generator=g).to(dt)
+    if mode == "max":
+        x[0, 3, 5] = float("nan")
+    out, ws = pool_stats(x.cuda(), H, H, mode)
+    want = _torch_pool(x, H, H, mode)
+    assert out.shape == want.shape
+    assert torch.equal(out.cpu().view(torch.int16 if dt != torch.float32 else torch.int32),
+                       want.view(torch.int16 if dt != torch.float32 else torch.int32))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pool_stats_bilinear_is_within_one_ulp_of_torch(dt):
+    from vidcom2_amd.fused import pool_stats
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 27 * 27, 256, generator=g).to(dt)
+    out, _ = pool_stats(x.cuda(), 27, 27, "bilinear")
+    want = _torch_pool(x, 27, 27, "bilinear")
+    assert out.shape == (4, 196, 256)
+    a, b = out.cpu().float(), want.float()
+    tol = {torch.float32: 2.0 ** -22, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dt]
+    assert ((a - b).abs() <= tol * b.abs().clamp_min(1.0)).all()          # one ulp of T at most
+    if dt != torch.float32:
+        assert (a != b).float().mean().item() < 1e-3                      # and almost never
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("mode,H", [("average", 28), ("max", 28), ("bilinear", 27)])
+def test_pass_with_fused_stats_equals_pass_on_the_pooled_tensor(dt, mode, H):
+    import vidcom2_amd as V
+    from vidcom2_amd.fused import pool_stats
+    D = 512
+    x = synth.make(8, H * H, D, dt, 11).reshape(8, H * H, D).cuda()
+    pooled, ws = pool_stats(x, H, H, mode)
+    assert pooled.shape[1] == 196
+    flat = pooled.flatten(0, 1)
+    a = V.compress(flat, 196, 0.25, want_scores=True)
+    b = V.compress(flat, 196, 0.25, want_scores=True, stats_ws=ws)
+    assert a.K == b.K and torch.equal(a.global_idx, b.global_idx) and torch.equal(a.ks, b.ks)
+    assert torch.equal(a.rows, b.rows) and torch.equal(a.v_score, b.v_score) and torch.equal(a.f_score, b.f_score)
+
+
+@pytest.mark.parametrize("newline,side,mode", [("one_token", 28, "average"), ("grid", 26, "average"),
+                                               ("grid", 27, "max")])
+def test_llava_hook_with_fused_pooling_equals_unfused(newline, side, mode, monkeypatch):
+    """The hook with get_2dPool + sweep 1 fused gives the same prompt embeddings as with the model's own pooling."""
+    import types
+    import _stub_models as S
+    from vidcom2_amd.models.llava import cus_prepare_inputs_labels_for_multimodal as hook
+    D, F = 256, 6
+
+    class Pooling(S.StubLlava):
+        def get_2dPool(self, image_feature, stride=2):
+            return _torch_pool(image_feature, side, side, self.config.mm_spatial_pool_mode).to(image_feature.device)
+
+    def run(knob):
+        monkeypatch.setenv("VC2_FUSED_POOL", knob)
+        monkeypatch.setenv("R_RATIO", "0.25")
+        m = Pooling(D, torch.bfloat16, "cuda", 3, "spatial_unpad", newline)
+        m.config.mm_spatial_pool_mode = mode
+        m.model._tower.num_patches_per_side = side
+        feats = synth.make(F, side * side, D, torch.bfloat16, 21).reshape(F, side * side, D, 1).cuda()
+        ids = torch.tensor([[5, 6, S.IMAGE_TOKEN_INDEX, 7]], device="cuda")
+        m.prepare_inputs_labels_for_multimodal = types.MethodType(hook, m)
+        return m.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, [feats], ["video"], None)[4]
+
+    if newline == "grid":
+        # llava_vid frames are 13 x 13 = 169 tokens
+        assert side // 2 == 13
+    fused, plain = run(""), run("off")
+    assert fused.shape == plain.shape and torch.equal(fused, plain)

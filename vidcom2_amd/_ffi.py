@@ -37,8 +37,10 @@ _SIGNATURES = {
     "vc2_gather_rows": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _vp],
     "vc2_compress": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
                      _vp, _vp, _vp, _vp],
-    "vc2_compress_tail": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
-                          _vp, _vp, _vp, _vp, _i64, _vp],
+    "vc2_compress_ex": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
+                        _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "vc2_pool_out_tokens": [_i64, _i64, _i32, _vp, _vp],
+    "vc2_pool_stats": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _vp],
     "vc2_gather_scatter": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
     "vc2_keep_positions": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "vc2_stat_block_frames": [],

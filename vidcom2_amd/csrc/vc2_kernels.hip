@@ -70,11 +70,88 @@ constexpr int kStatsWaves = 4;
 // video is processed whole or frame-sharded over 1, 2, 4 or 8 ranks.
 constexpr int kStatBlockFrames = 8;
 
-template <int DT, int VEC, int U>
+// POOL != 0: the rows are not read but MADE here -- row (f, oy, ox) of the pooled video is the
+// 2x2 pool of four rows of the un-pooled projector output xin[F][H*W][D] (LLaVA's get_2dPool, reference
+// llava/model/llava_arch.py:171-190, in the token-major layout it permutes from and back to) -- and stored to x on the
+// way, so the pooled tensor is written once and its channel statistics cost no sweep of their own.
+//   1 average: ((a + b) + c) + d in fp32, / 4, one rounding to T      (torch avg_pool2d's accumulation order)
+//   2 max
+//   3 bilinear to ceil(H/2) x ceil(W/2), align_corners=False: index / weights as ATen's
+//     compute_source_index_and_lambda (fma'd source index), out = fma(w11,d, fma(w10,c, fma(w00,a, w01*b))), one
+//     rounding to T -- the arithmetic of ATen's scalar loop; its vector loop contracts differently (last fp32 bit).
+struct PoolSrc { const void* xin; int H, W, h, w, mode; };
+
+template <int DT, int VEC>
+__device__ __forceinline__ void pooled_row(const PoolSrc& ps, int64_t rr, int N, int D, int cv, float (&v)[VEC]) {
+  const int64_t f = rr / N;
+  const int t = int(rr - f * N), oy = t / ps.w, ox = t - oy * ps.w;
+  int y0, y1, x0, x1;
+  float w00 = 0.f, w01 = 0.f, w10 = 0.f, w11 = 0.f;
+  if (ps.mode == 3) {
+    auto src = [](int in, int out, int i, int& i0, int& i1, float& l0, float& l1) {
+      const float scale = float(in) / float(out);
+      float real = __builtin_fmaf(scale, float(i) + 0.5f, -0.5f);
+      real = real < 0.f ? 0.f : real;
+      i0 = min(int(floorf(real)), in - 1);
+      l1 = fminf(fmaxf(real - float(i0), 0.f), 1.f);
+      l0 = 1.f - l1;
+      i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    };
+    float ly0, ly1, lx0, lx1;
+    src(ps.H, ps.h, oy, y0, y1, ly0, ly1);
+    src(ps.W, ps.w, ox, x0, x1, lx0, lx1);
+    w00 = ly0 * lx0; w01 = ly0 * lx1; w10 = ly1 * lx0; w11 = ly1 * lx1;
+  } else {
+    y0 = 2 * oy; y1 = y0 + 1; x0 = 2 * ox; x1 = x0 + 1;
+  }
+  const int64_t fb = f * ps.H * ps.W;
+  float a[VEC], b[VEC], c[VEC], d[VEC];
+  const RawVec<DT, VEC> ra = load_raw<DT, VEC>(ps.xin, (fb + int64_t(y0) * ps.W + x0) * D + int64_t(cv) * VEC);
+  const RawVec<DT, VEC> rb = load_raw<DT, VEC>(ps.xin, (fb + int64_t(y0) * ps.W + x1) * D + int64_t(cv) * VEC);
+  const RawVec<DT, VEC> rc = load_raw<DT, VEC>(ps.xin, (fb + int64_t(y1) * ps.W + x0) * D + int64_t(cv) * VEC);
+  const RawVec<DT, VEC> rd = load_raw<DT, VEC>(ps.xin, (fb + int64_t(y1) * ps.W + x1) * D + int64_t(cv) * VEC);
+  unpack<DT, VEC>(ra, a); unpack<DT, VEC>(rb, b); unpack<DT, VEC>(rc, c); unpack<DT, VEC>(rd, d);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float o;
+    if (ps.mode == 1) o = (((a[j] + b[j]) + c[j]) + d[j]) / 4.f;
+    else if (ps.mode == 2) {
+      // torch max_pool2d: (val > max) || isnan(val) in scan order
+      o = a[j];
+      if (b[j] > o || b[j] != b[j]) o = b[j];
+      if (c[j] > o || c[j] != c[j]) o = c[j];
+      if (d[j] > o || d[j] != d[j]) o = d[j];
+    } else {
+      o = w01 * b[j];
+      o = __builtin_fmaf(w00, a[j], o); o = __builtin_fmaf(w10, c[j], o); o = __builtin_fmaf(w11, d[j], o);
+    }
+    v[j] = rnT<DT>(o);
+  }
+}
+template <int DT, int VEC>
+__device__ __forceinline__ void store_row_T(void* x, int64_t elem, const float (&v)[VEC]) {   // v: T-representable
+  if constexpr (VEC == 1) {
+    stT<DT>(x, elem, v[0]);
+  } else if constexpr (DT == VC2_F32) {
+    *reinterpret_cast<float4*>(static_cast<float*>(x) + elem) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (DT == VC2_BF16) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (__float_as_uint(v[2 * i]) >> 16) | (__float_as_uint(v[2 * i + 1]) & 0xFFFF0000u);
+    *reinterpret_cast<uint4*>(static_cast<uint16_t*>(x) + elem) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    union { uint4 u; _Float16 h[8]; } c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.h[i] = static_cast<_Float16>(v[i]);
+    *reinterpret_cast<uint4*>(static_cast<uint16_t*>(x) + elem) = c.u;
+  }
+}
+
+template <int DT, int VEC, int U, int POOL>
 __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __restrict__ x, int64_t R,
                                                                  int D, int CV, int N, int splits,
                                                                  int rows_per_group, int block_frames,
-                                                                 double* __restrict__ part) {
+                                                                 double* __restrict__ part, PoolSrc pool) {
   __shared__ double sm[kStatsWaves][2 * VEC][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cv = blockIdx.x * 64 + lane;
@@ -88,10 +165,24 @@ __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __r
   for (int j = 0; j < VEC; ++j) { s[j] = 0.0; q[j] = 0.0; }
   if (active) {
     float kf[VEC];
-    unpack<DT, VEC>(load_raw<DT, VEC>(x, rK * D + int64_t(cv) * VEC), kf);
+    if constexpr (POOL != 0) pooled_row<DT, VEC>(pool, rK, N, D, cv, kf);
+    else unpack<DT, VEC>(load_raw<DT, VEC>(x, rK * D + int64_t(cv) * VEC), kf);
     double K[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) K[j] = double(kf[j]);
+    if constexpr (POOL != 0) {
+      for (int64_t rr = r0 + wave; rr < r1; rr += kStatsWaves) {
+        float v[VEC];
+        pooled_row<DT, VEC>(pool, rr, N, D, cv, v);
+        store_row_T<DT, VEC>(const_cast<void*>(x), rr * D + int64_t(cv) * VEC, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const double d = double(v[j]) - K[j];
+          s[j] += d;
+          q[j] = fma(d, d, q[j]);
+        }
+      }
+    } else
     for (int64_t r = r0 + wave; r < r1; r += int64_t(kStatsWaves) * U) {
       RawVec<DT, VEC> raw[U];
 #pragma unroll
@@ -1953,7 +2044,7 @@ enum KernelId { KID_STATS = 0, KID_STATS_REDUCE, KID_CHAN_SELECT, KID_NORM_COLSU
                 KID_CENTRE_FIX, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"k_chan_stats", "k_stats_reduce", "k_chan_select", "k_norm_colsum",
                                              "k_centres", "k_dist", "k_token_epilogue", "k_scales", "k_ks(unused)",
-                                             "k_select", "k_gather_rows", "k_norm_fix", "k_chan_select(order; side stream)",
+                                             "k_select", "k_gather_rows", "k_norm_fix", "k_chan_order",
                                              "k_dist_fix", "k_centre_fix"};
 struct ProfRec { int id; hipEvent_t a, b; };
 bool g_prof = false;                // (bench-only; the record list is mutex-protected)
@@ -1993,14 +2084,28 @@ int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
 // sweep 1 -> (mean, M2) stats and/or var
 // sweep 1 -> per stat block (mean, M2) in bstats[NB][2][D] (ws when bstats == nullptr), and -- var_f32 / var_T --
 // the variance of THESE rows reduced from them (single-rank case)
-int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, void* var_T, float* var_f32,
-                      hipStream_t st, bool zero_queue_counters = false) {
+// sweep 1 alone: the per-group partials of x into ws (pool.xin != null: x is produced here, see k_chan_stats)
+int launch_stats_sweep(const Plan& p, const void* x, void* ws, const PoolSrc& pool, hipStream_t st) {
   double* part = wsp<double>(ws, p.o_part_stats);
   if (p.G > 65535) return fail(VC2_ERR_UNSUPPORTED, "too many sweep-1 row groups (%d)", p.G);
   dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
-  { ProfScope ps_(KID_STATS, st);
-  VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8>), grid, dim3(kStatsWaves * 64), 0, st, x,
-                                          p.R, int(p.D), p.CV, int(p.N), p.stat_splits, p.rows_per_group, p.BF, part)); }
+  ProfScope ps_(KID_STATS, st);
+  if (pool.xin) {
+    VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8, 1>), grid, dim3(kStatsWaves * 64), 0, st, x,
+                                            p.R, int(p.D), p.CV, int(p.N), p.stat_splits, p.rows_per_group, p.BF, part,
+                                            pool));
+  } else {
+    VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8, 0>), grid, dim3(kStatsWaves * 64), 0, st, x,
+                                            p.R, int(p.D), p.CV, int(p.N), p.stat_splits, p.rows_per_group, p.BF, part,
+                                            pool));
+  }
+  return check_launch("chan_stats");
+}
+
+int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, void* var_T, float* var_f32,
+                      hipStream_t st, bool zero_queue_counters = false, bool have_partials = false) {
+  double* part = wsp<double>(ws, p.o_part_stats);
+  if (!have_partials) { int rcs = launch_stats_sweep(p, x, ws, PoolSrc{}, st); if (rcs) return rcs; }
   { ProfScope ps_(KID_STATS_REDUCE, st);
   const PartSrc src{part, x, p.R, p.BF * p.stat_splits, p.G, int(p.N), p.BF};
   if (bstats)         // the frame-sharded pass needs the block statistics themselves (exchange 1)
@@ -2479,6 +2584,27 @@ int vc2_map_indices(const int64_t* local_idx, const int64_t* ks, const int64_t* 
   return check_launch("map_indices");
 }
 
+int vc2_pool_out_tokens(int64_t H, int64_t W, int mode, int64_t* h_out, int64_t* w_out) {
+  if (H < 2 || W < 2 || mode < 1 || mode > 3 || !h_out || !w_out) return fail(VC2_ERR_ARG, "bad pool arguments");
+  *h_out = mode == VC2_POOL_BILINEAR ? (H + 1) / 2 : H / 2;
+  *w_out = mode == VC2_POOL_BILINEAR ? (W + 1) / 2 : W / 2;
+  return VC2_OK;
+}
+
+int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, int dtype, int mode, void* ws,
+                   size_t ws_bytes, void* x_out, void* stream) {
+  if (!xin || !x_out) return fail(VC2_ERR_ARG, "null pointer");
+  int64_t h, w;
+  int rc = vc2_pool_out_tokens(H, W, mode, &h, &w);
+  if (rc) return rc;
+  if (H > 32768 || W > 32768) return fail(VC2_ERR_UNSUPPORTED, "H, W up to 32768");
+  Plan p;
+  if ((rc = make_plan(F, h * w, D, dtype, &p))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  const PoolSrc pool{xin, int(H), int(W), int(h), int(w), mode};
+  return launch_stats_sweep(p, x_out, ws, pool, static_cast<hipStream_t>(stream));
+}
+
 int vc2_gather_scatter(const void* const* srcs, const int64_t* src_rows, void* const* dsts, const int64_t* dst_rows,
                        int n_src, int64_t D, int dtype, const int64_t* idx, const int64_t* n_dev, int64_t n_max,
                        const int64_t* dst_pos, int64_t dst_row0, const void* tail, int64_t tail_rows, int32_t* status,
@@ -2521,14 +2647,14 @@ int vc2_compress(const void* x, int64_t F, int64_t N, int64_t D, int dtype, doub
                  int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
                  void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
                  void* stream) {
-  return vc2_compress_tail(x, F, N, D, dtype, base_scale, map_mode, grid_h, gather_src, gather_rows, ws, ws_bytes,
-                           out_rows, idx_out, cap, ks, K_out, v_T, f_T, nullptr, 0, stream);
+  return vc2_compress_ex(x, F, N, D, dtype, base_scale, map_mode, grid_h, gather_src, gather_rows, ws, ws_bytes,
+                           out_rows, idx_out, cap, ks, K_out, v_T, f_T, nullptr, 0, 0, stream);
 }
 
-int vc2_compress_tail(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale, int map_mode,
+int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale, int map_mode,
                       int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
                       void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
-                      const void* tail, int64_t tail_rows, void* stream) {
+                      const void* tail, int64_t tail_rows, int flags, void* stream) {
   if (!x || !idx_out || !ks || !K_out) return fail(VC2_ERR_ARG, "null pointer");
   if (tail_rows < 0 || (tail_rows > 0 && !tail)) return fail(VC2_ERR_ARG, "tail_rows without tail");
   if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
@@ -2542,7 +2668,9 @@ int vc2_compress_tail(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
   int* cols = wsp<int>(ws, p.o_cols);
-  if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true))) return rc;
+  if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true,
+                              /*have_partials=*/(flags & VC2_FLAG_HAVE_STATS) != 0)))
+    return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
   const bool strict = g_strict && p.ES == 2;
   int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;

@@ -8,7 +8,9 @@ Host mirror of `vc2_gather_scatter` / `vc2_keep_positions` (include/vc2.h).  The
 * `inputs_embeds[:, keep_token_indices, :]` (models/qwen2_5_vl.py:153-182): `keep_positions` builds the kept
   sequence positions on the device (no `nonzero` round trips), `gather_scatter` copies text and kept video rows in
   one launch;
-* the N+1 gathers of Qwen3-VL's deep-stack (models/qwen3_vl.py:140-165): several tensors, one index list, one launch.
+* the N+1 gathers of Qwen3-VL's deep-stack (models/qwen3_vl.py:140-165): several tensors, one index list, one launch;
+* (f3) LLaVA's `get_2dPool` (llava/model/llava_arch.py:171-190) followed by the pass's first sweep: `pool_stats`
+  writes the pooled video once and leaves its channel statistics in the pass's workspace.
 
 Device tensors only: there is no CPU fallback.
 """
@@ -21,7 +23,7 @@ import torch
 
 from ._ffi import DTYPE_CODE, check, lib, on_device, ptr, require_device, stream_ptr
 
-__all__ = ["gather_scatter", "keep_positions"]
+__all__ = ["gather_scatter", "keep_positions", "pool_stats", "POOL_MODES"]
 
 MAX_SOURCES = 8
 
@@ -134,3 +136,39 @@ def keep_positions(video_mask: torch.Tensor, kept: torch.Tensor, n_video: Option
         n_rows = int(counts[1].item()) if n_visual is None else int(n_visual) - int(n_video) + K
         vis_rows = vis_rows[:n_rows]
     return keep, vis_rows
+
+
+POOL_MODES = {"average": 1, "max": 2, "bilinear": 3}
+
+
+def pool_stats(image_feature: torch.Tensor, height: int, width: int, mode: str = "average"):
+    """2x2 pool of the projector output `[F, height*width, D]` (get_2dPool with stride 2, in the token-major layout it
+    permutes from and back to) fused with sweep 1 of the compression pass.
+
+    Returns (pooled `[F, h*w, D]`, workspace): hand the workspace to `compress(..., stats_ws=workspace)` /
+    `CompressPlan(..., ws=workspace).enqueue(..., have_stats=True)` on the same stream and the pass skips its first
+    sweep.  "average" and "max" reproduce torch's avg_pool2d / max_pool2d bits; "bilinear" follows ATen's scalar
+    arithmetic (see include/vc2.h) and may differ from torch's vector loop in the last bit."""
+    from . import _ffi
+    require_device(image_feature, "image_feature")
+    if mode not in POOL_MODES:
+        raise ValueError(f"Unexpected mm_spatial_pool_mode: {mode}")
+    x = image_feature
+    if x.dim() != 3 or x.shape[1] != int(height) * int(width):
+        raise RuntimeError(f"image_feature must be [frames, {height}*{width}, dim], got {tuple(x.shape)}")
+    if x.dtype not in DTYPE_CODE:
+        raise TypeError(f"unsupported dtype {x.dtype} (fp32 / bf16 / fp16 only)")
+    x = x if x.is_contiguous() else x.contiguous()
+    F, _, D = x.shape
+    h = ctypes.c_int64(0)
+    w = ctypes.c_int64(0)
+    check(lib().vc2_pool_out_tokens(int(height), int(width), POOL_MODES[mode], ctypes.byref(h), ctypes.byref(w)),
+          "vc2_pool_out_tokens")
+    n = int(h.value) * int(w.value)
+    ws = _ffi.workspace(F, n, D, x.dtype, x.device)
+    out = torch.empty((F, n, D), dtype=x.dtype, device=x.device)
+    with on_device(x.device):
+        rc = lib().vc2_pool_stats(ptr(x), F, int(height), int(width), D, DTYPE_CODE[x.dtype], POOL_MODES[mode], ptr(ws),
+                                  ws.numel(), ptr(out), stream_ptr(x.device))
+    check(rc, "vc2_pool_stats")
+    return out, ws

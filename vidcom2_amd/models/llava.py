@@ -68,12 +68,48 @@ class _CompressOnFlatten(torch.Tensor):
                     and newline.dim() == 1 and newline.shape[0] == flat.shape[1] and newline.is_contiguous():
                 # kept rows + the newline row behind them in ONE gather launch
                 from ..vidcom2 import MODEL_SPECS, compress
-                res = compress(flat, MODEL_SPECS["llava_ov"]["tpf"], retention_ratio(), tail=newline[None])
+                res = compress(flat, MODEL_SPECS["llava_ov"]["tpf"], retention_ratio(), tail=newline[None],
+                               stats_ws=getattr(self, "_vc2_stats_ws", None))
                 rows = res.rows[: res.K].as_subclass(_NewlineFused)
                 rows._vc2_fused = (res.rows, newline.data_ptr())
                 return rows
+            ws = getattr(self, "_vc2_stats_ws", None)
+            if ws is not None and flat.is_cuda:
+                from ..vidcom2 import MODEL_SPECS, compress
+                return compress(flat, MODEL_SPECS["llava_ov"]["tpf"], retention_ratio(), stats_ws=ws).rows
             return vidcom2_compression(flat, base_scale=retention_ratio())
         return flat
+
+
+class _PooledWithStats(torch.Tensor):
+    """A pooled video `[F, N, D]` that carries the workspace holding its sweep-1 statistics (fused.pool_stats)."""
+
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+
+def _fused_pool(model, pool_inner, image_feature, args, kwargs):
+    """get_2dPool + sweep 1 in one kernel when the configuration allows a bit-identical pooled tensor (average / max;
+    bilinear only with VC2_FUSED_POOL=bilinear: last-bit differences to torch's vector loop).  None: not applicable."""
+    import os
+    stride = args[0] if args else kwargs.get("stride", 2)
+    mode = getattr(model.config, "mm_spatial_pool_mode", None)
+    knob = os.getenv("VC2_FUSED_POOL", "")
+    if knob == "off":
+        return None
+    allowed = {"average", "max"} | ({"bilinear"} if knob == "bilinear" else set())
+    if stride != 2 or mode not in allowed or not (torch.is_tensor(image_feature) and image_feature.is_cuda):
+        return None
+    if image_feature.dim() != 3 or image_feature.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return None
+    try:
+        side = int(model.get_vision_tower().num_patches_per_side)
+    except Exception:
+        return None
+    if side * side != image_feature.shape[1]:
+        return None
+    from ..fused import pool_stats
+    out, ws = pool_stats(image_feature, side, side, mode)
+    return out, ws
 
 
 def cus_prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values,
@@ -100,9 +136,26 @@ def cus_prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, atte
                     # uncompressed (llava.py:130-131)
                     return out
                 flat = image_feature.reshape(-1, image_feature.shape[-1])
+                ws = getattr(image_feature, "_vc2_stats_ws", None)
+                if ws is not None and flat.is_cuda:
+                    from ..vidcom2 import MODEL_SPECS, compress
+                    spec = MODEL_SPECS["llava_vid"]
+                    return compress(flat, spec["tpf"], retention_ratio(), "grid_vid", spec["grid"], out,
+                                    stats_ws=ws).rows
                 return vidcom2_compression(flat, "llava_vid", base_scale=retention_ratio(), img_feat=out)
 
             patches["add_token_per_grid"] = add_token_per_grid
+            pool_inner_g = self.get_2dPool
+
+            def get_2dPool_grid(image_feature, *args, **kwargs):
+                fused = _fused_pool(self, pool_inner_g, image_feature, args, kwargs)
+                if fused is None:
+                    return pool_inner_g(image_feature, *args, **kwargs)
+                out = fused[0].as_subclass(_PooledWithStats)
+                out._vc2_stats_ws = fused[1]
+                return out
+
+            patches["get_2dPool"] = get_2dPool_grid
         elif newline == "one_token" and "unpad" in merge_type:
             pool_inner = self.get_2dPool
 
@@ -110,7 +163,12 @@ def cus_prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, atte
             newline_vec = getattr(inner_model, "image_newline", None) if inner_model is not None else None
 
             def get_2dPool(image_feature, *args, **kwargs):
-                out = pool_inner(image_feature, *args, **kwargs).as_subclass(_CompressOnFlatten)
+                fused = _fused_pool(self, pool_inner, image_feature, args, kwargs)
+                if fused is None:
+                    out = pool_inner(image_feature, *args, **kwargs).as_subclass(_CompressOnFlatten)
+                else:
+                    out = fused[0].as_subclass(_CompressOnFlatten)
+                    out._vc2_stats_ws = fused[1]
                 if torch.is_tensor(newline_vec):
                     out._vc2_newline = newline_vec.detach()
                 return out

@@ -89,7 +89,7 @@ class CompressPlan:
 
     def __init__(self, F: int, N: int, D: int, dtype, device, base_scale: float = 0.25,
                  mapper: str = "linear", grid_h: int = 0, want_scores: bool = False, gather: bool = True,
-                 tail_rows: int = 0):
+                 tail_rows: int = 0, ws: Optional[torch.Tensor] = None):
         if mapper not in ("linear", "grid_vid"):
             raise ValueError(f"unknown mapper {mapper!r}")
         self.F, self.N, self.D, self.dtype, self.device = int(F), int(N), int(D), dtype, torch.device(device)
@@ -101,7 +101,7 @@ class CompressPlan:
         if self.map_mode == MAP_GRID_VID:
             cap += self.F * self.grid_h
         self.cap = cap
-        self.ws = _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
+        self.ws = ws if ws is not None else _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
         self.idx = torch.empty(cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(self.F, dtype=torch.int64, device=self.device)
         self.kout = torch.empty(2, dtype=torch.int64, device=self.device)    # both words written by every pass
@@ -112,7 +112,9 @@ class CompressPlan:
         self.f = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
 
     def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None,
-                tail: Optional[torch.Tensor] = None) -> None:
+                tail: Optional[torch.Tensor] = None, have_stats: bool = False) -> None:
+        """have_stats: `self.ws` already holds flat's sweep-1 partials (fused.pool_stats wrote them on this
+        stream), so the pass starts at the variance reduction."""
         src = flat if gather_src is None else gather_src
         if self.tail_rows:
             if tail is None or tail.shape != (self.tail_rows, self.D) or tail.dtype != self.dtype \
@@ -120,12 +122,12 @@ class CompressPlan:
                 raise RuntimeError(f"tail must be [{self.tail_rows}, {self.D}] {self.dtype} on {self.device}")
             tail = tail.contiguous()
         with on_device(self.device):
-            rc = lib().vc2_compress_tail(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
-                                         self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
-                                         src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
-                                         self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
-                                         ptr(tail if self.tail_rows else None), self.tail_rows,
-                                         stream_ptr(self.device))
+            rc = lib().vc2_compress_ex(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
+                                       self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
+                                       src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
+                                       self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
+                                       ptr(tail if self.tail_rows else None), self.tail_rows,
+                                       1 if have_stats else 0, stream_ptr(self.device))
         check(rc, "vc2_compress")
 
     def finish(self) -> CompressionResult:
@@ -140,10 +142,12 @@ class CompressPlan:
 @_guarded
 def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, mapper: str = "linear",
              grid_h: int = 0, img_feat: Optional[torch.Tensor] = None, want_scores: bool = False,
-             gather: bool = True, tail: Optional[torch.Tensor] = None) -> CompressionResult:
+             gather: bool = True, tail: Optional[torch.Tensor] = None,
+             stats_ws: Optional[torch.Tensor] = None) -> CompressionResult:
     """One whole pass: feature tensor resident in HBM -> kept rows + indices + budgets.
     tail ([m, D], e.g. LLaVA's newline embedding): written behind the kept rows by the gather launch itself;
-    `rows` is then [K + m, D]."""
+    `rows` is then [K + m, D].  stats_ws: the workspace `fused.pool_stats` returned together with THIS tensor --
+    the pass then skips its first sweep."""
     x = _prep(flattened_feat, "flattened_feat")
     if x.dim() != 2:
         raise RuntimeError(f"flattened_feat must be 2-D [frames*tokens, dim], got {tuple(x.shape)}")
@@ -166,9 +170,12 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
                              if src.dim() == 2 else "img_feat must be 2-D [rows, dim]")
     if tail is not None:
         tail = _prep(tail if tail.dim() == 2 else tail[None], "tail")
+    if stats_ws is not None and (x.data_ptr() != flattened_feat.data_ptr()
+                                 or stats_ws.numel() < _ffi.workspace_bytes(R // tpf, tpf, D, x.dtype)):
+        stats_ws = None                                   # a copy was made / another shape: the statistics are not its
     plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather,
-                        tail_rows=0 if tail is None else tail.shape[0])
-    plan.enqueue(x, src, tail)
+                        tail_rows=0 if tail is None else tail.shape[0], ws=stats_ws)
+    plan.enqueue(x, src, tail, have_stats=stats_ws is not None)
     return plan.finish()
 
 
