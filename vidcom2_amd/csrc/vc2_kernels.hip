@@ -3,20 +3,22 @@
 // Replaces the tensor work of token_compressor/vidcom2/vidcom2.py:15-115 (reference).  The pass
 // is three dependent streaming sweeps over X[F*N, D] plus O(F*N) scalar work:
 //
-//   sweep 1  k_chan_stats      per-channel sum / sum-of-squares (fp64)        vidcom2.py:40
-//            k_stats_reduce    fixed-order partial reduce -> var (T)
+//   sweep 1  k_chan_stats      per-channel shifted sum / sum of squares (fp64) vidcom2.py:40
+//            k_var_from_stats  canonical stat blocks, Chan-folded in a fixed shape -> var (T)
 //            k_chan_select     lowest-variance half, CPU-reference ties       vidcom2.py:41-42
-//                              (+ torch.topk's sorted ORDER on a side stream in "torch order" mode)
+//            (k_chan_order     torch.topk's sorted ORDER: normally rider workgroups of sweep 2)
 //   sweep 2  k_norm_colsum     token L2 norms, x^ = x/||x||, per-frame sums   vidcom2.py:47-52
-//            k_centres, k_vid_centre   frame / video centres (T)
-//   sweep 3  k_dist            squared distances to both centres              vidcom2.py:61
-//            k_token_epilogue  5-scale Gaussian sums, v+f, per-frame mean     vidcom2.py:62,32-33
-//            k_scales          softmax budgets                                vidcom2.py:64-68
-//            k_select          ks, per-frame bottom-k (libstdc++ ties) + map  vidcom2.py:72-77,99-115
-//            k_gather_rows     kept rows                                      vidcom2.py:91,96
-//   "torch order" mode only: k_norm_fix, k_centre_fix, k_dist_fix replay torch's fp32 accumulation order for
-//   the few values whose exact result lies next to a T rounding boundary (DESIGN.md "Numerics contract").
-//   standalone helper: k_multi_scale_gaussian                                 vidcom2.py:59-62
+//            k_frame_centres, k_video_centre   frame / video centres (T)      vidcom2.py:51-52
+//   sweep 3  k_dist            squared distances to both centres + the 5-scale Gaussian sums, v + f and the
+//                              per-frame score partials in its epilogue       vidcom2.py:61-62,32-33
+//            k_select          softmax budgets, ks, per-frame bottom-k (libstdc++ ties) + map
+//                                                                              vidcom2.py:64-77,99-115
+//            k_gather_rows     kept rows (+ tail rows; several tensors)       vidcom2.py:91,96
+//   "torch order" mode: values whose exact result lies next to a T rounding boundary are replayed in torch's fp32
+//   accumulation order -- inside the sweeps' own workgroups (distances, centre means) or by k_norm_fix (norms)
+//   (DESIGN.md "Numerics contract").
+//   standalone helpers: k_multi_scale_gaussian (vidcom2.py:59-62), k_scales (:64-68), k_keep_positions (hooks);
+//   POOL variant of k_chan_stats: LLaVA's get_2dPool fused with sweep 1.
 //
 // HBM-bound: no dense contraction exists in the reference, so no MFMA.  All global
 // loads are 16 B/lane coalesced along D; reductions are fixed-order (no float atomics) so results
