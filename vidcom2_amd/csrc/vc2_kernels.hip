@@ -235,9 +235,16 @@ template <int DT>
 __device__ __forceinline__ void block_stat(const PartSrc& ps, int b, int c, int D, double& mean, double& m2) {
   const int g0 = b * ps.groups_per_block, g1 = min(ps.G, g0 + ps.groups_per_block);
   double s = 0.0, q = 0.0;
-  for (int g = g0; g < g1; ++g) {
-    s += ps.part[(int64_t(g) * 2 + 0) * D + c];
-    q += ps.part[(int64_t(g) * 2 + 1) * D + c];
+  for (int gb = g0; gb < g1; gb += 8) {                  // eight groups' loads in flight, added in group order
+    double vs[8], vq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int g = min(gb + u, g1 - 1);
+      vs[u] = ps.part[(int64_t(g) * 2 + 0) * D + c];
+      vq[u] = ps.part[(int64_t(g) * 2 + 1) * D + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (gb + u < g1) { s += vs[u]; q += vq[u]; }
   }
   const int64_t rK = int64_t(b) * ps.block_frames * ps.N;
   const double n = double(min<int64_t>(ps.R - rK, int64_t(ps.block_frames) * ps.N));
@@ -336,7 +343,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t c, uint32_t* xch, u
 template <typename W>
 __device__ __forceinline__ void chan_select_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
                                                  uint8_t* __restrict__ mask, int* __restrict__ cols,
-                                                 int* __restrict__ perm) {
+                                                 int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                 uint32_t* __restrict__ wcpos) {
   using T = WordTr<W>;
   constexpr int NW = kSelNT / 64;
   const int tid = threadIdx.x;
@@ -361,19 +369,29 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   for (int p = b; p < e; ++p) {
     const bool on = S.la[p] != 0;
     if (mask) mask[p] = on ? 1 : 0;
-    if (on) { if (cols) cols[o] = p; ++o; }
+    if (on) { if (cols) cols[o] = p; S.lb[p] = uint16_t(o); ++o; }
+  }
+  // for the ORDER riders: the kept channels as packed words in nth_element's order, and each one's position in cols
+  // (one coalesced load each instead of perm -> var_f32 and cols -> table)
+  if constexpr (sizeof(W) == 4) {
+    if (wperm && wcpos && k < D) {
+      __syncthreads();
+      for (int i = tid; i < k; i += kSelNT) { const W w = S.w[i]; wperm[i] = uint32_t(w); wcpos[i] = S.lb[T::idx(w)]; }
+    }
   }
 }
 
 __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
-                                                        int* __restrict__ perm) {
+                                                        int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                        uint32_t* __restrict__ wcpos) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int bad = 0;
   for (int i = threadIdx.x; i < D; i += kSelNT) bad |= key_fits_u32(var_f32[i]) ? 0 : 1;
   // widened 16-bit variances pack into 32-bit words (the common case); arbitrary fp32 ones take 64-bit words
-  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, var_f32, D, k, mask, cols, perm);
-  else chan_select_body<uint32_t>(smem, var_f32, D, k, mask, cols, perm);
+  // (wperm / wcpos are only requested for 16-bit inputs)
+  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, var_f32, D, k, mask, cols, perm, nullptr, nullptr);
+  else chan_select_body<uint32_t>(smem, var_f32, D, k, mask, cols, perm, wperm, wcpos);
 }
 __host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
 
@@ -385,55 +403,64 @@ template <typename W, int NW, int SOLO, int COOP>
 __device__ __forceinline__ void chan_order_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
                                                 const int* __restrict__ perm, const int* __restrict__ cols,
                                                 int* __restrict__ order, int* __restrict__ opos,
-                                                int* __restrict__ spos, int part, int nparts) {
+                                                int* __restrict__ spos, int part, int nparts,
+                                                const uint32_t* __restrict__ wperm = nullptr,
+                                                const uint32_t* __restrict__ wcpos = nullptr) {
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   Sel2<W> S = sel2_carve<W>(smem, k);
   unsigned char* p = smem + (sel2_bytes(k, int(sizeof(W))) + 15) / 16 * 16;
-  SortScratch2 Q = sort2_carve(p);
-  int* ord = reinterpret_cast<int*>(p + (sort2_bytes(k) + 15) / 16 * 16);      // [k] sorted order (LDS)
-  uint16_t* cpos = reinterpret_cast<uint16_t*>(ord + k);                       // [D] channel -> position in cols
-  for (int i = tid; i < k; i += NT) { const int c = perm[i]; S.w[i] = T::pack(topk_key(var_f32[c]), c); }
-  if (cols) for (int j = tid; j < k; j += NT) cpos[cols[j]] = uint16_t(j);
+  SortScratch2 Q = sort2_carve(p, NW);
+  uint16_t* cpos = reinterpret_cast<uint16_t*>(p + (sort2_bytes(k, NW) + 15) / 16 * 16);   // [D] channel -> position in cols
+  bool packed = false;
+  if constexpr (sizeof(W) == 4) packed = wperm != nullptr && wcpos != nullptr && k < D;
+  if (packed) {                                      // k_chan_select left the words and their cols positions ready
+    if constexpr (sizeof(W) == 4)
+      for (int i = tid; i < k; i += NT) { const W w = wperm[i]; S.w[i] = w; cpos[T::idx(w)] = uint16_t(wcpos[i]); }
+  } else {
+    for (int i = tid; i < k; i += NT) { const int c = perm[i]; S.w[i] = T::pack(topk_key(var_f32[c]), c); }
+    if (cols) for (int j = tid; j < k; j += NT) cpos[cols[j]] = uint16_t(j);
+  }
   __syncthreads();
+  auto emit = [&](int q, int c) {                    // channel c stands at sorted position q
+    if (order) order[q] = c;
+    if (cols && opos) { const int cp = int(cpos[c]); opos[q] = cp; if (spos) spos[cp] = q; }
+  };
   const bool partial = int64_t(k) * 64 <= int64_t(D) && k < D;
   if (partial) {
     if (part != 0) return;                                                     // (serial: one workgroup does it all)
     if (tid == 0) s2_sort_heap(S.w, 0, k);                                     // partial_sort = heap_select + sort_heap
     __syncthreads();
-    for (int q = tid; q < k; q += NT) ord[q] = T::idx(S.w[q]);
+    for (int q = tid; q < k; q += NT) emit(q, T::idx(S.w[q]));
   } else {
-    // workgroup `part` of `nparts` answers for the slice [ta, tb) of std::sort(q, q + k - 1) (see introsort2)
-    const int n = k - 1;
-    const int ta = int(int64_t(n) * part / nparts), tb = int(int64_t(n) * (part + 1) / nparts);
-    for (int q = tid; q < k; q += NT) ord[q] = -1;
-    __syncthreads();
-    introsort2<W, NW, SOLO, COOP>(S, Q, n, ord, tid, ta, tb);
-    if (tid == 0 && part == nparts - 1) ord[k - 1] = T::idx(S.w[k - 1]);       // the nth_element pivot stays last
-  }
-  __syncthreads();
-  for (int q = tid; q < k; q += NT) {
-    const int c = ord[q];
-    if (c < 0) continue;                                                       // another workgroup's position
-    if (order) order[q] = c;
-    if (cols && opos) { const int cp = int(cpos[c]); opos[q] = cp; if (spos) spos[cp] = q; }
+    // workgroup `part` of `nparts` = 2^L answers for one arrival segment of std::sort(q, q + k - 1) (see introsort2)
+    introsort2<W, NW, SOLO, COOP>(S, Q, k - 1, emit, tid, part, 31 - __clz(nparts));
+    if (tid == 0 && part == nparts - 1) emit(k - 1, T::idx(S.w[k - 1]));       // the nth_element pivot stays last
   }
 }
 __host__ inline size_t chan_order_lds(int D, int k, int wbytes) {
-  return (sel2_bytes(k, wbytes) + 15) / 16 * 16 + (sort2_bytes(k) + 15) / 16 * 16 + size_t(k) * 4 + size_t(D) * 2 + 64;
+  return (sel2_bytes(k, wbytes) + 15) / 16 * 16 + (sort2_bytes(k, 4) + 15) / 16 * 16 + size_t(D) * 2 + 64;
 }
 struct OrderArgs {          // the ORDER job (all null: none), done by `parts` workgroups side by side
   const float* var_f32; const int* perm; const int* cols; int* order; int* opos; int* spos; int D; int k; int parts;
+  const uint32_t* wperm; const uint32_t* wcpos;        // optional: k_chan_select's packed words / cols positions
 };
-// workgroups for the ORDER job: slices of >= 128 positions (a slice costs its workgroup the partitions above it)
+// workgroups for the ORDER job: 2^L arrival segments of >= 128 positions on average
 #ifndef VC2_RIDER_PARTS
-#define VC2_RIDER_PARTS 8      // rider workgroups of sweep 2 (4 waves each)
+#define VC2_RIDER_PARTS 16     // rider workgroups of sweep 2 (4 waves each)
 #endif
 #ifndef VC2_ORDER_PARTS
-#define VC2_ORDER_PARTS 8      // workgroups of the stand-alone k_chan_order
+#define VC2_ORDER_PARTS 16     // workgroups of the stand-alone k_chan_order
 #endif
-__host__ inline int order_parts(int k, int max_parts) { return std::max(1, std::min(max_parts, (k - 1) / 128)); }
+#ifndef VC2_ORDER_MINSEG
+#define VC2_ORDER_MINSEG 64
+#endif
+__host__ inline int order_parts(int k, int max_parts) {        // a power of two
+  int parts = 1;
+  while (parts * 2 <= max_parts && parts * 2 <= (k - 1) / VC2_ORDER_MINSEG) parts *= 2;
+  return parts;
+}
 
 __global__ __launch_bounds__(kOrdNT) void k_chan_order(OrderArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -445,7 +472,7 @@ __global__ __launch_bounds__(kOrdNT) void k_chan_order(OrderArgs a) {
                                         int(blockIdx.x), int(gridDim.x));
   else
     chan_order_body<uint32_t, NW, 4, 8>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
-                                        int(blockIdx.x), int(gridDim.x));
+                                        int(blockIdx.x), int(gridDim.x), a.wperm, a.wcpos);
 }
 
 template <int DT>
@@ -781,12 +808,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
   // (RIDER = 0 instantiations carry no ORDER code: it is only ever attached in "torch order" mode.)
-  const int nrider = (RIDER && rider.perm) ? rider.parts : 0;
+  const int nrider = (RIDER && rider.perm) ? (rider.parts & 0xFF) : 0;
+#ifdef VC2_RIDER_PROBE
+  if (int(blockIdx.x) >= nrider && (rider.parts >> 8) == 1) return;     // probe: riders alone
+  if (int(blockIdx.x) < nrider && (rider.parts >> 8) == 2) return;      // probe: sweep alone
+#endif
   if constexpr (RIDER != 0) {
     if (int(blockIdx.x) < nrider) {
       chan_order_body<uint32_t, kRowWaves, 4, 4>(smem, rider.var_f32, rider.D, rider.k, rider.perm, rider.cols,
                                                  rider.order, rider.opos, rider.spos,    // (16-bit variances: 32-bit words)
-                                                 int(blockIdx.x), nrider);
+                                                 int(blockIdx.x), nrider, rider.wperm, rider.wcpos);
       return;
     }
   }
@@ -1078,7 +1109,13 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   __syncthreads();
   double sf = 0.0;
   if (c < C && f < F) {
-    for (int s = 0; s < S; ++s) sf += part[(int64_t(f) * S + s) * C + c];
+    for (int s0 = 0; s0 < S; s0 += 8) {                         // (S <= 8: one batch of loads, added in split order)
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t(f) * S + min(s0 + u, S - 1)) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (s0 + u < S) sf += v[u];
+    }
     const int nc = corr_count ? *corr_count : 0;
     for (int e = 0; e < nc; ++e) {                              // rows whose norm k_norm_fix corrected (normally none)
       if (corr[e].frame == f) {
@@ -1961,6 +1998,10 @@ struct Plan {
   int vstride;
 };
 
+// 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
+// result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
+thread_local int g_strict = 1;      // per calling thread (vc2_set_mode): concurrent callers cannot change each other's mode
+
 int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total = 0, int block_frames = 0) {
   if (F <= 0 || N <= 0 || D <= 0) return fail(VC2_ERR_ARG, "F, N, D must be positive (got %lld, %lld, %lld)",
                                               (long long)F, (long long)N, (long long)D);
@@ -1983,7 +2024,12 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->G = int(F * p->stat_splits);
   p->BF = block_frames > 0 ? std::min(block_frames, kStatBlockFrames) : kStatBlockFrames;
   p->NB = int(cdiv(F, p->BF));
-  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, cdiv(512, p->F_total)));
+  // sweep 2 runs as ONE wave of workgroups: 2 per CU fit (LDS row buffers, VGPRs) = 512 slots on 256 CUs, and every
+  // workgroup lives for the whole sweep.  The ORDER riders ("torch order" mode, 16-bit inputs) are workgroups of the
+  // same launch, so the splits are chosen to leave them slots -- with 512 + 16 workgroups the last 16 start when the
+  // riders end and the sweep takes 51 instead of 36 us; with 384 + 16 it takes 41.
+  const int64_t riders = (g_strict && dt != VC2_F32) ? VC2_RIDER_PARTS : 0;
+  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, (512 - riders) / p->F_total));
   p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), std::min<int64_t>(N, 8 * kRowWaves)));
   p->S = int(cdiv(N, p->rows_per_split));
   {
@@ -2008,7 +2054,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_spos = take(size_t(D) * 4);
   p->o_perm = take(size_t(D) * 4);
   p->o_den = take(size_t(p->R) * 4);
-  p->o_part_col = take(size_t(F) * p->S * D * 8);
+  p->o_part_col = take(size_t(F) * 8 * D * 8);                // (S <= 8 whatever the mode: one workspace size per shape)
   p->o_fc = take(size_t(F) * D * 4);
   p->o_csum = take(size_t(D) * 8);
   p->o_csum_part = take(size_t(cdiv(F, kCentreFL)) * D * 8);
@@ -2141,13 +2187,14 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what)
 }
 
 int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* perm,
-                       hipStream_t st) {
+                       hipStream_t st, uint32_t* wperm = nullptr, uint32_t* wcpos = nullptr) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = chan_select_lds(int(D));
   { int rca = allow_big_lds(&k_chan_select, smem, "k_chan_select"); if (rca) return rca; }
   { ProfScope ps_(KID_CHAN_SELECT, st);
-  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, perm); }
+  hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, perm, wperm,
+                     wcpos); }
   return check_launch("chan_select");
 }
 // torch.topk's ORDER of the kept channels as its own kernel (the scoring entry points attach it to sweep 2 instead)
@@ -2159,9 +2206,6 @@ int launch_chan_order(const OrderArgs& oa, hipStream_t st) {
   return check_launch("chan_order");
 }
 
-// 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
-// result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
-thread_local int g_strict = 1;      // per calling thread (vc2_set_mode): concurrent callers cannot change each other's mode
 
 // the scored channels: ascending list (nullptr = all D), the same channels in torch.topk's order and their
 // positions in `cols` (both nullptr = identity when cols is nullptr, else strict mode is unavailable)
@@ -2191,7 +2235,7 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
   if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>, smem, "k_norm_colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.F * p.S + (rider.perm ? rider.parts : 0))),
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.F * p.S + (rider.perm ? (rider.parts & 0xFF) : 0))),
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.rows_per_split,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
@@ -2264,6 +2308,9 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
     ride = OrderArgs{};
   }
   if (ride.perm) ride.parts = order_parts(ride.k, VC2_RIDER_PARTS);
+#ifdef VC2_RIDER_PROBE
+  if (ride.perm) { const char* e = getenv("VC2_RIDER_PROBE_MODE"); if (e) ride.parts |= atoi(e) << 8; }
+#endif
   { ProfScope ps_(KID_NORM_COLSUM, st);
   int rc = VC2_OK;
   VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, ride, st));
@@ -2447,7 +2494,7 @@ int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_chan_select(var_f32, D, k, mask, cols, perm, st);
   if (rc || !(order || opos || spos)) return rc;
-  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k), 1}, st);
+  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k), 1, nullptr, nullptr}, st);
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -2489,7 +2536,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   const ChanSet cs = make_chanset(p, cols, spos, C);
   OrderArgs rider{};
   if (perm && cs.strict)      // torch.topk's ORDER of the channels (-> spos), replayed by a rider workgroup of sweep 2
-    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1};
+    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1, nullptr, nullptr};
   rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider);
   if (rc) return rc;
   if (csum_parts) {       // the fp64 sums of x^ per group of kCentreFL frames, in frame order: [ceil(F/16)][C]
@@ -2677,12 +2724,16 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   const bool strict = g_strict && p.ES == 2;
   int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;
   int* perm = strict ? wsp<int>(ws, p.o_perm) : nullptr;
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st))) return rc;
+  // (wperm / wcpos live in the o_tmp_f32 scratch, free until the selection stage: 2 * kc words <= R or D floats)
+  uint32_t* wperm = strict && 2 * kc <= std::max<int64_t>(p.R, D) ? wsp<uint32_t>(ws, p.o_tmp_f32) : nullptr;
+  uint32_t* wcpos = wperm ? wperm + kc : nullptr;
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos))) return rc;
   const ChanSet cs = make_chanset(p, cols, spos, kc);
   // torch.topk's ORDER of the selected channels (needed only by the "torch order" fix-ups, which run after sweep 2)
   // is replayed by a rider workgroup of sweep 2 itself
   OrderArgs rider{};
-  if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc), 1};
+  if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc), 1,
+                                wperm, wcpos};
   if ((rc = launch_phase1(p, x, cs, ws, true, st, rider))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* scales = wsp<float>(ws, p.o_scales_f32);

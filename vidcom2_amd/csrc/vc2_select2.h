@@ -384,128 +384,166 @@ __device__ __forceinline__ void topk_smallest2(const Sel2<W>& S, int n, int k, i
 
 // ---- std::sort(first, first + n) replay (the `sorted=True` half of torch.topk, TopKImpl.h) ---------------
 // __introsort_loop: every segment longer than 16 is partitioned (the same __unguarded_partition_pivot) and both
-// halves recurse with depth_limit - 1; at depth 0 a segment is heap-sorted instead.  Segments of one recursion
-// level are independent, so the workgroup walks the tree LEVEL BY LEVEL (one barrier per level): segments longer
-// than kCoopMin by all waves together, one after the other; the rest dealt round-robin to the waves, each alone.
+// halves recurse with depth_limit - 1; at depth 0 a segment is heap-sorted instead.  Segments are independent, so
+// the order in which they are partitioned is free:
+//   phase A  all waves together partition the longest pending segment while that pays (see there).  A cooperative
+//            partition returns its cut to every thread, so the pending segments are THREAD-UNIFORM bookkeeping: four
+//            register slots, no memory, no atomics, no barriers beyond the partition's own three;
+//   phase B  the remaining segments are dealt round-robin to the waves; every wave sorts its own (a private stack,
+//            one wave per partition, no synchronisation at all).
 // __final_insertion_sort then equals a STABLE sort inside every leaf (<= 16 elements; elements never cross a cut
 // and the insertion uses a strict compare); because everything left of a leaf is <= and everything right of it is
 // >= its elements, the final position of element p is p + #{q in (p, p+16): key_q < key_p} - #{q in (p-16, p):
 // key_q > key_p} -- no leaf bookkeeping at all.
-// Slices: a partition's two sides are independent, so R workgroups replay the same sort side by side.  Workgroup r
-// answers for the positions [ta, tb): it follows only the segments that reach into its slice (the few partitions
-// above them are repeated by everybody -- same input, same result), ranks the positions of its slice and stores
-// those.  Segments that straddle a slice boundary are sorted by both neighbours.
-// out_order[p] = original index at sorted position p (written for the positions the slice's elements land on).
-constexpr int kMaxSeg2 = 512;            // segments (> 16 elements) of one level: n <= 8192
+// Slices: a partition's two sides are independent, so R = 2^L workgroups replay the same sort side by side.
+// Workgroup r first walks L levels down the partition tree -- at level l it partitions the segment it stands on
+// (the same input as everybody else on that segment, so the same result) and steps to the left or right part by
+// bit L-1-l of r -- and then sorts, ranks and stores the segment it arrived at.  The 2^L arrival segments tile
+// [0, n): no position is answered twice, none is left out.  (A segment that is already a leaf above level L goes to
+// the workgroup whose remaining bits are zero.)
+// out(p, i): original index i stands at sorted position p (called for the positions of the arrival segment).
+constexpr int kSortOwnCap = 512;         // a wave's own segments (every segment > 16: at most n / 17 = 481 in all)
 struct SortScratch2 {
-  uint32_t* segA;   // [kMaxSeg2] segment lists of even levels
-  uint32_t* segB;   // [kMaxSeg2] ... of odd levels
-  int* cnt;         // [4]: entries of the list of level L in cnt[L % 3]
+  uint32_t* own;    // [NW][kSortOwnCap]  every wave's private stack
 };
-__host__ __device__ inline size_t sort2_bytes(int /*n*/) { return size_t(kMaxSeg2) * 8 + 16; }
-__device__ __forceinline__ SortScratch2 sort2_carve(unsigned char* p) {
+__host__ __device__ inline size_t sort2_bytes(int /*n*/, int nw = 4) { return size_t(nw) * kSortOwnCap * 4 + 16; }
+__device__ __forceinline__ SortScratch2 sort2_carve(unsigned char* p, int /*nw*/) {
   SortScratch2 Q;
-  Q.segA = reinterpret_cast<uint32_t*>(p);
-  Q.segB = Q.segA + kMaxSeg2;
-  Q.cnt = reinterpret_cast<int*>(Q.segB + kMaxSeg2);
+  Q.own = reinterpret_cast<uint32_t*>(p);
   return Q;
 }
 __device__ __forceinline__ uint32_t seg_pack(int first, int last, int depth) {
   return uint32_t(first) | (uint32_t(last) << 13) | (uint32_t(depth) << 26);   // last <= 8191, depth <= 26
 }
 
-template <typename W, int NW, int SOLO, int COOP>
-__device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, int* __restrict__ out_order, int tid,
-                                           int ta = 0, int tb = 0x7FFFFFFF) {
+template <typename W, int NW, int SOLO, int COOP, typename OUT>
+__device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, OUT out, int tid,
+                                           int part = 0, int levels = 0) {
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
-  constexpr int kCoopMin = NW > 1 ? 256 : 0x7FFFFFFF;           // longer segments: all waves together
-  static_assert(NW == 1 || kCoopMin <= sel2_capacity(1, SOLO), "a dealt segment must fit one wave");
+  constexpr int kCoopMin = NW > 1 ? 64 : 0x7FFFFFFF;            // longer segments: all waves together
   const int lane = tid & 63, wave = tid >> 6;
-  volatile int* cnt = Q.cnt;
+  uint32_t* const mine = Q.own + wave * kSortOwnCap;
 #ifdef VC2_SEL2_DEBUG
   if (tid == 0) g_sel2_dbg[0] = __builtin_readcyclecounter();
+  int dbg_coop = 0, dbg_dealt = 0; unsigned long long dbg_tc = 0, dbg_td = 0;
 #endif
-  if (tid == 0) {
-    cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
-    if (n > 16) { Q.segA[0] = seg_pack(0, n, 2 * (31 - __clz(n))); cnt[0] = 1; }
+  int nmine = 0, ndealt = 0;
+  // pending segments for phase A: at most four, thread-uniform, kept in (scalar) registers sorted by length -- an LDS
+  // round trip costs a lone wave ~200 cycles, so no list in memory
+  uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
+  auto seglen = [](uint32_t sg) { return int((sg >> 13) & 0x1FFFu) - int(sg & 0x1FFFu); };
+  auto push_mine = [&](uint32_t sg) {
+    if (nmine < kSortOwnCap) { if (lane == 0) mine[nmine] = sg; ++nmine; } else if (lane == 0) guard_hit(4);
+  };
+  auto deal = [&](uint32_t sg) {                                  // round-robin over the waves (uniform decision)
+    if ((ndealt % NW) == wave) push_mine(sg);
+    ++ndealt;
+  };
+  auto push_uniform = [&](int f, int l, int depth) {             // identical arguments in every thread of the workgroup
+    if (l - f <= 16) return;                                     // a leaf
+    uint32_t sg = seg_pack(f, l, depth);
+    if (NW > 1 && l - f > kCoopMin && depth != 0 && l - f <= sel2_capacity(NW, COOP)) {
+      uint32_t t;
+      if (seglen(sg) > seglen(s0)) { t = s0; s0 = sg; sg = t; }
+      if (seglen(sg) > seglen(s1)) { t = s1; s1 = sg; sg = t; }
+      if (seglen(sg) > seglen(s2)) { t = s2; s2 = sg; sg = t; }
+      if (seglen(sg) > seglen(s3)) { t = s3; s3 = sg; sg = t; }
+      if (sg != 0u) deal(sg);                                    // the shortest of five goes to a wave right away
+    } else {
+      deal(sg);
+    }
+  };
+  // walk down to my arrival segment [ta, tb)
+  int ta = 0, tb = n;
+  {
+    int first = 0, last = n, depth = n > 1 ? 2 * (31 - __clz(n)) : 0;
+    bool mine_ = true;
+    for (int l = 0; l < levels && mine_; ++l) {
+      const int rest = part & ((1 << (levels - l)) - 1);          // my bits from this level on
+      if (last - first <= 16 || depth == 0) { mine_ = rest == 0; break; }   // a leaf (or a heapsort segment): one owner
+      int cut;
+      if constexpr (NW > 1) cut = sel2_partition<W, NW, 0, COOP>(S, first, last, S.la + first, S.lb + first, tid);
+      else cut = sel2_partition<W, 1, 0, SOLO>(S, first, last, S.la + first, S.lb + first, lane);
+      if ((rest >> (levels - l - 1)) & 1) first = cut; else last = cut;
+      --depth;
+    }
+    if (mine_) { ta = first; tb = last; if (last - first > 16) push_uniform(first, last, depth); }
+    else { ta = 0; tb = 0; }
   }
-  __syncthreads();
 #ifdef VC2_SEL2_DEBUG
   if (tid == 0) g_sel2_dbg[1] = __builtin_readcyclecounter();
 #endif
-  int c_cur = 0, c_nxt = 1, c_free = 2;
+  if constexpr (NW > 1) {
+    // Phase A.  All waves together partition the LONGEST pending segment while that pays: as long as it is longer
+    // than 128, or there are fewer pending segments than waves (a cooperative round costs about as much as a short
+    // solo one, but leaves the other waves idle only when there is nothing else to hand them).
+    for (int guard = 0; s0 != 0u && guard < 4 * 8192; ++guard) {
+      const int cnt = 1 + (s1 != 0u ? 1 : 0) + (s2 != 0u ? 1 : 0) + (s3 != 0u ? 1 : 0);
+      const int blen = seglen(s0);
+      if (!(blen > 128 || (cnt < NW && blen > 64))) break;
+      const uint32_t bsg = s0;
+      s0 = s1; s1 = s2; s2 = s3; s3 = 0u;
+      const int first = int(bsg & 0x1FFFu), last = int((bsg >> 13) & 0x1FFFu), depth = int(bsg >> 26);
 #ifdef VC2_SEL2_DEBUG
-  int dbg_levels = 0, dbg_coop = 0, dbg_dealt = 0; unsigned long long dbg_tc = 0, dbg_td = 0;
+      const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
-  for (int level = 0; level < 64; ++level) {
-    const uint32_t* cur = (level & 1) ? Q.segB : Q.segA;
-    uint32_t* nxt = (level & 1) ? Q.segA : Q.segB;
-    const int ns = min(int(cnt[c_cur]), kMaxSeg2);
-    if (ns == 0) break;
-    if (tid == 0) cnt[c_free] = 0;                              // (the list two levels on; last read one level ago)
-    auto push_children = [&](int first, int cut, int last, int depth) {     // one thread
-      const int fs[2] = {first, cut}, ls[2] = {cut, last};
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        if (ls[c] - fs[c] <= 16 || fs[c] >= tb || ls[c] <= ta) continue;    // a leaf, or outside my slice
-        const int j = atomicAdd(const_cast<int*>(&cnt[c_nxt]), 1);
-        if (j < kMaxSeg2) nxt[j] = seg_pack(fs[c], ls[c], depth - 1); else guard_hit(4);
-      }
-    };
-    if constexpr (NW > 1) {                                     // the long segments, all waves together
-      for (int si = 0; si < ns; ++si) {
-        const uint32_t sg = cur[si];
-        const int first = int(sg & 0x1FFFu), last = int((sg >> 13) & 0x1FFFu), depth = int(sg >> 26);
-        if (last - first <= kCoopMin || depth == 0) continue;
+      const int cut = sel2_partition<W, NW, 0, COOP>(S, first, last, S.la + first, S.lb + first, tid);
 #ifdef VC2_SEL2_DEBUG
-        const unsigned long long c0 = __builtin_readcyclecounter();
+      dbg_tc += __builtin_readcyclecounter() - c0; ++dbg_coop;
 #endif
-        const int cut = sel2_partition<W, NW, 1, COOP>(S, first, last, S.la + first, S.lb + first, tid);
-#ifdef VC2_SEL2_DEBUG
-        dbg_tc += __builtin_readcyclecounter() - c0; ++dbg_coop;
-#endif
-        if (tid == 0) push_children(first, cut, last, depth);
-      }
+      push_uniform(first, cut, depth - 1);
+      push_uniform(cut, last, depth - 1);
+      if (guard == 4 * 8192 - 1 && tid == 0) guard_hit(2);
     }
-    int dealt = 0;
-    for (int si = 0; si < ns; ++si) {                           // the others: one wave each
-      const uint32_t sg = cur[si];
-      const int first = int(sg & 0x1FFFu), last = int((sg >> 13) & 0x1FFFu), depth = int(sg >> 26);
-      if (NW > 1 && last - first > kCoopMin && depth != 0) continue;
-      if ((dealt++ % NW) != wave) continue;
-      if (depth == 0) {                                         // __partial_sort(first, last, last): heapsort
-        if (lane == 0) { s2_heap_select(S.w, first, last, last); s2_sort_heap(S.w, first, last); }
-        continue;
-      }
-#if defined(VC2_SEL2_DEBUG) && VC2_SEL2_DEBUG >= 2
-      const unsigned long long dt0 = __builtin_readcyclecounter();
-#endif
-#ifdef VC2_SEL2_DEBUG
-      const unsigned long long d0 = __builtin_readcyclecounter();
-#endif
-      const int cut = sel2_partition<W, 1, 0, SOLO>(S, first, last, S.la + first, S.lb + first, lane);
-#ifdef VC2_SEL2_DEBUG
-      dbg_td += __builtin_readcyclecounter() - d0; ++dbg_dealt;
-#endif
-#if defined(VC2_SEL2_DEBUG) && VC2_SEL2_DEBUG >= 2
-      if (lane == 0) { g_sel2_dbg[16 + wave * 2] += __builtin_readcyclecounter() - dt0; g_sel2_dbg[17 + wave * 2] += 1; }
-#endif
-      if (lane == 0) push_children(first, cut, last, depth);
-    }
-    __syncthreads();
-    const int t = c_cur; c_cur = c_nxt; c_nxt = c_free; c_free = t;
-    if (level == 63 && tid == 0) guard_hit(2);
-#ifdef VC2_SEL2_DEBUG
-    ++dbg_levels;
-#endif
+    if (s0 != 0u) deal(s0);
+    if (s1 != 0u) deal(s1);
+    if (s2 != 0u) deal(s2);
+    if (s3 != 0u) deal(s3);
   }
 #ifdef VC2_SEL2_DEBUG
-  if (tid == 0) { g_sel2_dbg[2] = __builtin_readcyclecounter(); g_sel2_dbg[6] = dbg_levels; g_sel2_dbg[7] = dbg_coop; g_sel2_dbg[8] = dbg_tc;
+  if (tid == 0) g_sel2_dbg[2] = __builtin_readcyclecounter();
+#endif
+  // Phase B: my own segments, depth first; the segment to continue with stays in a register
+  uint32_t cur = 0u;
+  for (int guard = 0; guard < 4 * 8192; ++guard) {
+    if (cur == 0u) {
+      if (nmine == 0) break;
+      --nmine;
+      wave_lds_order();
+      cur = uint32_t(__builtin_amdgcn_readfirstlane(int(mine[nmine])));
+    }
+    const int first = int(cur & 0x1FFFu), last = int((cur >> 13) & 0x1FFFu), depth = int(cur >> 26);
+    cur = 0u;
+    if (depth == 0 || last - first > sel2_capacity(1, SOLO)) {  // __partial_sort(first, last, last): heapsort
+      if (lane == 0) { s2_heap_select(S.w, first, last, last); s2_sort_heap(S.w, first, last); }
+      if (depth != 0 && lane == 0) guard_hit(5);               // (a long segment that phase A could not take)
+      wave_lds_order();
+      continue;
+    }
+#ifdef VC2_SEL2_DEBUG
+    const unsigned long long d0 = __builtin_readcyclecounter();
+#endif
+    const int cut = sel2_partition<W, 1, 0, SOLO>(S, first, last, S.la + first, S.lb + first, lane);
+#ifdef VC2_SEL2_DEBUG
+    dbg_td += __builtin_readcyclecounter() - d0; ++dbg_dealt;
+#endif
+    const bool left = cut - first > 16, right = last - cut > 16;
+    if (left) {
+      cur = seg_pack(first, cut, depth - 1);
+      if (right) push_mine(seg_pack(cut, last, depth - 1));
+    } else if (right) {
+      cur = seg_pack(cut, last, depth - 1);
+    }
+    if (guard == 4 * 8192 - 1 && lane == 0) guard_hit(3);
+  }
+  __syncthreads();
+#ifdef VC2_SEL2_DEBUG
+  if (tid == 0) { g_sel2_dbg[3] = __builtin_readcyclecounter(); g_sel2_dbg[7] = dbg_coop; g_sel2_dbg[8] = dbg_tc;
                   g_sel2_dbg[9] = dbg_dealt; g_sel2_dbg[10] = dbg_td; }
 #endif
   // __final_insertion_sort == a stable rank inside the 31-wide window (see above)
-  for (int p = max(ta, 0) + tid; p < min(n, tb); p += NT) {
+  for (int p = ta + tid; p < tb; p += NT) {
     const W wp = S.w[p];
     const uint32_t kp = T::key(wp);
     int r = p;
@@ -516,7 +554,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
       r -= (ql >= 0 && kl > kp) ? 1 : 0;
       r += (qr < n && kr < kp) ? 1 : 0;
     }
-    out_order[r] = T::idx(wp);
+    out(r, T::idx(wp));                                        // sorted position r holds original index idx
   }
   __syncthreads();
 #ifdef VC2_SEL2_DEBUG
