@@ -216,6 +216,24 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
                       int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
                       void* f_T, float* total_f32, float* s_f32, void* stream);
+/* Video-centre replay of the frame-sharded pass ("torch order" mode, 16-bit inputs, rows per rank % 16 == 0,
+ * R_total <= 2^19).  Between exchange 2 and phase 2:
+ *   vc2_video_centre_blocks  flags the boundary-near video-centre columns (identically on every rank) and writes, for
+ *                            the first `cap` of them, the level-0 sums of THIS rank's rows (blocks of 16 rows, torch's
+ *                            SumKernel cascade) to blocks_out[cap][F*N/16]
+ *   (all-gather -> blocks_all[world][cap][F*N/16], rank order)
+ *   vc2_scores_phase2_blocks = vc2_scores_phase2, which then finishes the cascade over the whole video for those
+ *                            columns, so their means round like the unsharded pass / the reference.
+ * When the conditions do not hold both calls fall back to vc2_scores_phase2's behaviour (exact means, counted). */
+int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+                            int64_t C, const int32_t* spos, const double* csum_all, int64_t P,
+                            int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, float* blocks_out,
+                            int cap, void* stream);
+int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+                             int64_t C, const int32_t* spos, const double* csum_all, int64_t P,
+                             int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T, void* f_T,
+                             float* total_f32, float* s_f32, const float* blocks_all, int world, int cap,
+                             void* stream);
 
 /* Step 3 of the sharded path: s_all_f32[F_total] = the all-gathered per-frame uniqueness scores
  * (fp32-widened T values); budgets are computed over all F_total frames, selection + gather only for

@@ -54,5 +54,6 @@ def test_cfg4_frame_sharded_is_world_size_invariant(c):
         ks = torch.cat([r.ks for r in res]).cpu().tolist()
         rows = torch.cat([r.rows for r in res]).cpu()
         _check(c, ks, gidx, rows)
+        assert all(s_.vc_fragile == 0 for s_ in st)          # every boundary-near video-centre mean was replayed
         del res, st
         torch.cuda.empty_cache()

@@ -78,7 +78,12 @@ def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev):
     for s in st:
         s.select_channels(stats_all, F * N)
     csum_all = torch.stack([s.phase1(xs).clone() for s, xs in zip(st, shards)])
-    s_all = torch.cat([s.phase2(xs, csum_all, F * N).clone() for s, xs in zip(st, shards)])
+    blocks = [s.vc_blocks(xs, csum_all, F * N) for s, xs in zip(st, shards)]          # exchange 2b (may not apply)
+    if all(b is not None for b in blocks):
+        blocks_all = torch.stack([b.clone() for b in blocks])
+        s_all = torch.cat([s.phase2(xs, csum_all, F * N, blocks_all).clone() for s, xs in zip(st, shards)])
+    else:
+        s_all = torch.cat([s.phase2(xs, csum_all, F * N).clone() for s, xs in zip(st, shards)])
     out = []
     for p, (s, xs) in enumerate(zip(st, shards)):
         s.select(xs, s_all, p * Fl)
@@ -100,10 +105,15 @@ def test_world_size_invariance_on_gpu(case):
     O.set_mode("torch")
     ref = O.compress_indices(x, N, base)
     O.set_mode("exact")
-    whole = vc.compress(xd, N, base)
+    whole = vc.compress(xd, N, base, want_scores=True)
     assert torch.equal(whole.global_idx.cpu(), ref["global_idx"])
     for P in (1, 2, 4):
         res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, base, P, dev)
+        if all(s.vc_fragile == 0 for s in st) and dtype != torch.float32:
+            # every boundary-near video-centre mean was replayed across the ranks: the scores themselves are the
+            # unsharded pass's bits, not only the decisions taken from them
+            tot = torch.cat([s.total for s in st])
+            assert torch.equal(tot, (whole.v_score + whole.f_score).float().flatten()), f"P={P}"
         gidx = torch.cat([r.global_idx for r in res]).cpu()
         ks = torch.cat([r.ks for r in res]).cpu()
         assert ks.tolist() == ref["ks"].tolist(), f"P={P}"

@@ -322,8 +322,14 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
 #define VC2_SEL_NT 1024
 #endif
 constexpr int kSelNT = VC2_SEL_NT;  // k_chan_select
-constexpr int kSelCoop = kSelNT >= 1024 ? 2 : (kSelNT >= 512 ? 4 : 8);     // quads per thread at D = 8192
-constexpr int kSelSolo = kSelNT >= 1024 ? 2 : 4;
+#ifndef VC2_SEL_ACTIVE
+#define VC2_SEL_ACTIVE 16
+#endif
+// waves that take part in a cooperative round (the rest idle at the barriers).  Measured at D = 3584: 16 -> 20.8 us,
+// 8 -> 22.2, 4 -> 27.4: the elements per thread cost more than the extra waves per SIMD
+constexpr int kSelActive = VC2_SEL_ACTIVE;
+constexpr int kSelCoop = 8192 / (64 * kSelActive * 4);                      // quads per thread at D = 8192
+constexpr int kSelSolo = kSelActive >= 16 ? 2 : 4;
 constexpr int kOrdNT = 256;         // k_chan_order: 4 waves per slice, like the rider workgroups of sweep 2
 
 // block-wide exclusive prefix of a small count (thread-contiguous chunks), fixed order; NW waves
@@ -351,8 +357,8 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   Sel2<W> S = sel2_carve<W>(smem, D);
   for (int i = tid; i < D; i += kSelNT) S.w[i] = T::pack(topk_key(var_f32[i]), i);
   __syncthreads();
-  if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
-  else topk_smallest2<W, NW, kSelSolo, kSelCoop>(S, D, k, tid);
+  if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
+  else topk_smallest2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, k, tid);
   __syncthreads();
   if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
   // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction)
@@ -1166,7 +1172,8 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       int D, const int* __restrict__ cols,
                                                       const int* __restrict__ spos, const float* __restrict__ den,
                                                       int strict, int replay_rows, int* __restrict__ fragile_count,
-                                                      float* __restrict__ l1g, int vstride, int* __restrict__ vtick) {
+                                                      float* __restrict__ l1g, int vstride, int* __restrict__ vtick,
+                                                      uint8_t* __restrict__ vflag = nullptr) {
   __shared__ float l1s[2052];                        // level-1 groups of one column (R <= 2^19 rows)
   const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = gridDim.y;
   const bool replay = strict != 0 && DT != VC2_F32;
@@ -1187,6 +1194,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
     if (y == 0) vc[c] = mean_T<DT>(t, R);
     flag = replay && R <= (int64_t(1) << 19) && (all || mean_near_T_boundary<DT>(float(t) / float(R)));
   }
+  if (vflag && y == 0 && c < C) vflag[c] = flag ? 1 : 0;         // (frame-sharded pass: which columns to replay)
   if (!replay) return;
   const uint64_t flagged = __ballot(flag);
   if (!flagged) return;
@@ -1239,6 +1247,85 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
     const float s = wave_cascade_final<DT>(l1s, nbv, x, D, col, den, 0, 1, R, lane);
     wave_lds_fence();
     if (lane == 0) vc[cc] = rnT<DT>(s / float(R));
+  }
+}
+
+// ---- frame-sharded pass: the video-centre replay across ranks ------------------------------------------------
+// Every rank flags the same columns (the flags come from the all-gathered group sums).  Slot j = the j-th flagged
+// column in ascending order.  k_vc_blocks: level-0 sums of MY rows -- blocks of 16 consecutive rows, added in row
+// order -- for the first `cap` flagged columns; these are all-gathered (rank order = row order) and k_vc_finish
+// runs the rest of torch's cascade over the whole video's blocks.  Needs rows-per-rank % 16 == 0 (blocks do not
+// straddle ranks) and the cascade's plain form (column in a full group of 32, R_total <= 2^19).
+__device__ __forceinline__ int nth_flagged_column(const uint8_t* __restrict__ vflag, int C, int j, int lane) {
+  // lane-contiguous chunks, wave scan; returns the column of the j-th set flag or -1 (same value in every lane)
+  const int E = (C + 63) / 64;
+  const int b = lane * E, e = min(C, b + E);
+  uint32_t cnt = 0;
+  for (int c = b; c < e; ++c) cnt += vflag[c] ? 1u : 0u;
+  const uint32_t incl = wave_incl_scan_u32(cnt);
+  const uint32_t before = incl - cnt;
+  int found = -1;
+  if (uint32_t(j) >= before && uint32_t(j) < incl) {
+    uint32_t k = before;
+    for (int c = b; c < e; ++c) if (vflag[c]) { if (k == uint32_t(j)) { found = c; break; } ++k; }
+  }
+  const uint64_t m = __ballot(found >= 0);
+  return m ? __shfl(found, __builtin_ctzll(m), 64) : -1;
+}
+
+template <int DT>
+__global__ __launch_bounds__(64) void k_vc_blocks(const uint8_t* __restrict__ vflag, int C, const void* __restrict__ x,
+                                                  int D, const int* __restrict__ cols, const int* __restrict__ spos,
+                                                  const float* __restrict__ den, int64_t nb_local,
+                                                  float* __restrict__ blocks_out) {
+  const int lane = threadIdx.x, j = blockIdx.y;
+  const int cc = nth_flagged_column(vflag, C, j, lane);
+  if (cc < 0) return;
+  const int col = cols ? cols[cc] : cc;
+  const int64_t b = int64_t(blockIdx.x) * 64 + lane;
+  if (b >= nb_local) return;
+  float v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, (b << 4) + u, D, col, den);
+  float a = v[0];
+#pragma unroll
+  for (int u = 1; u < 16; ++u) a += v[u];
+  blocks_out[int64_t(j) * nb_local + b] = a;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ vflag, int C,
+                                                   const int* __restrict__ spos, const float* __restrict__ blocks_all,
+                                                   int world, int cap, int64_t nb_local, int64_t R_total,
+                                                   float* __restrict__ vc, int* __restrict__ fragile_count) {
+  __shared__ float l1[2052];
+  const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x;
+  const int cc = nth_flagged_column(vflag, C, j, lane);
+  if (cc < 0) return;
+  const int group = C >= 8 ? 32 : 4;
+  const int sp = spos ? spos[cc] : cc;
+  if (sp >= (C / group) * group) return;                        // row_sum's interleaved chains: not replayed here
+  const int64_t nbv = R_total >> 4;                             // (R_total % 16 == 0: checked by the caller)
+  const int G1 = int((nbv + 15) >> 4);
+  for (int g = tid; g < G1; g += 256) {                         // level 1: 16 block sums in block order
+    const int64_t b0 = int64_t(g) << 4;
+    const int nbl = int(min<int64_t>(16, nbv - b0));
+    float a = 0.f;
+    for (int u = 0; u < nbl; ++u) {
+      const int64_t b = b0 + u;
+      const int64_t w = b / nb_local, bl = b - w * nb_local;
+      const float t = blocks_all[(w * cap + j) * nb_local + bl];
+      a = u == 0 ? t : a + t;
+    }
+    l1[g] = a;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, nbv << 4, lane);   // (no tail rows)
+    if (lane == 0) {
+      vc[cc] = rnT<DT>(s / float(R_total));
+      if (fragile_count) atomicSub(fragile_count, 1);            // one flagged column less that kept its exact mean
+    }
   }
 }
 
@@ -2547,10 +2634,48 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   return VC2_OK;
 }
 
+// can the frame-sharded pass replay its video-centre means (see k_vc_blocks)?
+static bool vc_blocks_ok(const Plan& p, int64_t R_total, int strict) {
+  return strict != 0 && p.dt != VC2_F32 && p.R % 16 == 0 && R_total % 16 == 0 && R_total <= (int64_t(1) << 19);
+}
+
+int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
+                            const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
+                            int64_t R_total, void* ws, size_t ws_bytes, float* blocks_out, int cap, void* stream) {
+  if (!x || !csum_all || !blocks_out || P <= 0 || csum_stride < C || cap <= 0)
+    return fail(VC2_ERR_ARG, "bad video_centre_blocks arguments");
+  { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p, R_total / N);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ChanSet cs0 = make_chanset(p, cols, spos, C);
+  if (!vc_blocks_ok(p, R_total, cs0.strict)) return VC2_OK;      // nothing to exchange: phase 2 keeps the exact means
+  uint8_t* vflag = wsp<uint8_t>(ws, p.o_mask);
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
+                                            csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
+                                            int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
+                                            (int*)nullptr, (float*)nullptr, 0, (int*)nullptr, vflag));
+  const int64_t nb = p.R / 16;
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64)), unsigned(cap)), dim3(64), 0, st,
+                                            vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), nb,
+                                            blocks_out));
+  return check_launch("video_centre_blocks");
+}
+
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
                       const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
                       int64_t R_total, void* ws,
                       size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
+  return vc2_scores_phase2_blocks(x, F, N, D, dtype, cols, C, spos, csum_all, P, csum_stride, R_total, ws, ws_bytes, v_T,
+                                  f_T, total_f32, s_f32, nullptr, 0, 0, stream);
+}
+
+int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
+                             const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
+                             int64_t R_total, void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32,
+                             float* s_f32, const float* blocks_all, int world, int cap, void* stream) {
   if (!x || !csum_all || P <= 0 || csum_stride < C) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
@@ -2562,10 +2687,15 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
                                             csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                             int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
-                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr));
-  // (ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary: this pass
-  // keeps the exactly rounded mean there -- the unsharded pass replays torch's summation order --, and
-  // vc2_select_sharded reports the count in K_out[2])
+                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr,
+                                            wsp<uint8_t>(ws, p.o_mask)));
+  // ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary.  With the
+  // all-gathered level-0 block sums (vc2_video_centre_blocks) torch's cascade is finished here for the first `cap`
+  // of them; the others keep the exactly rounded mean and stay counted (vc2_select_sharded reports K_out[2]).
+  if (blocks_all && world > 0 && cap > 0 && vc_blocks_ok(p, R_total, cs0.strict) && R_total == int64_t(world) * p.R)
+    VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_finish<DT>), dim3(unsigned(cap)), dim3(256), 0, st,
+                                              wsp<uint8_t>(ws, p.o_mask), int(C), spos, blocks_all, world, cap,
+                                              p.R / 16, R_total, wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket) + 5));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, make_chanset(p, cols, spos, C), ws, v_T, f_T, total, s, st);

@@ -333,7 +333,10 @@ __host__ __device__ constexpr int sel2_capacity(int nw, int eq) { return 64 * nw
 // std::nth_element(first, first + nth, first + n) on S.w[0, n).  All 64*NW threads of the workgroup call this
 // (tid = threadIdx.x).  Ranges longer than sel2_capacity(1, SOLO) are partitioned by all NW waves together
 // (n <= sel2_capacity(NW, COOP)), shorter ones by wave 0 alone.
-template <typename W, int NW, int SOLO, int COOP>
+// NWA (<= NW): the waves that take part in a cooperative round; the others only keep the workgroup barriers company.
+// A partition round is a serial chain of dependent steps: more than one wave per SIMD on it only contend for issue
+// slots (measured: 16-wave rounds ~4 us, 4-wave rounds ~2.2 us at 3584 elements).
+template <typename W, int NW, int SOLO, int COOP, int NWA = NW>
 __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, int tid) {
   if (n == 0 || nth >= n) return;
   int lo = 0, hi = n;
@@ -347,7 +350,19 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
         break;
       }
       --depth;
-      const int cut = sel2_partition<W, NW, 1, COOP>(S, lo, hi, S.la, S.lb, tid);
+      int cut;
+      if constexpr (NWA == NW) {
+        cut = sel2_partition<W, NW, 1, COOP>(S, lo, hi, S.la, S.lb, tid);
+      } else {
+        if (tid < 64 * NWA) {
+          cut = sel2_partition<W, NWA, 1, COOP>(S, lo, hi, S.la, S.lb, tid);
+        } else {                                              // the partition's three workgroup barriers, then its cut
+          __syncthreads(); __syncthreads(); __syncthreads();
+          const uint32_t cutv = S.xch[kXchCut];
+          cut = cutv < uint32_t(hi) ? int(cutv) : hi;
+        }
+        // (the cut cell is reset by thread 0 after the NEXT round's first barrier: every reader is done by then)
+      }
       if (cut <= nth) lo = cut; else hi = cut;
       if (guard == 255 && tid == 0) guard_hit(0);
     }
@@ -371,14 +386,14 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
 
 // torch.topk(v, k, largest=False) SET: afterwards S.w[0, k) holds the kept elements (ATen/native/TopKImpl.h:
 // partial_sort when k*64 <= n, else nth_element(k-1))
-template <typename W, int NW, int SOLO, int COOP>
+template <typename W, int NW, int SOLO, int COOP, int NWA = NW>
 __device__ __forceinline__ void topk_smallest2(const Sel2<W>& S, int n, int k, int tid) {
   if (k <= 0 || k >= n) return;                               // k == n: everything kept, nothing moves
   if (int64_t(k) * 64 <= int64_t(n)) {
     if (tid == 0) s2_heap_select(S.w, 0, k, n);               // partial_sort = heap_select + sort_heap (only permutes [0,k))
     sel2_sync<NW>();
   } else {
-    introselect2<W, NW, SOLO, COOP>(S, n, k - 1, tid);
+    introselect2<W, NW, SOLO, COOP, NWA>(S, n, k - 1, tid);
   }
 }
 

@@ -68,13 +68,17 @@ class HipStages:
         self.idx = torch.empty(self.cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(F, dtype=torch.int64, device=self.device)
         self.kout = torch.zeros(4, dtype=torch.int64, device=self.device)     # K, capacity overflow, fragile centre columns
+        # exchange 2b (video-centre replay): level-0 block sums of this rank's rows for up to VC_CAP flagged columns
+        self.vc_cap = 16
+        self.vc_replay = dtype != torch.float32 and (F * N) % 16 == 0
+        self.blocks = torch.zeros((self.vc_cap, max(1, F * N // 16)), dtype=torch.float32, device=self.device)
         self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
 
         # device pointers of the fixed buffers, resolved once: the per-pass host work is five C calls plus
         # three collectives, and that host time bounds the pass when it exceeds the ~0.3 ms of GPU work
         self._L = L
         self._p = {n: ptr(getattr(self, n)) for n in ("ws", "stats", "csum", "var_f32", "mask", "cols", "perm",
-                                                     "spos", "total", "s", "idx", "ks", "kout", "rows")}
+                                                     "spos", "total", "s", "idx", "ks", "kout", "rows", "blocks")}
         self._ws_n = self.ws.numel()
 
     def _st(self):
@@ -104,12 +108,28 @@ class HipStages:
               "vc2_scores_phase1")
         return self.csum
 
-    def phase2(self, x, csum_all, R_total):
+    def vc_blocks(self, x, csum_all, R_total):
+        """Exchange 2b: this rank's level-0 block sums of the boundary-near video-centre columns, or None when the
+        replay does not apply (fp32, exact mode, rows per rank not a multiple of 16, more than 2^19 tokens) -- a
+        decision every rank takes identically."""
+        if not self.vc_replay or _ffi.get_mode() != "torch" or R_total > (1 << 19) or R_total % 16 != 0:
+            return None
+        p = self._p
+        parts = csum_all.reshape(-1, csum_all.shape[-1])
+        check(self._L.vc2_video_centre_blocks(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
+                                              ptr(parts), parts.shape[0], parts.shape[1], R_total, p["ws"], self._ws_n,
+                                              p["blocks"], self.vc_cap, self._st()), "vc2_video_centre_blocks")
+        return self.blocks
+
+    def phase2(self, x, csum_all, R_total, blocks_all=None):
         p = self._p
         parts = csum_all.reshape(-1, csum_all.shape[-1])       # [world * groups, C], rank order = frame order
-        check(self._L.vc2_scores_phase2(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
-                                        ptr(parts), parts.shape[0], parts.shape[1], R_total, p["ws"],
-                                        self._ws_n, None, None, p["total"], p["s"], self._st()), "vc2_scores_phase2")
+        world = 0 if blocks_all is None else int(blocks_all.shape[0])
+        check(self._L.vc2_scores_phase2_blocks(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
+                                               ptr(parts), parts.shape[0], parts.shape[1], R_total, p["ws"],
+                                               self._ws_n, None, None, p["total"], p["s"],
+                                               ptr(blocks_all) if blocks_all is not None else None, world, self.vc_cap,
+                                               self._st()), "vc2_scores_phase2")
         return self.s
 
     def select(self, x, s_all, f0):
@@ -127,8 +147,10 @@ class HipStages:
         if vc_fragile and _ffi.get_mode() == "torch":
             import warnings
             warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within 16 fp32-ulps of a "
-                          "rounding boundary; this path keeps the exactly rounded mean there, the reference's fp32 summation "
-                          "order could round the other way (the unsharded pass replays it).", RuntimeWarning, stacklevel=2)
+                          "rounding boundary and could not be replayed across ranks (rows per rank not a multiple of 16, more "
+                          "than 16 such columns, or a channel count that is not a multiple of 32); they keep the exactly "
+                          "rounded mean, the reference's fp32 summation order could round the other way.",
+                          RuntimeWarning, stacklevel=2)
         li = self.idx[:K]
         return ShardResult(self.rows[:K] if self.rows is not None else None, li, li + f0 * self.N, self.ks, int(K))
 
@@ -189,7 +211,12 @@ class ShardedCompressor:
         stats_all = self._gather("stats", st.chan_stats(x_local))               # exchange 1: [W, 2, D] fp64
         st.select_channels(stats_all, R_total)
         csum_all = self._gather("csum", st.phase1(x_local))                     # exchange 2: [W, D] fp64
-        s_all = self._gather("s", st.phase2(x_local, csum_all, R_total))        # exchange 3: [W, F_local]
+        blocks = st.vc_blocks(x_local, csum_all, R_total) if hasattr(st, "vc_blocks") else None
+        if blocks is not None:                                                   # exchange 2b: [W, 16, R_local/16] fp32
+            s_loc = st.phase2(x_local, csum_all, R_total, self._gather("blocks", blocks))
+        else:
+            s_loc = st.phase2(x_local, csum_all, R_total)
+        s_all = self._gather("s", s_loc)                                         # exchange 3: [W, F_local]
         st.select(x_local, s_all.reshape(-1), self.f0)
 
     def finish(self) -> ShardResult:

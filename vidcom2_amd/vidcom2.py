@@ -12,6 +12,7 @@ input's device.  Tensors must live on a ROCm device: there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import warnings
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -101,6 +102,13 @@ class CompressPlan:
         if self.map_mode == MAP_GRID_VID:
             cap += self.F * self.grid_h
         self.cap = cap
+        if dtype != torch.float32 and _ffi.get_mode() == "torch" and (self.F * self.N > (1 << 19) or self.N > (1 << 17)):
+            # beyond these sizes torch's outer-sum cascade changes shape (SumKernel.cpp level_power) and the centre-mean
+            # replays are not modelled: say so instead of silently keeping the exactly rounded means
+            warnings.warn(f"vidcom2_amd: {self.F} x {self.N} tokens exceed the modelled range of torch's centre-mean "
+                          "accumulation order (2^19 tokens per video, 2^17 per frame); boundary-near centre values "
+                          "keep their exactly rounded mean and may differ from the CPU reference by one ulp",
+                          RuntimeWarning, stacklevel=3)
         self.ws = ws if ws is not None else _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
         self.idx = torch.empty(cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(self.F, dtype=torch.int64, device=self.device)
