@@ -1823,7 +1823,13 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       if (i < F) {
         if (vpart) {
           double t = 0.0;
-          for (int q = 0; q < S2; ++q) t += vpart[int64_t(i) * S2 + q];
+          for (int q0 = 0; q0 < S2; q0 += 8) {                  // eight loads in flight, added in split order
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = vpart[int64_t(i) * S2 + min(q0 + u, S2 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (q0 + u < S2) t += pv[u];
+          }
           sv[j] = -mean_T<DT>(t, N);                              // vidcom2.py:32
         } else {
           sv[j] = frame_scores[i];
