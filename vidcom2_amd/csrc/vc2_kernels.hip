@@ -454,13 +454,14 @@ struct OrderArgs {          // the ORDER job (all null: none), done by `parts` w
 };
 // workgroups for the ORDER job: 2^L arrival segments of >= 128 positions on average
 #ifndef VC2_RIDER_PARTS
-#define VC2_RIDER_PARTS 16     // rider workgroups of sweep 2 (4 waves each)
+#define VC2_RIDER_PARTS 64     // rider workgroups of sweep 2 (4 waves each); 16 -> 64: the slowest rider (largest
+                               // arrival segment) sets the time: cfg2 131 -> 124 us
 #endif
 #ifndef VC2_ORDER_PARTS
-#define VC2_ORDER_PARTS 16     // workgroups of the stand-alone k_chan_order
+#define VC2_ORDER_PARTS 64     // workgroups of the stand-alone k_chan_order
 #endif
 #ifndef VC2_ORDER_MINSEG
-#define VC2_ORDER_MINSEG 64
+#define VC2_ORDER_MINSEG 16
 #endif
 __host__ inline int order_parts(int k, int max_parts) {        // a power of two
   int parts = 1;
@@ -2128,7 +2129,13 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   {
     // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
     // that the 10 exp per token of the fused epilogue are ONE round over the workgroup's 256 threads
-    int64_t rps = std::max<int64_t>(16, std::min<int64_t>(25, cdiv(p->R, 1024)));
+#ifndef VC2_DIST_WGS
+#define VC2_DIST_WGS 1024
+#endif
+#ifndef VC2_DIST_RPS_MIN
+#define VC2_DIST_RPS_MIN 16
+#endif
+    int64_t rps = std::max<int64_t>(VC2_DIST_RPS_MIN, std::min<int64_t>(25, cdiv(p->R, VC2_DIST_WGS)));
     rps = std::min<int64_t>(rps, N);
     p->S2 = int(cdiv(N, rps));
     p->rows_per_split2 = int(cdiv(N, p->S2));
@@ -2321,7 +2328,11 @@ inline bool fast_acc(const Plan& p, const ChanSet& cs) { return cs.strict != 0 &
 template <int DT, int VEC, int NPLB, int ACC>
 int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
   const int* cols = cs.cols; const int C = cs.C;
+#ifdef VC2_NO_RIDER
+  constexpr int RIDER = 0;
+#else
   constexpr int RIDER = (ACC == 1 && VEC > 1) ? 1 : 0;       // the kernels that can carry the ORDER rider
+#endif
   if (rider.perm && !RIDER) return fail(VC2_ERR_UNSUPPORTED, "internal: ORDER rider on a sweep without one");
   size_t smem = std::max<size_t>(2 * kRowWaves * row_lds_bytes(int(p.D), Tr<DT>::ES),
                                  size_t(kRowWaves) * NPLB * 64 * 8);               // row buffers, then the combine
