@@ -265,7 +265,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DT_NAME[dtype], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {F_total} frames x {N} tokens x {D}-d {DT_NAME[dtype]}, "
-                               f"retain {base}" + (f", frame-sharded {F} frames/GPU, 3 RCCL all-gathers" if dist_on else ""),
+                               f"retain {base}" + (f", frame-sharded {F} frames/GPU, 4 RCCL all-gathers" if dist_on else ""),
                    "kept_tokens": K, "parallelism": f"frame-shard x{world}" if dist_on else "single GPU"},
         "roofline": roof,
         "cpu_baseline": cpu,

@@ -2123,7 +2123,10 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   // same launch, so the splits are chosen to leave them slots -- with 512 + 16 workgroups the last 16 start when the
   // riders end and the sweep takes 51 instead of 36 us; with 384 + 16 it takes 41.
   const int64_t riders = (g_strict && dt != VC2_F32) ? VC2_RIDER_PARTS : 0;
-  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, (512 - riders) / p->F_total));
+  // S is chosen from THIS rank's frames (occupancy), not from the whole video's: the frame sums are fp64 sums of
+  // T-rounded x^ in [-1, 1] -- exact (so independent of how the rows are cut) for fp16 by range (2^-24 .. 1, <= 8192
+  // rows: 48 bits), and for bf16 unless a nonzero |x^| < 2^-39 meets a frame sum > 2^6
+  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, (512 - riders) / F));
   p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), std::min<int64_t>(N, 8 * kRowWaves)));
   p->S = int(cdiv(N, p->rows_per_split));
   {
