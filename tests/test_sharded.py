@@ -35,6 +35,11 @@ def _worker(rank, world, port, dtype_name, q):
         xl = x[rank * Fl * N: (rank + 1) * Fl * N].contiguous()
         sc = ShardedCompressor(Fl, N, D, dtype, "cpu", base, stages=OracleStages(Fl, N, D, dtype, base))
         res = sc(xl)
+        # SURVEY §8e "output": every rank (or one) can also get ALL kept rows, in frame order
+        rows_all, gidx_all, counts = sc.gather_kept(res)
+        assert counts[rank] == res.K and torch.equal(rows_all, x[gidx_all])
+        only0 = sc.gather_kept(res, dst=0)
+        assert (only0 is None) == (rank != 0)
         q.put((rank, res.global_idx.tolist(), res.ks.tolist(), synth.sha256_tensor(res.rows)))
     finally:
         dist.destroy_process_group()
@@ -151,6 +156,8 @@ def _gpu_worker(rank, world, port, q):
         sc = ShardedCompressor(Fl, N, D, torch.bfloat16, dev, base)
         res = sc(xl)
         torch.cuda.synchronize()
+        rows_all, gidx_all, counts = sc.gather_kept(res)
+        assert sum(counts) == rows_all.shape[0] and torch.equal(rows_all.cpu(), x[gidx_all.cpu()])
         q.put((rank, res.global_idx.cpu().tolist(), res.ks.cpu().tolist(), synth.sha256_tensor(res.rows.cpu())))
     finally:
         dist.destroy_process_group()

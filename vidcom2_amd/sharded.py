@@ -225,3 +225,29 @@ class ShardedCompressor:
     def __call__(self, x_local: torch.Tensor) -> ShardResult:
         self.enqueue(x_local)
         return self.finish()
+
+    def gather_kept(self, res: ShardResult, dst: Optional[int] = None):
+        """All ranks' kept rows in frame order (SURVEY.md §8e "output": the consumer is usually one rank's LLM
+        prefill).  Two all-gathers: the per-rank counts, then the rows padded to the largest count (an all-gather-v).
+        Returns (rows [K_total, D], global_idx [K_total], counts) on every rank, or only on rank `dst` (None
+        elsewhere).  The kept rows stay sharded unless this is called."""
+        if res.rows is None:
+            raise RuntimeError("gather_kept needs a compressor built with gather=True")
+        if self.world == 1:
+            return res.rows, res.global_idx, [res.K]
+        dev = res.rows.device
+        counts = _all_gather(torch.tensor([res.K], dtype=torch.int64, device=dev), self.group, self.world).view(-1)
+        counts = [int(c) for c in counts.tolist()]                  # (host sync: sizes of the result)
+        kmax = max(counts)
+        D = res.rows.shape[1]
+        pad_rows = torch.zeros((kmax, D), dtype=res.rows.dtype, device=dev)
+        pad_idx = torch.zeros(kmax, dtype=torch.int64, device=dev)
+        pad_rows[: res.K] = res.rows
+        pad_idx[: res.K] = res.global_idx
+        all_rows = _all_gather(pad_rows, self.group, self.world)
+        all_idx = _all_gather(pad_idx, self.group, self.world)
+        if dst is not None and self.rank != dst:
+            return None
+        rows = torch.cat([all_rows[r, :c] for r, c in enumerate(counts)])
+        gidx = torch.cat([all_idx[r, :c] for r, c in enumerate(counts)])
+        return rows, gidx, counts
