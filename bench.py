@@ -194,6 +194,8 @@ def main():
     #                                 sharded code path on one GPU; used by the single-GPU smoke run only)
     if args.gpus != world and rank == 0 and dist_on:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if os.environ.get("VC2_BENCH_ONE_GPU") == "1":    # test knob: every rank on cuda:0 (with VC2_BENCH_BACKEND=gloo;
+        local = 0                                     # RCCL refuses two ranks on one device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
@@ -203,7 +205,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         # lazy communicator creation on purpose: with `device_id=` (eager init) every pass measured ~45 us slower on
         # this stack in round 1; with it the numbers match a plain process
-        torch.distributed.init_process_group("nccl")
+        torch.distributed.init_process_group(os.environ.get("VC2_BENCH_BACKEND", "nccl"))
 
     import vidcom2_amd as vc
     from vidcom2_amd import _ffi, synth
