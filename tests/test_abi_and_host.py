@@ -90,3 +90,18 @@ def test_synth_is_deterministic():
     assert np.array_equal(x32[2:4], synth.make_fp32_frames(4, 5, 8, 2, 2, 1))
     bits = synth.f32_to_bf16_bits(np.array([1.0, 1.00390625, 1.01171875, np.inf, -0.0], np.float32))
     assert bits.tolist() == [0x3F80, 0x3F80, 0x3F82, 0x7F80, 0x8000]    # ties-to-even
+
+
+def test_fused_ops_have_no_cpu_fallback():
+    """f1 / f3 host mirrors: argument checks run anywhere, the work itself only on a ROCm device."""
+    from vidcom2_amd import fused
+    x = torch.zeros(4, 8, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback|CPU fallback"):
+        fused.gather_scatter([x])
+    with pytest.raises(ValueError):
+        fused.gather_scatter([])
+    with pytest.raises(RuntimeError, match="no CPU fallback|CPU fallback"):
+        fused.keep_positions(torch.zeros(5, dtype=torch.bool), torch.zeros(0, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="no CPU fallback|CPU fallback"):
+        fused.pool_stats(torch.zeros(2, 16, 8, dtype=torch.bfloat16), 4, 4, "average")
+    assert set(fused.POOL_MODES) == {"average", "max", "bilinear"}
