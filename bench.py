@@ -366,34 +366,34 @@ def main():
                           "pass_frac_of_8TBs": round(alg_bytes_pass(Fb, N, D, es, base) / (eb / nb) / 1e9 / HBM_PEAK_GBS, 4),
                           "kernels_us": kb}
         del xb, pb
-    # ---- side (f3): LLaVA's get_2dPool fused with sweep 1.  Projector output 128 x (28x28) x 3584 bf16, average pool
-    #      to 14x14 = 196 tokens: torch's permute/avg_pool2d/permute on the device + the full pass, against
+    # ---- side (f3): LLaVA's get_2dPool fused with sweep 1.  Projector output 128 x (27x27) x 3584 bf16, bilinear pool
+    #      to 14x14 = 196 tokens: torch's permute/interpolate/permute on the device + the full pass, against
     #      fused.pool_stats + the pass without its first sweep -------------------------------------------------
     if extra and args.workload == "target" and dtype != torch.float32:
         from vidcom2_amd.fused import pool_stats
-        Hs = 28
+        Hs = 27                                      # LLaVA-OneVision: 27 x 27 patches -> bilinear -> 14 x 14 = 196
         xin = torch.randn(F, Hs * Hs, D, device=dev, dtype=torch.float32).to(dtype)
         pl_a = vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base)
 
         def unfused():
             t = xin.view(F, Hs, Hs, D).permute(0, 3, 1, 2).contiguous()
-            t = torch.nn.functional.avg_pool2d(t, 2).permute(0, 2, 3, 1).reshape(F * N, D)
+            t = torch.nn.functional.interpolate(t, size=[14, 14], mode="bilinear").permute(0, 2, 3, 1).reshape(F * N, D)
             pl_a.enqueue(t)
 
         def fused():
-            pooled, ws = pool_stats(xin, Hs, Hs, "average")
+            pooled, ws = pool_stats(xin, Hs, Hs, "bilinear")
             pl_b = vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base, ws=ws)
             pl_b.enqueue(pooled.view(F * N, D), have_stats=True)
 
         def pool_only():
-            pool_stats(xin, Hs, Hs, "average")
+            pool_stats(xin, Hs, Hs, "bilinear")
         res = {}
         for name, fn in (("torch_pool_then_pass", unfused), ("fused_pool_stats_then_pass", fused),
                          ("pool_stats_kernel_only", pool_only)):
             for _ in range(5):
                 fn()
             res[name + "_us"] = round(time_steps(fn, max(10, args.steps // 2), False) / max(10, args.steps // 2) * 1e6, 1)
-        res["workload"] = f"{F}x({Hs}x{Hs})x{D} {DT_NAME[dtype]} -> average pool -> {F}x{N}x{D}, retain {base}"
+        res["workload"] = f"{F}x({Hs}x{Hs})x{D} {DT_NAME[dtype]} -> bilinear pool (get_2dPool) -> {F}x{N}x{D}, retain {base}"
         res["pool_alg_bytes"] = F * (Hs * Hs + N) * D * es
         res["pool_alg_GBs"] = round(res["pool_alg_bytes"] / (res["pool_stats_kernel_only_us"] * 1e-6) / 1e9, 1)
         out["llava_pool_fused"] = res

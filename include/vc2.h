@@ -156,10 +156,10 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
  * written once and vc2_compress_ex(..., VC2_FLAG_HAVE_STATS) reads it only twice more.
  *   VC2_POOL_AVG       avg_pool2d(kernel 2, stride 2): h = H/2, w = W/2; bit-exact to torch (fp32 sum in window order, / 4)
  *   VC2_POOL_MAX       max_pool2d(2): bit-exact (NaN propagates like torch)
- *   VC2_POOL_BILINEAR  interpolate(size=ceil(H/2) x ceil(W/2), mode="bilinear", align_corners=False): ATen's source
- *                      index / lambda arithmetic and its SCALAR loop's fma order; ATen's vector loop (C >= 16 on x86)
- *                      contracts differently, so outputs can differ from torch in the last fp32 bit before the
- *                      rounding to T (measured: ~1e-4 of bf16 outputs by one bf16 ulp).  Not used by default. */
+ *   VC2_POOL_BILINEAR  interpolate(size=ceil(H/2) x ceil(W/2), mode="bilinear", align_corners=False): bit-exact to
+ *                      torch 2.10's x86 CPU kernel (ATen's source index / lambda arithmetic and the fma order of its
+ *                      vectorised channel loop); needs D % 8 == 0 (fp32) / D % 16 == 0 (16-bit), else
+ *                      VC2_ERR_UNSUPPORTED (the loop's scalar tail contracts differently). */
 #define VC2_POOL_AVG 1
 #define VC2_POOL_MAX 2
 #define VC2_POOL_BILINEAR 3

@@ -79,8 +79,12 @@ constexpr int kStatBlockFrames = 8;
 //   1 average: ((a + b) + c) + d in fp32, / 4, one rounding to T      (torch avg_pool2d's accumulation order)
 //   2 max
 //   3 bilinear to ceil(H/2) x ceil(W/2), align_corners=False: index / weights as ATen's
-//     compute_source_index_and_lambda (fma'd source index), out = fma(w11,d, fma(w10,c, fma(w00,a, w01*b))), one
-//     rounding to T -- the arithmetic of ATen's scalar loop; its vector loop contracts differently (last fp32 bit).
+//     compute_source_index_and_lambda (fma'd source index); the four products w_yx * v are added in the order ATen's
+//     vectorised channel loop (cpu_upsample_linear_channels_last, the kernel NCHW inputs with C >= 8 end up in) is
+//     contracted to by the x86 build of torch 2.10: fp32  fma(w00,a, fma(w01,b, fma(w11,d, w10*c))),
+//     bf16 / fp16  fma(w00,a, fma(w01,b, fma(w10,c, w11*d))); one rounding to T.  (Found by exhaustive search over
+//     the association orders against torch's own outputs; the loop's scalar tail -- D % 8 channels in fp32, D % 16 in
+//     16-bit -- contracts differently, so such D are refused.)
 struct PoolSrc { const void* xin; int H, W, h, w, mode; };
 
 template <int DT, int VEC>
@@ -123,9 +127,12 @@ __device__ __forceinline__ void pooled_row(const PoolSrc& ps, int64_t rr, int N,
       if (b[j] > o || b[j] != b[j]) o = b[j];
       if (c[j] > o || c[j] != c[j]) o = c[j];
       if (d[j] > o || d[j] != d[j]) o = d[j];
-    } else {
-      o = w01 * b[j];
-      o = __builtin_fmaf(w00, a[j], o); o = __builtin_fmaf(w10, c[j], o); o = __builtin_fmaf(w11, d[j], o);
+    } else if constexpr (DT == VC2_F32) {      // ATen's Vectorized<float> loop (8 channels per step) as GCC contracts it
+      o = w10 * c[j];
+      o = __builtin_fmaf(w11, d[j], o); o = __builtin_fmaf(w01, b[j], o); o = __builtin_fmaf(w00, a[j], o);
+    } else {                                   // ... and its reduced-precision instantiation (16 channels per step)
+      o = w11 * d[j];
+      o = __builtin_fmaf(w10, c[j], o); o = __builtin_fmaf(w01, b[j], o); o = __builtin_fmaf(w00, a[j], o);
     }
     v[j] = rnT<DT>(o);
   }
@@ -2797,6 +2804,9 @@ int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, 
   int rc = vc2_pool_out_tokens(H, W, mode, &h, &w);
   if (rc) return rc;
   if (H > 32768 || W > 32768) return fail(VC2_ERR_UNSUPPORTED, "H, W up to 32768");
+  if (mode == VC2_POOL_BILINEAR && D % (dtype == VC2_F32 ? 8 : 16) != 0)
+    return fail(VC2_ERR_UNSUPPORTED, "bilinear pooling: D=%lld is not a multiple of torch's vector width (%d)",
+                (long long)D, dtype == VC2_F32 ? 8 : 16);
   Plan p;
   if ((rc = make_plan(F, h * w, D, dtype, &p))) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;

@@ -147,8 +147,8 @@ def pool_stats(image_feature: torch.Tensor, height: int, width: int, mode: str =
 
     Returns (pooled `[F, h*w, D]`, workspace): hand the workspace to `compress(..., stats_ws=workspace)` /
     `CompressPlan(..., ws=workspace).enqueue(..., have_stats=True)` on the same stream and the pass skips its first
-    sweep.  "average" and "max" reproduce torch's avg_pool2d / max_pool2d bits; "bilinear" follows ATen's scalar
-    arithmetic (see include/vc2.h) and may differ from torch's vector loop in the last bit."""
+    sweep.  All three modes reproduce torch's bits (avg_pool2d / max_pool2d / interpolate(mode="bilinear") on the x86
+    CPU build; bilinear needs D % 8 == 0 in fp32, D % 16 == 0 in 16-bit, see include/vc2.h)."""
     from . import _ffi
     require_device(image_feature, "image_feature")
     if mode not in POOL_MODES:

@@ -88,16 +88,19 @@ class _PooledWithStats(torch.Tensor):
 
 
 def _fused_pool(model, pool_inner, image_feature, args, kwargs):
-    """get_2dPool + sweep 1 in one kernel when the configuration allows a bit-identical pooled tensor (average / max;
-    bilinear only with VC2_FUSED_POOL=bilinear: last-bit differences to torch's vector loop).  None: not applicable."""
+    """get_2dPool + sweep 1 in one kernel when the configuration allows a bit-identical pooled tensor (average / max
+    / bilinear with a feature size that is a multiple of torch's vector width).  None: not applicable.
+    VC2_FUSED_POOL=off keeps the model's own pooling."""
     import os
     stride = args[0] if args else kwargs.get("stride", 2)
     mode = getattr(model.config, "mm_spatial_pool_mode", None)
     knob = os.getenv("VC2_FUSED_POOL", "")
     if knob == "off":
         return None
-    allowed = {"average", "max"} | ({"bilinear"} if knob == "bilinear" else set())
-    if stride != 2 or mode not in allowed or not (torch.is_tensor(image_feature) and image_feature.is_cuda):
+    if stride != 2 or mode not in ("average", "max", "bilinear") or not (torch.is_tensor(image_feature)
+                                                                         and image_feature.is_cuda):
+        return None
+    if mode == "bilinear" and image_feature.shape[-1] % (8 if image_feature.dtype == torch.float32 else 16) != 0:
         return None
     if image_feature.dim() != 3 or image_feature.dtype not in (torch.float32, torch.bfloat16, torch.float16):
         return None
