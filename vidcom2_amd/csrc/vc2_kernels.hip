@@ -2683,7 +2683,7 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
                                             csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                             int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
-                                            (int*)nullptr, (float*)nullptr, 0, (int*)nullptr, vflag));
+                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr, vflag));
   const int64_t nb = p.R / 16;
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64)), unsigned(cap)), dim3(64), 0, st,
                                             vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), nb,
@@ -2711,15 +2711,18 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
-  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
-                                            csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
-                                            int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
-                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr,
-                                            wsp<uint8_t>(ws, p.o_mask)));
+  const bool have_blocks = blocks_all && world > 0 && cap > 0 && vc_blocks_ok(p, R_total, cs0.strict) &&
+                           R_total == int64_t(world) * p.R;
+  if (!have_blocks)      // (with blocks: vc2_video_centre_blocks already computed the means, the flags and the count)
+    VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
+                                              csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
+                                              int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
+                                              wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr,
+                                              wsp<uint8_t>(ws, p.o_mask)));
   // ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary.  With the
   // all-gathered level-0 block sums (vc2_video_centre_blocks) torch's cascade is finished here for the first `cap`
   // of them; the others keep the exactly rounded mean and stay counted (vc2_select_sharded reports K_out[2]).
-  if (blocks_all && world > 0 && cap > 0 && vc_blocks_ok(p, R_total, cs0.strict) && R_total == int64_t(world) * p.R)
+  if (have_blocks)
     VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_finish<DT>), dim3(unsigned(cap)), dim3(256), 0, st,
                                               wsp<uint8_t>(ws, p.o_mask), int(C), spos, blocks_all, world, cap,
                                               p.R / 16, R_total, wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket) + 5));
