@@ -813,7 +813,7 @@ constexpr uint32_t kBf16SpanLen = 0x3880u;    // ... up to 2^50 (0x5880)
 template <int DT, int VEC, int NPLB, int ACC, int RIDER>
 __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
                                                                 int C, const int* __restrict__ cols,
-                                                                int strict, int S, int rows_per_split,
+                                                                int strict, int S, int nhi,
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ nfix_count, int* __restrict__ nfix_list,
                                                                 int nfix_cap, uint8_t* __restrict__ rflag,
@@ -839,7 +839,11 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = bid / S, sp = bid % S;
+  // frames [0, nhi) are cut in S pieces, the others in S - 1 (make_plan: the launch fills the resident slots exactly)
+  int f, sp, Sf;
+  if (bid < nhi * S) { f = bid / S; sp = bid - f * S; Sf = S; }
+  else { const int b2 = bid - nhi * S; f = nhi + b2 / (S - 1); sp = b2 - (f - nhi) * (S - 1); Sf = S - 1; }
+  const int rows_per_split = (N + Sf - 1) / Sf;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
   unsigned char* buf0 = smem + size_t(2 * wave) * rowb;          // [kRowWaves][2][rowb]; later double sacc[C]
@@ -932,7 +936,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     double t = sacc[p];
 #pragma unroll
     for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
-    part[int64_t(bid) * C + p] = t;
+    part[(int64_t(f) * S + sp) * C + p] = t;
   }
 }
 
@@ -1096,7 +1100,7 @@ __device__ float wave_column_solo(float* l1s, bool simple, const void* __restric
 constexpr int kCen2List = 1024;
 
 template <int DT>
-__global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int N,
+__global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_nhi, int N,
                                                                    int C, float* __restrict__ fc,
                                                                    double* __restrict__ csum_part,
                                                                    const void* __restrict__ x, int D,
@@ -1123,12 +1127,13 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   __syncthreads();
   double sf = 0.0;
   if (c < C && f < F) {
-    for (int s0 = 0; s0 < S; s0 += 8) {                         // (S <= 8: one batch of loads, added in split order)
+    const int Sf = f < S_nhi ? S : S - 1;                       // this frame's pieces (see make_plan)
+    for (int s0 = 0; s0 < Sf; s0 += 8) {                        // (S <= 8: one batch of loads, added in split order)
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t(f) * S + min(s0 + u, S - 1)) * C + c];
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t(f) * S + min(s0 + u, Sf - 1)) * C + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (s0 + u < S) sf += v[u];
+      for (int u = 0; u < 8; ++u) if (s0 + u < Sf) sf += v[u];
     }
     const int nc = corr_count ? *corr_count : 0;
     for (int e = 0; e < nc; ++e) {                              // rows whose norm k_norm_fix corrected (normally none)
@@ -2091,7 +2096,7 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups (G = F * stat_splits), stat blocks
   int stat_splits, NB, BF;      // groups per frame; stat blocks of BF (<= kStatBlockFrames) frames
   int64_t F_total;              // frames of the WHOLE video (frame-sharded pass: canonical blockings depend on it)
-  int S, rows_per_split;        // sweep-2 splits per frame
+  int S, S_nhi;                 // sweep 2: frames [0, S_nhi) are cut in S pieces, the others in S - 1
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
@@ -2133,9 +2138,14 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   // S is chosen from THIS rank's frames (occupancy), not from the whole video's: the frame sums are fp64 sums of
   // T-rounded x^ in [-1, 1] -- exact (so independent of how the rows are cut) for fp16 by range (2^-24 .. 1, <= 8192
   // rows: 48 bits), and for bf16 unless a nonzero |x^| < 2^-39 meets a frame sum > 2^6
-  int64_t s = std::max<int64_t>(1, std::min<int64_t>(8, (512 - riders) / F));
-  p->rows_per_split = int(std::max<int64_t>(cdiv(N, s), std::min<int64_t>(N, 8 * kRowWaves)));
-  p->S = int(cdiv(N, p->rows_per_split));
+  {
+    const int64_t budget = 512 - riders;
+    const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(8, N / std::min<int64_t>(N, 8 * kRowWaves)));   // >= 32 rows a piece
+    const int64_t s_lo = std::max<int64_t>(1, std::min<int64_t>(smax, budget / F));
+    const int64_t left = budget - F * s_lo;                    // slots still free with s_lo pieces per frame
+    if (s_lo < smax && left > 0) { p->S = int(s_lo + 1); p->S_nhi = int(std::min<int64_t>(F, left)); }
+    else { p->S = int(s_lo); p->S_nhi = int(F); }
+  }
   {
     // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
     // that the 10 exp per token of the fused epilogue are ONE round over the workgroup's 256 threads
@@ -2349,9 +2359,9 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
   if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>, smem, "k_norm_colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.F * p.S + (rider.perm ? (rider.parts & 0xFF) : 0))),
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(int64_t(p.S_nhi) * p.S + (p.F - p.S_nhi) * (p.S - 1) + (rider.perm ? (rider.parts & 0xFF) : 0))),
                      dim3(kRowWaves * 64), smem, st, x,
-                     int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.rows_per_split,
+                     int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_nhi,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
                      wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
   return VC2_OK;
@@ -2438,7 +2448,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   { ProfScope ps_(KID_CENTRES, st);
   const int FG = int(cdiv(p.F, kCentreFL));
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
-                                           dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, int(p.N), C,
+                                           dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, p.S_nhi, int(p.N), C,
                                            wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
                                            wsp<float>(ws, p.o_den),
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
