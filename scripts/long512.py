@@ -1,0 +1,14 @@
+"""Timing of the 512-frame clip (720 MB) for a library build: VC2_LIB_PATH=... python scripts/long512.py"""
+import time, torch
+import vidcom2_amd as vc
+F, N, D = 512, 196, 3584
+x = torch.randn(F * N, D, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+p = vc.vidcom2.CompressPlan(F, N, D, torch.bfloat16, x.device, 0.25)
+for _ in range(5):
+    p.enqueue(x)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    p.enqueue(x)
+torch.cuda.synchronize()
+print("512 frames: %.1f us / pass" % ((time.perf_counter() - t0) / 20 * 1e6))
