@@ -185,3 +185,23 @@ def test_two_processes_one_gpu_hip_stages_and_a_real_collective():
     assert sum((g[1] for g in got), []) == ref["global_idx"].tolist()
     for r, gi, _, sha in got:
         assert synth.sha256_tensor(x[torch.tensor(gi, dtype=torch.int64)]) == sha
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 end to end (ShardedCompressor + the four exchanges + timing + the JSON line), both ranks on
+    cuda:0 with gloo collectives (RCCL refuses two ranks on one device): the code the driver's scaling run executes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC2_BENCH_ONE_GPU="1", VC2_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--workload", "cfg2"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "frame-shard x2"
