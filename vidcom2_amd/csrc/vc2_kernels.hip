@@ -40,6 +40,13 @@
 #include "vc2_device.h"
 #include "vc2_select2.h"
 
+#ifndef VC2_PROBE_D3
+#define VC2_PROBE_D3 0
+#endif
+#ifndef VC2_PROBE_S2
+#define VC2_PROBE_S2 0
+#endif
+
 using namespace vc2;
 
 namespace {
@@ -622,18 +629,43 @@ __device__ __forceinline__ void row_wait() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// compact position p = i*64 + lane of this lane -> element index inside the row buffer (D = zero pad)
-template <int NPLB>
+// Compact positions a lane owns.  PAIR = 0: p = i*64 + lane (k_norm_fix).  PAIR = 1 (sweep 2): ADJACENT positions two by
+// two, p = 128*(i/2) + 2*lane + (i&1), so that a lane's pair (i, i+1) is one 4-byte (8-byte for fp32) element of the
+// materialised x^ row and a wave's store of it is 256 (512) contiguous bytes.
+template <int PAIR> __device__ __forceinline__ int compact_pos(int i, int lane) {
+  return PAIR ? 128 * (i >> 1) + 2 * lane + (i & 1) : i * 64 + lane;
+}
+// compact position of this lane -> element index inside the row buffer (D = zero pad)
+template <int NPLB, int PAIR = 0>
 __device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, int C, int D, int lane,
                                                  int (&coff)[NPLB]) {
   int t[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) {                      // unconditional (clamped) loads: all in flight together
-    const uint32_t p = uint32_t(i * 64 + lane);
+    const uint32_t p = uint32_t(compact_pos<PAIR>(i, lane));
     t[i] = cols ? cols[p < uint32_t(C) ? p : uint32_t(C - 1)] : int(p);
   }
 #pragma unroll
-  for (int i = 0; i < NPLB; ++i) coff[i] = i * 64 + lane < C ? t[i] : D;
+  for (int i = 0; i < NPLB; ++i) coff[i] = compact_pos<PAIR>(i, lane) < C ? t[i] : D;
+}
+
+// ---- the materialised x^ rows (round 3) -------------------------------------------------------------------------
+// Sweep 2 stores x^ = RN_T(x[:, cols] / den) once, channel-compacted (ascending cols order), as xh[R][Cp] in T with
+// Cp = C rounded up to 128 elements (zero padded: a whole wave stores every pair slot): sweep 3, the replays and the centre fix-ups stream these 16-byte
+// aligned rows instead of gathering from X and dividing again.
+__host__ __device__ inline int xh_stride(int C) { return (C + 127) & ~127; }
+template <int DT> __device__ __forceinline__ void xh_store_pair(void* __restrict__ xh, int64_t row, int Cp, int p,
+                                                               float a, float b) {   // a, b: T-representable
+  if constexpr (DT == VC2_F32) {
+    *reinterpret_cast<float2*>(static_cast<float*>(xh) + row * Cp + p) = make_float2(a, b);
+  } else if constexpr (DT == VC2_BF16) {
+    *reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(xh) + row * Cp + p) =
+        (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+  } else {
+    union { uint32_t u; _Float16 h[2]; } c;
+    c.h[0] = static_cast<_Float16>(a); c.h[1] = static_cast<_Float16>(b);
+    *reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(xh) + row * Cp + p) = c.u;
+  }
 }
 
 // ---- strict mode: torch's own fp32 accumulation order for the tokens where it matters -----------------
@@ -817,7 +849,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ nfix_count, int* __restrict__ nfix_list,
                                                                 int nfix_cap, uint8_t* __restrict__ rflag,
-                                                                OrderArgs rider) {
+                                                                void* __restrict__ xh, OrderArgs rider) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
@@ -853,73 +885,119 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     reinterpret_cast<uint32_t*>(buf1 + rowb - 16)[lane] = 0u;
   }
   int coff[NPLB];
-  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
+  load_col_offsets<NPLB, 1>(cols, C, int((rowb - 16) / ES), lane, coff);
+  const int Cp = xh_stride(C);
   double acc[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
   int n = n0 + wave;
   if (n < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+  constexpr bool kFastBf16 = ACC == 1 && DT == VC2_BF16;
+  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
   for (; n < n1; n += kRowWaves) {
     const int64_t row = int64_t(f) * N + n;
     row_wait();
     if (n + kRowWaves < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, row + kRowWaves, D, CV, buf1, lane);
+    // the norm rounded to T, the "torch order" queue, the denominator (F.normalize's clamp_min), den[row]
+    auto finish_norm = [&](float nrm32, int margin) -> float {
+      const float norm = rnT<DT>(nrm32);
+      // strict mode: where the norm sits within a few fp32 ulps of a T rounding boundary, torch's own
+      // fp32 accumulation order decides the result -> queue the row for k_norm_fix (a few per thousand)
+      if (strict && lane == 0 && (strict >= 2 || near_T_boundary<DT>(nrm32, margin)))
+        { const int j = atomicAdd(nfix_count, 1); if (j < nfix_cap) nfix_list[j] = int(row); }
+      // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
+      float dn = rnT<DT>(fmaxf(norm, 1e-12f));
+      if (norm != norm) dn = norm;
+      if (lane == 0) den_out[row] = dn;
+      return dn;
+    };
     float xv[NPLB];
-    float nrm32;
-    bool exact_div = true;                                      // this row's quotients go through the fp64 reciprocal
-    int margin = kFragileUlpsNorm;
-    float s0 = 0.f, s1 = 0.f;
-    if constexpr (ACC == 1) {
-      uint32_t span = 0u;
+    bool done = false;
+    if constexpr (kFastBf16) {
+      // ---- bf16, "torch order" mode: the lane's elements two by two as packed pairs (lo = even slot) ----------
+      // VALU issue is what this loop costs (scripts/ubench/valu_rates.hip), so: ONE v_dot2c_f32_bf16 squares and
+      // adds a pair, the range test runs on both halves at once (packed 16-bit ops), and the rounded quotients are
+      // stored as the v_cvt_pk_bf16_f32 result they come out of.
+      typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+      uint32_t P[NPLB / 2];
 #pragma unroll
-      for (int i = 0; i < NPLB; ++i) {
-        if constexpr (DT == VC2_BF16) {
-          const uint32_t raw = reinterpret_cast<const uint16_t*>(buf0)[coff[i]];
-          xv[i] = __uint_as_float(raw << 16);
-          // (padded positions i*64 + lane >= C read the zero pad element: they must not force the exact path)
-          const uint32_t sp = (raw & 0x7FFFu) - kBf16SpanLo;
-          if (i * 64 + 63 < C || i * 64 + lane < C) span = sp > span ? sp : span;
-        } else {
-          xv[i] = lds_elem<DT>(buf0, coff[i]);
+      for (int k = 0; k < NPLB / 2; ++k)
+        P[k] = uint32_t(reinterpret_cast<const uint16_t*>(buf0)[coff[2 * k]]) |
+               (uint32_t(reinterpret_cast<const uint16_t*>(buf0)[coff[2 * k + 1]]) << 16);
+      float ssq = 0.f;
+      union { uint32_t u; us2_t h; } span;
+      span.u = 0u;
+#pragma unroll
+      for (int k = 0; k < NPLB / 2; ++k) {
+        union { uint32_t u; b2_t b; us2_t h; } pk, lo, t;
+        pk.u = P[k];
+        ssq = __builtin_amdgcn_fdot2_f32_bf16(pk.b, pk.b, ssq, false);
+        // |x| outside [2^-63, 2^50] (zero included) -> the row divides exactly (see kBf16SpanLo)
+        pk.u &= 0x7FFF7FFFu;
+        lo.u = kBf16SpanLo * 0x10001u;
+        t.h = pk.h - lo.h;
+        if (128 * k + 127 >= C) {                                 // (padded positions read the zero pad element:
+          const int p0 = 128 * k + 2 * lane;                      //  they must not force the exact path)
+          t.u &= (p0 < C ? 0xFFFFu : 0u) | (p0 + 1 < C ? 0xFFFF0000u : 0u);
         }
-        if (i & 1) s1 = fmaf(xv[i], xv[i], s1); else s0 = fmaf(xv[i], xv[i], s0);
+        span.h = __builtin_elementwise_max(span.h, t.h);
       }
-      if constexpr (DT == VC2_BF16) exact_div = __any(span > kBf16SpanLen) != 0;
-    }
-    if (ACC == 0 || (DT == VC2_BF16 && exact_div)) {
-      double t = 0.0;
+      const bool exact_div = __any(span.h.x > kBf16SpanLen || span.h.y > kBf16SpanLen) != 0;
+      if (!exact_div) {
+        const float nrm32 = float(sqrt(double(wave_sum_bcast_f32(ssq))));   // correctly rounded fp32 square root
+        const float dn = finish_norm(nrm32, kFragileUlpsNorm + acc_norm_ulps(NPLB));
+        const float r = __builtin_amdgcn_rcpf(dn);
+        uint32_t* __restrict__ orow = static_cast<uint32_t*>(xh) + (row * Cp >> 1) + lane;
 #pragma unroll
-      for (int i = 0; i < NPLB; ++i) {
-        if constexpr (ACC == 0) xv[i] = lds_elem<DT>(buf0, coff[i]);
-        t = fma(double(xv[i]), double(xv[i]), t);
+        for (int k = 0; k < NPLB / 2; ++k) {
+          union { b2_t b; uint32_t u; } q;
+          q.b = __builtin_convertvector((f2_t){__uint_as_float(P[k] << 16) * r, __uint_as_float(P[k] & 0xFFFF0000u) * r}, b2_t);
+          acc[2 * k] += double(__uint_as_float(q.u << 16));
+          acc[2 * k + 1] += double(__uint_as_float(q.u & 0xFFFF0000u));
+#if VC2_PROBE_S2 != 1
+          if (128 * k < Cp) orow[64 * k] = q.u;                   // (padded positions: x = 0 -> +0)
+#endif
+        }
+        done = true;
+      } else {
+#pragma unroll
+        for (int k = 0; k < NPLB / 2; ++k) { xv[2 * k] = __uint_as_float(P[k] << 16); xv[2 * k + 1] = __uint_as_float(P[k] & 0xFFFF0000u); }
       }
-      nrm32 = float(sqrt(wave_sum_bcast(t)));
-    } else {
-      nrm32 = float(sqrt(double(wave_sum_bcast_f32(s0 + s1))));   // correctly rounded fp32 square root
-      margin = kFragileUlpsNorm + acc_norm_ulps(NPLB);
     }
-    const float norm = rnT<DT>(nrm32);
-    // strict mode: where the norm sits within a few fp32 ulps of a T rounding boundary, torch's own
-    // fp32 accumulation order decides the result -> queue the row for k_norm_fix (a few per thousand)
-    if (strict && lane == 0 && (strict >= 2 || near_T_boundary<DT>(nrm32, margin)))
-      { const int j = atomicAdd(nfix_count, 1); if (j < nfix_cap) nfix_list[j] = int(row); }
-    // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
-    float dn = rnT<DT>(fmaxf(norm, 1e-12f));
-    if (norm != norm) dn = norm;
-    if (lane == 0) { den_out[row] = dn; if (ACC == 1 && rflag) rflag[row] = exact_div ? 1 : 0; }
-    if (ACC == 1 && DT == VC2_BF16 && !exact_div) {
-      const float r = __builtin_amdgcn_rcpf(dn);
+    if (!done) {
+      float nrm32;
+      int margin = kFragileUlpsNorm;
+      if constexpr (ACC == 1 && DT != VC2_BF16) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPLB; ++i) {
+          xv[i] = lds_elem<DT>(buf0, coff[i]);
+          if (i & 1) s1 = fmaf(xv[i], xv[i], s1); else s0 = fmaf(xv[i], xv[i], s0);
+        }
+        nrm32 = float(sqrt(double(wave_sum_bcast_f32(s0 + s1))));
+        margin = kFragileUlpsNorm + acc_norm_ulps(NPLB);
+      } else {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPLB; ++i) {
+          if constexpr (!kFastBf16) xv[i] = lds_elem<DT>(buf0, coff[i]);
+          t = fma(double(xv[i]), double(xv[i]), t);
+        }
+        nrm32 = float(sqrt(wave_sum_bcast(t)));
+      }
+      const float dn = finish_norm(nrm32, margin);
+      const double inv = 1.0 / double(dn);
       static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
 #pragma unroll
       for (int i = 0; i < NPLB; i += 2) {
-        float a, b;
-        rnT2<DT>(xv[i] * r, xv[i + 1] * r, a, b);
+        const int p = compact_pos<1>(i, lane);
+        float a = rnT<DT>(div_via_f64(xv[i], inv)), b = rnT<DT>(div_via_f64(xv[i + 1], inv));
         acc[i] += double(a);
         acc[i + 1] += double(b);
+        if (p >= C) a = 0.f;                                     // padding stays zero whatever den is (NaN rows)
+        if (p + 1 >= C) b = 0.f;
+        if (128 * (i >> 1) < Cp) xh_store_pair<DT>(xh, row, Cp, p, a, b);
       }
-    } else {
-      const double inv = 1.0 / double(dn);
-#pragma unroll
-      for (int i = 0; i < NPLB; ++i) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
     }
     unsigned char* tbuf = buf0; buf0 = buf1; buf1 = tbuf;
   }
@@ -930,7 +1008,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   __syncthreads();
   double* sacc = reinterpret_cast<double*>(smem);                // [kRowWaves][NPLB * 64] doubles
 #pragma unroll
-  for (int i = 0; i < NPLB; ++i) sacc[(wave * NPLB + i) * 64 + lane] = acc[i];
+  for (int i = 0; i < NPLB; ++i) sacc[wave * NPLB * 64 + compact_pos<1>(i, lane)] = acc[i];
   __syncthreads();
   for (int p = tid; p < C; p += kRowWaves * 64) {
     double t = sacc[p];
@@ -952,11 +1030,12 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
                                                  float* __restrict__ den, const int* __restrict__ nfix_count,
                                                  const int* __restrict__ nfix_list, int max_entries,
                                                  int* __restrict__ corr_count, NormCorr* __restrict__ corr,
-                                                 int N) {
+                                                 int N, void* __restrict__ xh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
   const int lane = threadIdx.x;
+  const int Cp = xh_stride(C);
   unsigned char* buf0 = smem;
   const int count = min(*nfix_count, max_entries);
   if (int(blockIdx.x) >= count) return;
@@ -982,10 +1061,19 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
     const float norm = rnT<DT>(norm_torch_order<DT>(sv, C, lane));
     float dn = rnT<DT>(fmaxf(norm, 1e-12f));
     if (norm != norm) dn = norm;
-    if (lane == 0 && !(dn == dn_old) && !(dn != dn && dn_old != dn_old)) {
+    const bool changed = !(dn == dn_old) && !(dn != dn && dn_old != dn_old);
+    if (lane == 0 && changed) {
       den[row] = dn;
       const int j = atomicAdd(corr_count, 1);
       if (j < max_entries) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
+    }
+    if (changed && xh) {                                       // the row's materialised x^ follows the corrected norm
+      const double inv = 1.0 / double(dn);
+#pragma unroll
+      for (int i = 0; i < NPLB; ++i) {
+        const int p = i * 64 + lane;
+        if (p < C) stT<DT>(xh, row * Cp + p, div_via_f64(xv[i], inv));
+      }
     }
     wave_lds_fence();
     if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
@@ -1349,6 +1437,25 @@ __device__ __forceinline__ float gauss_term(float dist, int a) {
   const float arg = rnT<DT>((-dist) / two_a);
   return rnT<DT>(float(exp(double(arg))));
 }
+// The same term through v_exp_f32 (half precision only): e = 2^(arg * log2 e) carries < 30 fp32-ulps of error for
+// |arg| <= 16 (1 ulp of v_exp_f32; the product's rounding and the constant's error scale with |arg * log2 e| <= 23.1:
+// 23.1 * 1.5 * 2^-24 * ln 2 relative), so RN_T(e) is the correctly rounded result unless e lies within
+// kFragileUlpsExp of a T rounding boundary -- then (false) the caller takes the fp64 path.  dist <= 4 for unit
+// vectors, i.e. arg >= -16 and e >= 1.1e-7: a normal fp32 number (v_exp_f32 flushes subnormals).
+constexpr int kFragileUlpsExp = 64;
+template <int DT>
+__device__ __forceinline__ bool gauss_term_fast(float dist, int a, float& out) {
+  if constexpr (DT == VC2_F32) {
+    out = gauss_term<DT>(dist, a);
+    return true;
+  } else {
+    const float two_a = a == 0 ? 0.25f : a == 1 ? 0.5f : a == 2 ? 1.0f : a == 3 ? 2.0f : 4.0f;
+    const float arg = rnT<DT>((-dist) / two_a);
+    const float e = __builtin_amdgcn_exp2f(arg * 1.44269504088896341f);
+    out = rnT<DT>(e);
+    return fabsf(arg) <= 16.f && !near_T_boundary<DT>(e, kFragileUlpsExp);     // (NaN: not decided here)
+  }
+}
 template <int DT>
 __device__ __forceinline__ float gauss_sum(float dist) {
   float acc = 0.f;
@@ -1360,187 +1467,290 @@ __device__ __forceinline__ float gauss_sum(float dist) {
   return acc;
 }
 
+// ---- sweep 3 arithmetic ---------------------------------------------------------------------------------------
+// The sweep is bound by VALU ISSUE, not by memory (measured, scripts/ubench/valu_rates.hip: a wave64 shift, cvt_pk,
+// packed or DPP op costs ~4.3 cycles per SIMD, and / sub / mul ~2.7), so the per-element sequence is what is optimised:
+//   bf16  x^ unpacked once (and + shift); per centre: two subtractions, ONE v_cvt_pk_bf16_f32 rounding both
+//         differences, unpack, two exact products, ONE cvt_pk rounding both squares, and -- "torch order" mode -- ONE
+//         v_dot2c_f32_bf16 against (1, 1) adding both squares to the fp32 accumulator (keeps subnormals, rounds the
+//         three-term sum once: scripts/ubench/valu_rates.hip) -- 20 instructions per two channels and two centres;
+//   fp16  the hardware's packed fp16 arithmetic IS the reference's arithmetic here: RN_16(RN_32(a - b)) == RN_16(a - b)
+//         for fp16 a, b (the fp32 difference is inexact only when the smaller operand is below 2^-13 of the larger,
+//         where both roundings return the larger), and a product of two fp16 numbers is exact in fp32; v_pk_add_f16 /
+//         v_pk_mul_f16 keep subnormals (IEEE, measured) -- v_pk_add_f16, v_pk_mul_f16, v_dot2c_f32_f16: 3 instructions
+//         per two channels and centre, with the centres as packed fp16 pairs;
+//   fp32 / "exact" mode: the plain sequence, fp64 accumulators.
+template <int DT, int ACC> struct DistArith {                     // generic: centres as fp32, accumulators acc_t
+  static constexpr int VEC = Tr<DT>::VEC;
+  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
+  struct Cen { float v[VEC], f[VEC]; };
+  static __device__ __forceinline__ void set(Cen& c, int e, float a, float b) { c.v[e] = a; c.f[e] = b; }
+  static __device__ __forceinline__ void vec(const RawVec<DT, VEC>& raw, const Cen& c, acc_t& pv, acc_t& pf) {
+    float xv[VEC];
+    unpack<DT, VEC>(raw, xv);
+#pragma unroll
+    for (int e = 0; e < VEC; e += 2) {
+      const f2_t d0 = rnT2v<DT>((f2_t){xv[e] - c.v[e], xv[e] - c.f[e]});
+      const f2_t d1 = rnT2v<DT>((f2_t){xv[e + 1] - c.v[e + 1], xv[e + 1] - c.f[e + 1]});
+      const f2_t q0 = rnT2v<DT>(d0 * d0), q1 = rnT2v<DT>(d1 * d1);
+      pv += acc_t(q0.x); pf += acc_t(q0.y);
+      pv += acc_t(q1.x); pf += acc_t(q1.y);
+    }
+  }
+};
+template <> struct DistArith<VC2_BF16, 1> {
+  static constexpr int VEC = 8;
+  using acc_t = float;
+  struct Cen { float v[VEC], f[VEC]; };
+  static __device__ __forceinline__ void set(Cen& c, int e, float a, float b) { c.v[e] = a; c.f[e] = b; }
+  static __device__ __forceinline__ uint32_t pk(float a, float b) {                // (RN_bf16(a) | RN_bf16(b) << 16)
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    union { b2_t h; uint32_t u; } c;
+    c.h = __builtin_convertvector((f2_t){a, b}, b2_t);
+    return c.u;
+  }
+  static __device__ __forceinline__ float dot_ones(uint32_t q, float acc) {        // acc + q.lo + q.hi
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    union { b2_t h; uint32_t u; } a, one;
+    a.u = q; one.u = 0x3F803F80u;
+    return __builtin_amdgcn_fdot2_f32_bf16(a.h, one.h, acc, false);
+  }
+  static __device__ __forceinline__ void vec(const RawVec<VC2_BF16, 8>& raw, const Cen& c, float& pv, float& pf) {
+    const uint32_t w[4] = {raw.v.x, raw.v.y, raw.v.z, raw.v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float xa = __uint_as_float(w[q] << 16), xb = __uint_as_float(w[q] & 0xFFFF0000u);
+      const uint32_t dv = pk(xa - c.v[2 * q], xb - c.v[2 * q + 1]);
+      const uint32_t df = pk(xa - c.f[2 * q], xb - c.f[2 * q + 1]);
+      const float va = __uint_as_float(dv << 16), vb = __uint_as_float(dv & 0xFFFF0000u);
+      const float fa = __uint_as_float(df << 16), fb = __uint_as_float(df & 0xFFFF0000u);
+      pv = dot_ones(pk(va * va, vb * vb), pv);
+      pf = dot_ones(pk(fa * fa, fb * fb), pf);
+    }
+  }
+};
+template <> struct DistArith<VC2_F16, 1> {
+  static constexpr int VEC = 8;
+  using acc_t = float;
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  struct Cen { h2_t v[4], f[4]; };
+  static __device__ __forceinline__ void set(Cen& c, int e, float a, float b) {    // a, b: fp16-representable
+    c.v[e >> 1][e & 1] = static_cast<_Float16>(a);
+    c.f[e >> 1][e & 1] = static_cast<_Float16>(b);
+  }
+  static __device__ __forceinline__ void vec(const RawVec<VC2_F16, 8>& raw, const Cen& c, float& pv, float& pf) {
+    const uint32_t w[4] = {raw.v.x, raw.v.y, raw.v.z, raw.v.w};
+    const h2_t ones = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      union { uint32_t u; h2_t h; } x;
+      x.u = w[q];
+      const h2_t dv = x.h - c.v[q], df = x.h - c.f[q];
+      pv = __builtin_amdgcn_fdot2(dv * dv, ones, pv, false);
+      pf = __builtin_amdgcn_fdot2(df * df, ones, pf, false);
+    }
+  }
+};
+
+// K fp32 partial sums per lane (K = 4, 8 or 16) -> their K wave totals with a FIXED tree whose first two levels fold
+// two values per instruction pair: v_permlane32_swap / v_permlane16_swap exchange halves / odd-even rows of two
+// registers, one add folds both; four DPP steps then finish the four 16-lane rows of every register at once.
+// On return register m (m < K/4) holds, in ALL lanes of row r (lanes 16r .. 16r+15), the total of value
+// 4m + {0, 2, 1, 3}[r].  (~2.5 instructions per value instead of 8.)
+template <int K>
+__device__ __forceinline__ void wave_totals_f32(float (&v)[K]) {
+  static_assert(K == 4 || K == 8 || K == 16, "K");
+#pragma unroll
+  for (int i = 0; i < K / 2; ++i) {                              // lanes l and l + 32
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);        // lanes 0-31: value 2i, lanes 32-63: value 2i + 1
+  }
+#pragma unroll
+  for (int i = 0; i < K / 4; ++i) {                              // rows r and r + 1 (r even)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2 * i]), __float_as_uint(v[2 * i + 1]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < K / 4; ++i) {
+    float t = v[i];
+    t = dpp_addf<0xB1, 0xF>(t);     // quad_perm [1,0,3,2]
+    t = dpp_addf<0x4E, 0xF>(t);     // quad_perm [2,3,0,1]
+    t = dpp_addf<0x141, 0xF>(t);    // row_half_mirror
+    t = dpp_addf<0x140, 0xF>(t);    // row_mirror
+    v[i] = t;
+  }
+}
+
 // sweep 3 (vidcom2.py:61-62, :32-33): per token dist_v = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with
-// the frame centre, x^ recomputed from X and den; then -- still inside the workgroup -- the 5-scale Gaussian sums
-// v, f, total = RN_T(v + f) and the workgroup's partial sum of v (for the per-frame uniqueness score).
-// Column offsets and both centres of the lane's compact positions live in registers for the whole workgroup; the
-// row loop touches LDS only for the row itself.  Three phases per workgroup (one frame split, <= 64 rows):
-//   1. row loop, one wave per row (ACC: see k_norm_colsum).  In "torch order" mode a sum within the replay margin
-//      of a T rounding boundary is put on a workgroup-local list;
-//   2. the (rare) listed sums are replayed in torch's cascade order by the whole workgroup: every thread recomputes
-//      a few squares from X and scatters them to their SORTED positions (spos) in LDS, wave 0 adds them;
+// the frame centre; then -- still inside the workgroup -- the 5-scale Gaussian sums v, f, total = RN_T(v + f) and the
+// workgroup's partial sum of v (for the per-frame uniqueness score).
+// Round 3: x^ is READ (the rows sweep 2 materialised, xh[R][Cp] in T: half the bytes of X, no gather, no division).
+// A row is spread over the whole workgroup: lane l of wave w owns the 16-byte vectors (w*per + l) + j*4*per, j < NVL,
+// of every row (per = ceil(vectors per row / 4 / NVL) <= 64), i.e. the SAME <= 8 * NVL channels for all rows -- both
+// centres of those channels stay in fp32 registers, and U rows' loads are in flight per lane.  Phases per workgroup
+// (one frame split, <= kDistMaxRows rows):
+//   1. row loop: per row and wave one partial pair (video, frame) -- per-lane sequential sum, fixed DPP tree (ACC = 1:
+//      fp32, bounded error, see acc_dist3_ulps; ACC = 0: fp64) -- parked in LDS; then the four wave partials of every
+//      row are added in wave order.  In "torch order" mode a sum within the replay margin of a T rounding boundary is
+//      put on a workgroup-local list;
+//   2. the (rare) listed sums are replayed in torch's cascade order by the whole workgroup: every thread scatters a
+//      few squares to their SORTED positions (spos) in LDS, wave 0 adds them;
 //   3. 10 exp per token spread over the workgroup's threads, the two running sums, outputs.
 constexpr int kDistMaxRows = 64;
+__host__ __device__ constexpr int dist_rows_in_flight(int nvl) { return nvl == 1 ? 4 : 2; }   // per batch; two batches
+// roundings on the way from a square to the row sum: VEC*NVL - 1 sequential adds, six tree levels, three wave adds
+__host__ __device__ constexpr int acc_dist3_ulps(int per_lane) { return per_lane + 8 + 3; }
 
-template <int DT, int VEC, int NPLB, int ACC>
-__global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
-                                                         const int* __restrict__ cols,
-                                                         const int* __restrict__ spos, int strict, int S,
-                                                         int rows_per_split, const float* __restrict__ den,
-                                                         const uint8_t* __restrict__ rflag,
-                                                         const float* __restrict__ vc,
-                                                         const float* __restrict__ fc,
-                                                         void* __restrict__ v_T, void* __restrict__ f_T,
-                                                         float* __restrict__ total, double* __restrict__ vpart) {
+template <int DT, int NVL, int ACC>
+__global__ __launch_bounds__(kRowWaves * 64) void k_dist3(const void* __restrict__ xh, int N, int C, int per,
+                                                          const int* __restrict__ spos, int strict, int S,
+                                                          int rows_per_split, const float* __restrict__ vc,
+                                                          const float* __restrict__ fc,
+                                                          void* __restrict__ v_T, void* __restrict__ f_T,
+                                                          float* __restrict__ total, double* __restrict__ vpart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int ES = Tr<DT>::ES;
-  const size_t rowb = row_lds_bytes(D, ES);
+  constexpr int VEC = Tr<DT>::VEC;
+  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
   const int nrows = n1 - n0;
-  // One row buffer per wave and no intra-wave prefetch: measured faster than double buffering here
-  // (45 vs 50 us at 128x196x3584) because the smaller LDS footprint doubles the resident waves.
-  unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]; phase 2: float sq[C]
-  const size_t area = (std::max(size_t(kRowWaves) * rowb, size_t(C) * 4 + 16) + 15) / 16 * 16;
-  float* dens = reinterpret_cast<float*>(smem + area);             // [kDistMaxRows]
-  float* dists = dens + kDistMaxRows;                             // [kDistMaxRows][2]  RN_T distances (v, f)
+  const int Cp = xh_stride(C), nvp = Cp / VEC;                    // vectors per materialised row
+  constexpr int kDistU = dist_rows_in_flight(NVL);                // rows in flight per lane
+  // LDS: phase 1 partials [kDistMaxRows][4][2] acc_t; phase 2 float sq[C]; then the small arrays
+  const size_t area = (std::max(size_t(kDistMaxRows) * 8 * sizeof(acc_t), size_t(C) * 4 + 16) + 15) / 16 * 16;
+  acc_t* psum = reinterpret_cast<acc_t*>(smem);
+  float* dists = reinterpret_cast<float*>(smem + area);           // [kDistMaxRows][2]  RN_T distances (v, f)
   float* ebuf = dists + 2 * kDistMaxRows;                         // [kDistMaxRows][10] Gaussian terms
   int* list = reinterpret_cast<int*>(ebuf + 10 * kDistMaxRows);   // [2 * kDistMaxRows] (local row) * 2 + centre
-  int* lcount = list + 2 * kDistMaxRows;
-  uint8_t* rfl = reinterpret_cast<uint8_t*>(lcount + 4);          // [kDistMaxRows]
-  int n = n0 + wave;
-  if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-  if (tid == 0) *lcount = 0;
-  for (int r = tid; r < nrows; r += kRowWaves * 64) {
-    dens[r] = den[int64_t(f) * N + n0 + r];
-    rfl[r] = (ACC == 1 && DT == VC2_BF16 && rflag) ? rflag[int64_t(f) * N + n0 + r] : 1;
-  }
-  int coff[NPLB];
-  // (video centre, frame centre) of the lane's compact positions: fp32 pairs, or -- half precision -- the two T
-  // values packed in one register (video | frame << 16; two unpack instructions per element buy 28 registers,
-  // i.e. a fourth wave per SIMD)
-#ifndef VC2_DIST_PACKED_CC
-#define VC2_DIST_PACKED_CC 0
-#endif
-  using CP = CentrePair<VC2_DIST_PACKED_CC ? DT : VC2_F32>;
-  typename CP::type cc[NPLB];
-  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
-  {
-    // unconditional loads (clamped index), batched; a load inside a conditional is waited for on the spot, and
-    // 2 * NPLB serialised L2 round trips cost the whole workgroup ~10 us.  (Batches of 8: the temporaries must
-    // not become the kernel's register peak.)
-    constexpr int B = NPLB % 8 == 0 ? 8 : NPLB % 7 == 0 ? 7 : 2;
-    const float* __restrict__ fcf = fc + int64_t(f) * C;
+  int* lcount = list + 2 * kDistMaxRows;                          // [0] phase-2 list, [1] phase-3 list
+  uint16_t* elist = reinterpret_cast<uint16_t*>(lcount + 4);      // [10 * kDistMaxRows] exp terms for the fp64 path
+  if (tid < 2) lcount[tid] = 0;
+  // my vectors and the centres of their channels (padding and idle lanes: zeros -> they add +0)
+  using AR = DistArith<DT, ACC>;
+  int vi[NVL];
+  bool act[NVL];
+  typename AR::Cen cen[NVL];
+  const float* __restrict__ fcf = fc + int64_t(f) * C;
 #pragma unroll
-    for (int i0 = 0; i0 < NPLB; i0 += B) {
-      float a[B], b[B];
+  for (int j = 0; j < NVL; ++j) {
+    vi[j] = wave * per + lane + j * 4 * per;
+    act[j] = lane < per && vi[j] < nvp;
+    vi[j] = act[j] ? vi[j] : nvp - 1;                             // idle: any valid vector (its partial is dropped)
+    float a[VEC], b[VEC];
 #pragma unroll
-      for (int j = 0; j < B; ++j) {
-        const uint32_t p = uint32_t((i0 + j) * 64 + lane), pc = p < uint32_t(C) ? p : uint32_t(C - 1);
-        a[j] = vc[pc];                                             // (32-bit offsets: scalar base + VGPR offset loads)
-        b[j] = fcf[pc];
-      }
-      asm volatile("" ::: "memory");                               // keep the batches apart
+    for (int e = 0; e < VEC; ++e) {                               // unconditional (clamped) loads, all in flight
+      const int pch = vi[j] * VEC + e, pc = pch < C ? pch : C - 1;
+      a[e] = vc[pc];
+      b[e] = fcf[pc];
+    }
 #pragma unroll
-      for (int j = 0; j < B; ++j) {
-        const bool in = (i0 + j) * 64 + lane < C;
-        cc[i0 + j] = CP::pack(in ? a[j] : 0.f, in ? b[j] : 0.f);
-      }
+    for (int e = 0; e < VEC; ++e) {
+      const bool in = act[j] && vi[j] * VEC + e < C;
+      AR::set(cen[j], e, in ? a[e] : 0.f, in ? b[e] : 0.f);
     }
   }
-  // (plain loads first: behind an in-flight global_load_lds the compiler waits for EVERY load separately)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (n < n1) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
-  __syncthreads();
-  // ---- phase 1 ---------------------------------------------------------------------------------------
-  // The row's results stay in the registers of lane `it` until the loop is over: the compiler orders every LDS
-  // access behind an in-flight global_load_lds with vmcnt(0).
-#ifndef VC2_DIST_PREFETCH
-#define VC2_DIST_PREFETCH 0
-#endif
-  float res_v = 0.f, res_f = 0.f;
-  uint32_t res_flag = 0u;
-  int it = 0;
-  for (; n < n1; n += kRowWaves, ++it) {
-#if VC2_DIST_PREFETCH
-    // wait for the row, pull the lane's elements into registers, re-issue the NEXT row into the same buffer, compute
-    row_wait();
-    const float dn = dens[n - n0];
-    const bool exact_div = DT != VC2_BF16 || ACC == 0 || rfl[n - n0] != 0;
-    typename RawPair<DT>::type raw[NPLB / 2];
+  const unsigned char* __restrict__ base = static_cast<const unsigned char*>(xh) + (int64_t(f) * N + n0) * Cp * Tr<DT>::ES;
+  // ---- phase 1 -------------------------------------------------------------------------------------------
+  // Batches of kDistU rows, software-pipelined: the loads of batch k + 1 are in flight while batch k is computed (all
+  // workgroups start together and do the same work, so without the prefetch the whole chip alternates between a
+  // memory burst and a compute burst: measured 32 us against 15 us for the arithmetic alone).
+  auto load = [&](RawVec<DT, VEC> (&raw)[kDistU][NVL], int r0) {
 #pragma unroll
-    for (int i = 0; i < NPLB; i += 2) raw[i / 2] = RawPair<DT>::make(lds_raw<DT>(buf0, coff[i]), lds_raw<DT>(buf0, coff[i + 1]));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads are done: the buffer may be refilled
-    if (n + kRowWaves < n1) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n + kRowWaves, D, CV, buf0, lane);
-#define VC2_DIST_ELEMS(i) RawPair<DT>::lo(raw[(i) / 2]), RawPair<DT>::hi(raw[(i) / 2])
+    for (int u = 0; u < kDistU; ++u) {
+      const int r = min(r0 + u, nrows - 1);                       // (clamped: the surplus rows are not stored)
+#pragma unroll
+      for (int j = 0; j < NVL; ++j) {
+#if VC2_PROBE_D3 == 4
+        raw[u][j] = zero_raw<DT, VEC>();
+        if constexpr (DT != VC2_F32) raw[u][j].v = make_uint4(0x3c003c00u + r + lane, 0x3c003c00u + (r ^ lane), 0x3c003c00u + r * 3 + lane, 0x3c003c00u + lane - r);
 #else
-    // issue the row's DMA, wait, compute straight from LDS
-    if (it) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
-    row_wait();
-    const float dn = dens[n - n0];
-    const bool exact_div = DT != VC2_BF16 || ACC == 0 || rfl[n - n0] != 0;
-#define VC2_DIST_ELEMS(i) lds_elem<DT>(buf0, coff[i]), lds_elem<DT>(buf0, coff[(i) + 1])
+        raw[u][j] = load_raw<DT, VEC>(base, (int64_t(r) * nvp + vi[j]) * VEC);
 #endif
-    float dvv, dff;
-    int margin = kFragileUlpsDist;
-    static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
-    // two compact positions per step: one packed conversion rounds both x^, the two subtract / square pairs
-    // are packed fp32 ops on (video, frame) register pairs
-    if constexpr (ACC == 0) {
-      const double inv = 1.0 / double(dn);
-      double pv = 0.0, pf = 0.0;                                  // accumulation order: i, then i + 1
-#pragma unroll
-      for (int i = 0; i < NPLB; i += 2) {
-        const float vv[2] = {VC2_DIST_ELEMS(i)};
-        const float v0 = vv[0], v1 = vv[1];
-        float xh0, xh1;
-        rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
-        const f2_t d0 = (f2_t){xh0, xh0} - CP::unpack(cc[i]);
-        const f2_t d1 = (f2_t){xh1, xh1} - CP::unpack(cc[i + 1]);
-        const f2_t r0 = rnT2v<DT>(d0), r1 = rnT2v<DT>(d1);
-        const f2_t q0 = rnT2v<DT>(pk_square(r0)), q1 = rnT2v<DT>(pk_square(r1));
-        pv += double(q0.x);
-        pf += double(q0.y);
-        pv += double(q1.x);
-        pf += double(q1.y);
       }
-      dvv = float(wave_sum_bcast(pv));
-      dff = float(wave_sum_bcast(pf));
-    } else {
-      f2_t acc = (f2_t){0.f, 0.f};
-      auto body = [&](auto exact_tag) {
-        constexpr bool kExact = decltype(exact_tag)::value;
-        const double inv = kExact ? 1.0 / double(dn) : 0.0;
-        const float r = kExact ? 0.f : __builtin_amdgcn_rcpf(dn);
-#pragma unroll
-        for (int i = 0; i < NPLB; i += 2) {
-          const float vv[2] = {VC2_DIST_ELEMS(i)};
-          const float v0 = vv[0], v1 = vv[1];
-          float xh0, xh1;
-          if constexpr (kExact) rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
-          else rnT2<DT>(v0 * r, v1 * r, xh0, xh1);
-          const f2_t d0 = (f2_t){xh0, xh0} - CP::unpack(cc[i]);
-          const f2_t d1 = (f2_t){xh1, xh1} - CP::unpack(cc[i + 1]);
-          const f2_t r0 = rnT2v<DT>(d0), r1 = rnT2v<DT>(d1);
-          const f2_t q0 = rnT2v<DT>(pk_square(r0)), q1 = rnT2v<DT>(pk_square(r1));
-          acc = acc + q0;
-          acc = acc + q1;
-        }
-      };
-      if (exact_div) body(std::true_type{}); else body(std::false_type{});
-      dvv = wave_sum_bcast_f32(acc.x);
-      dff = wave_sum_bcast_f32(acc.y);
-      margin = kFragileUlpsDist + acc_dist_ulps(NPLB);
     }
+  };
+  auto compute = [&](const RawVec<DT, VEC> (&raw)[kDistU][NVL], int r0) {
+    constexpr int U = kDistU;
+    acc_t part[2 * U];                                            // (video, frame) of row r0 + u at [2u], [2u + 1]
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc_t pv = 0, pf = 0;
+#pragma unroll
+      for (int j = 0; j < NVL; ++j) {
+        acc_t tv = 0, tf = 0;
+#if VC2_PROBE_D3 == 3
+        if constexpr (DT != VC2_F32) { tv = acc_t(raw[u][j].v.x ^ raw[u][j].v.y); tf = acc_t(raw[u][j].v.z ^ raw[u][j].v.w); }
+#else
+        AR::vec(raw[u][j], cen[j], tv, tf);
+#endif
+        pv += act[j] ? tv : acc_t(0);                             // (an idle lane's vector is somebody else's)
+        pf += act[j] ? tf : acc_t(0);
+      }
+      part[2 * u] = pv;
+      part[2 * u + 1] = pf;
+    }
+    if constexpr (ACC == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double sv = wave_sum_bcast(part[2 * u]), sf = wave_sum_bcast(part[2 * u + 1]);
+        if (lane == 0 && r0 + u < nrows) { psum[((r0 + u) * 4 + wave) * 2] = sv; psum[((r0 + u) * 4 + wave) * 2 + 1] = sf; }
+      }
+    } else {
+      wave_totals_f32<2 * U>(part);
+      // register m, row rr of the wave: value 4m + {0, 2, 1, 3}[rr] = row r0 + (idx >> 1), centre idx & 1
+      const int rr = lane >> 4;
+      const int sub = ((rr & 1) << 1) | (rr >> 1);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int m = 0; m < 2 * U / 4; ++m) {
+          const int idx = 4 * m + sub, r = r0 + (idx >> 1);
+          if (r < nrows) psum[(r * 4 + wave) * 2 + (idx & 1)] = part[m];
+        }
+      }
+    }
+  };
+  {
+    RawVec<DT, VEC> rawA[kDistU][NVL], rawB[kDistU][NVL];
+    const int nb = (nrows + kDistU - 1) / kDistU;
+    load(rawA, 0);
+    int b = 0;
+    for (; b + 2 < nb; b += 2) {                                  // (no branch in here: a join would cost a vmcnt(0))
+      load(rawB, (b + 1) * kDistU);
+      compute(rawA, b * kDistU);
+      load(rawA, (b + 2) * kDistU);
+      compute(rawB, (b + 1) * kDistU);
+    }
+    if (b + 1 < nb) {
+      load(rawB, (b + 1) * kDistU);
+      compute(rawA, b * kDistU);
+      compute(rawB, (b + 1) * kDistU);
+    } else {
+      compute(rawA, b * kDistU);
+    }
+  }
+  __syncthreads();
+  if (tid < nrows) {
+    const acc_t* q = psum + tid * 8;
+    const acc_t sv = ((q[0] + q[2]) + q[4]) + q[6], sf = ((q[1] + q[3]) + q[5]) + q[7];   // wave order
+    const float dvv = float(sv), dff = float(sf);
+    const int margin = ACC == 0 ? kFragileUlpsDist : kFragileUlpsDist + acc_dist3_ulps(VEC * NVL);
     // rare: a sum within a few fp32 ulps of a T rounding boundary, where torch's own fp32 accumulation order
     // decides the result -> phase 2
     const uint32_t fl = !strict ? 0u
                                 : ((strict >= 2 || near_T_boundary<DT>(dvv, margin)) ? 1u : 0u) |
                                       ((strict >= 2 || near_T_boundary<DT>(dff, margin)) ? 2u : 0u);
-    if (lane == it) { res_v = rnT<DT>(dvv); res_f = rnT<DT>(dff); res_flag = fl; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // LDS reads done before the buffer is refilled
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane < it) {
-    const int nl = wave + lane * kRowWaves;
-    dists[2 * nl] = res_v;
-    dists[2 * nl + 1] = res_f;
-    if (res_flag & 1u) list[atomicAdd(lcount, 1)] = nl * 2;
-    if (res_flag & 2u) list[atomicAdd(lcount, 1)] = nl * 2 + 1;
+    dists[2 * tid] = rnT<DT>(dvv);
+    dists[2 * tid + 1] = rnT<DT>(dff);
+    if (fl & 1u) list[atomicAdd(lcount, 1)] = tid * 2;
+    if (fl & 2u) list[atomicAdd(lcount, 1)] = tid * 2 + 1;
   }
   __syncthreads();
+#if VC2_PROBE_D3 == 1
+  if (tid == 0) vpart[blockIdx.x] = dists[0];
+  return;
+#endif
   // ---- phase 2: replay torch's cascade sum for the listed (row, centre) pairs ---------------------------
   if (strict) {
     const int cnt = *lcount;
@@ -1548,13 +1758,10 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     for (int e = 0; e < cnt; ++e) {
       const int ent = list[e];
       const int nl = ent >> 1, which = ent & 1;
-      const int64_t row = int64_t(f) * N + n0 + nl;
-      const double inv = 1.0 / double(dens[nl]);
-      const float* cen = which ? fc + int64_t(f) * C : vc;
+      const float* cen = which ? fcf : vc;
       for (int p = tid; p < C; p += kRowWaves * 64) {
-        const int col = cols ? cols[p] : p, spp = spos ? spos[p] : p;
-        const float xh = rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), inv));
-        const float a = rnT<DT>(xh - cen[p]);
+        const int spp = spos ? spos[p] : p;
+        const float a = rnT<DT>(ldT<DT>(base, int64_t(nl) * Cp + p) - cen[p]);
         sq[spp] = rnT<DT>(a * a);
       }
       __syncthreads();
@@ -1568,6 +1775,13 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   // ---- phase 3: Gaussian sums, total, partial frame sum ---------------------------------------------
   for (int it = tid; it < nrows * 10; it += kRowWaves * 64) {
     const int nl = it / 10, j = it - nl * 10;
+    float e;
+    if (!gauss_term_fast<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j, e)) elist[atomicAdd(lcount + 1, 1)] = uint16_t(it);
+    ebuf[it] = e;
+  }
+  __syncthreads();
+  for (int k = tid; k < lcount[1]; k += kRowWaves * 64) {         // the few terms next to a rounding boundary: fp64 exp
+    const int it = elist[k], nl = it / 10, j = it - nl * 10;
     ebuf[it] = gauss_term<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j);
   }
   __syncthreads();
@@ -2100,7 +2314,7 @@ struct Plan {
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_tmp_f32, o_xh, total_bytes;
   int vstride;
 };
 
@@ -2155,9 +2369,19 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
 #ifndef VC2_DIST_RPS_MIN
 #define VC2_DIST_RPS_MIN 16
 #endif
-    int64_t rps = std::max<int64_t>(VC2_DIST_RPS_MIN, std::min<int64_t>(25, cdiv(p->R, VC2_DIST_WGS)));
-    rps = std::min<int64_t>(rps, N);
-    p->S2 = int(cdiv(N, rps));
+    // rows per workgroup: 16 .. 32, at least ~768 workgroups when the video allows, and among those the split whose
+    // batches (4 rows) compute the fewest surplus rows; ties: fewer, longer splits
+    auto padded = [](int64_t n) { return (n + 3) / 4 * 4; };
+    const int64_t lo = std::min<int64_t>(N, VC2_DIST_RPS_MIN), hi = std::min<int64_t>(N, 32);
+    int64_t best = -1, best_cost = 0;
+    for (int64_t rps = hi; rps >= lo; --rps) {
+      const int64_t S2 = cdiv(N, rps), r2 = cdiv(N, S2), last = N - (S2 - 1) * r2;
+      if (F * S2 < std::min<int64_t>(VC2_DIST_WGS * 3 / 4, F * cdiv(N, lo)) && rps > lo) continue;   // too few workgroups
+      const int64_t cost = (S2 - 1) * padded(r2) + padded(last);
+      if (best < 0 || cost < best_cost) { best = rps; best_cost = cost; }
+    }
+    if (best < 0) best = lo;
+    p->S2 = int(cdiv(N, best));
     p->rows_per_split2 = int(cdiv(N, p->S2));
   }
   size_t o = 0;
@@ -2194,6 +2418,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
   p->o_vticket = take(size_t(D) * 4);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
+  p->o_xh = take(size_t(p->R) * size_t(xh_stride(int(D))) * p->ES);   // materialised x^ rows (any C <= D)
   p->total_bytes = o;
   return VC2_OK;
 }
@@ -2363,7 +2588,7 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_nhi,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
-                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
+                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), wsp<void>(ws, p.o_xh), rider);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -2383,31 +2608,42 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
                      cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + 2,
                      wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + 3,
-                     wsp<NormCorr>(ws, p.o_corr), int(p.N));
+                     wsp<NormCorr>(ws, p.o_corr), int(p.N), wsp<void>(ws, p.o_xh));
   return VC2_OK;
 }
 struct DistOut { void* v_T; void* f_T; float* total; };
 
-template <int DT, int VEC, int NPLB, int ACC>
-int launch_dist_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
-  const int* cols = cs.cols; const int C = cs.C;
-  const size_t area = (std::max(size_t(kRowWaves) * row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16) + 15) / 16 * 16;
-  const size_t smem = area + size_t(kDistMaxRows) * (4 + 8 + 40 + 8 + 1) + 64;
-  int rc = allow_big_lds(&k_dist<DT, VEC, NPLB, ACC>, smem, "k_dist");
+template <int DT, int NVL, int ACC>
+int launch_dist_nvl(const Plan& p, const ChanSet& cs, void* ws, const DistOut& o, int per, hipStream_t st) {
+  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
+  const int C = cs.C;
+  const size_t area = (std::max(size_t(kDistMaxRows) * 8 * sizeof(acc_t), size_t(C) * 4 + 16) + 15) / 16 * 16;
+  const size_t smem = area + size_t(kDistMaxRows) * (8 + 40 + 8 + 20) + 64;
+  int rc = allow_big_lds(&k_dist3<DT, NVL, ACC>, smem, "k_dist3");
   if (rc) return rc;
   ProfScope ps_(KID_DIST, st);
-  hipLaunchKernelGGL((k_dist<DT, VEC, NPLB, ACC>), dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st, x,
-                     int(p.N), int(p.D), p.CV, C, cols, cs.spos, cs.strict, p.S2, p.rows_per_split2,
-                     wsp<float>(ws, p.o_den), wsp<uint8_t>(ws, p.o_rflag), wsp<float>(ws, p.o_vc),
-                     wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total, wsp<double>(ws, p.o_vpart));
+  hipLaunchKernelGGL((k_dist3<DT, NVL, ACC>), dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st,
+                     wsp<const void>(ws, p.o_xh), int(p.N), C, per, cs.spos, cs.strict, p.S2, p.rows_per_split2,
+                     wsp<float>(ws, p.o_vc), wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total,
+                     wsp<double>(ws, p.o_vpart));
   return VC2_OK;
 }
-template <int DT, int VEC, int NPLB>
-int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
+template <int DT, int ACC>
+int launch_dist_acc(const Plan& p, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
+  const int nvp = xh_stride(cs.C) / Tr<DT>::VEC;                 // 16-byte vectors per materialised row
+  const int nvl = nvp <= 256 ? 1 : nvp <= 512 ? 2 : 4;
+  const int per = int(cdiv(nvp, 4 * nvl));
+  if (per > 64) return fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels");
+  if (nvl == 1) return launch_dist_nvl<DT, 1, ACC>(p, cs, ws, o, per, st);
+  if (nvl == 2) return launch_dist_nvl<DT, 2, ACC>(p, cs, ws, o, per, st);
+  return launch_dist_nvl<DT, 4, ACC>(p, cs, ws, o, per, st);
+}
+template <int DT>
+int launch_dist_t(const Plan& p, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
   if constexpr (DT != VC2_F32) {
-    if (fast_acc(p, cs)) return launch_dist_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, o, st);
+    if (fast_acc(p, cs)) return launch_dist_acc<DT, 1>(p, cs, ws, o, st);
   }
-  return launch_dist_acc<DT, VEC, NPLB, 0>(p, x, cs, ws, o, st);
+  return launch_dist_acc<DT, 0>(p, cs, ws, o, st);
 }
 // compact positions per lane -> compile-time bucket (28 = 3584-d, 32 = 4096-d models)
 #define VC2_DISPATCH_NPL(npl, FN, ...)                                   \
@@ -2478,9 +2714,8 @@ int launch_phase2(const Plan& p, const void* x, const ChanSet& cs, void* ws, voi
   const int C = cs.C;
   if (p.rows_per_split2 > kDistMaxRows) return fail(VC2_ERR_UNSUPPORTED, "internal: sweep-3 split too long");
   { int rc = VC2_OK;
-  const int npl = int(cdiv(C, 64));
   const DistOut o{v_T, f_T, total};
-  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cs, ws, o, st));
+  VC2_DISPATCH_DT(p.dt, rc = launch_dist_t<DT>(p, cs, ws, o, st));
   if (rc) return rc; }
   if (s) {
     ProfScope ps_(KID_EPILOGUE, st);
