@@ -2418,8 +2418,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
   p->o_vticket = take(size_t(D) * 4);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
-  p->o_xh = take(size_t(p->R) * size_t(xh_stride(int(D))) * p->ES);   // materialised x^ rows (any C <= D)
-  p->total_bytes = o;
+  p->o_xh = o;                                                // materialised x^ rows: LAST, sized by the call's C
+  p->total_bytes = o + align_up(size_t(p->R) * size_t(xh_stride(int(D))) * p->ES);   // (any C <= D)
   return VC2_OK;
 }
 
@@ -2467,10 +2467,16 @@ struct ProfScope {
   VC2_DISPATCH_DT((p).dt, if ((p).VEC == 1) { constexpr int VEC = 1; __VA_ARGS__; } \
                   else { constexpr int VEC = Tr<DT>::VEC; __VA_ARGS__; })
 
-int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
+// bytes a call needs that scores C channels (the materialised x^ rows close the workspace: C = 0 -> none of them)
+size_t ws_bytes_for(const Plan& p, int64_t C) {
+  return p.o_xh + align_up(size_t(p.R) * size_t(xh_stride(int(std::min<int64_t>(std::max<int64_t>(C, 0), p.D)))) * p.ES);
+}
+int need_ws(const Plan& p, void* ws, size_t ws_bytes, int64_t C) {
   if (!ws) return fail(VC2_ERR_ARG, "workspace pointer is null");
-  if (ws_bytes < p.total_bytes)
-    return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total_bytes);
+  const size_t need = ws_bytes_for(p, C);
+  if (ws_bytes < need)
+    return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes (vc2_workspace_bytes_c with C = %lld)", ws_bytes,
+                need, (long long)C);
   return VC2_OK;
 }
 
@@ -2790,11 +2796,16 @@ int vc2_set_mode(int mode) {
 int vc2_get_mode(void) { return g_strict; }
 
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
+  return vc2_workspace_bytes_c(F, N, D, dtype, D, out_bytes);
+}
+
+int vc2_workspace_bytes_c(int64_t F, int64_t N, int64_t D, int dtype, int64_t C_max, size_t* out_bytes) {
   if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
+  if (C_max < 0 || C_max > D) return fail(VC2_ERR_ARG, "C_max=%lld outside [0, D]", (long long)C_max);
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
-  *out_bytes = p.total_bytes;
+  *out_bytes = ws_bytes_for(p, C_max);
   return VC2_OK;
 }
 
@@ -2817,7 +2828,7 @@ int vc2_chan_stats(const void* x, int64_t F, int64_t N, int64_t D, int dtype, in
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, F_total, block_frames);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
   return launch_chan_stats(p, x, ws, bstats, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -2839,7 +2850,7 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
   Plan p;
   int rc = make_plan(1, R, D, dtype, &p);   // the variance does not depend on the frame structure
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
   float* vf = var_f32 ? var_f32 : wsp<float>(ws, p.o_var_f32);
   return launch_chan_stats(p, x, ws, nullptr, var_T, vf, static_cast<hipStream_t>(stream));
 }
@@ -2889,7 +2900,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, F_total);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((rc = zero_counters(p, ws, st))) return rc;
   const ChanSet cs = make_chanset(p, cols, spos, C);
@@ -2920,7 +2931,7 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, R_total / N);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
   if (!vc_blocks_ok(p, R_total, cs0.strict)) return VC2_OK;      // nothing to exchange: phase 2 keeps the exact means
@@ -2953,7 +2964,7 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, R_total / N);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
   const bool have_blocks = blocks_all && world > 0 && cap > 0 && vc_blocks_ok(p, R_total, cs0.strict) &&
@@ -2984,7 +2995,7 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
@@ -3057,7 +3068,7 @@ int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, 
                 (long long)D, dtype == VC2_F32 ? 8 : 16);
   Plan p;
   if ((rc = make_plan(F, h * w, D, dtype, &p))) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
   const PoolSrc pool{xin, int(H), int(W), int(h), int(w), mode};
   return launch_stats_sweep(p, x_out, ws, pool, static_cast<hipStream_t>(stream));
 }
@@ -3120,7 +3131,7 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, int64_t(double(D) * 0.5)))) return rc;
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
@@ -3178,7 +3189,7 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
   Plan p;
   int rc = make_plan(F_local, N, D, dtype, &p, F_total);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* scales = wsp<float>(ws, p.o_scales_f32);
   // budgets over ALL frames of the video (softmax + mean are global, vidcom2.py:66-67), selection only for this
