@@ -53,7 +53,8 @@ const char* vc2_version(void);
  *                variance-sorted channels / cascade sum / outer-sum cascade over the rows) is replayed for that
  *                token or centre element -> bit-exact to the CPU reference;
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
- * fp32 inputs are unaffected.  Process-wide. */
+ * fp32 inputs are unaffected.  The setting is per calling thread (default 1): concurrent callers cannot change each
+ * other's mode; a worker thread that wants another mode sets it itself. */
 int vc2_set_mode(int mode);
 int vc2_get_mode(void);
 /* Workspace (bytes) needed by any entry point below for an [F*N, D] input (scoring up to D channels). */
@@ -112,7 +113,9 @@ int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int
  * (tpf = the reference's multiplier, normally N; a k_f > N is reported raw in ks while min(k_f, N) tokens are
  * selected -- the caller raises torch.topk's "k out of range" error),
  * offs int64[F+1] (exclusive prefix of min(ks, N)), idx_out int64[cap] and K_out[0] = number of indices
- * written (K_out[1] = 1 if it would have exceeded `cap`; then nothing past cap is written). */
+ * written.  K_out[1] = status bits, all zero on a sound pass: 1 = the count would have exceeded `cap` (nothing past
+ * cap is written), 2 = a bounded wait between workgroups of one launch of this pass expired, 4 = a loop bound of the
+ * selection replay expired (vc2_selftest_counters has the details); the Python mirror raises on any of them. */
 int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int64_t tpf, int dtype,
                int map_mode, int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs,
                int64_t* idx_out, int64_t cap, int64_t* K_out, void* stream);

@@ -49,6 +49,21 @@
 
 using namespace vc2;
 
+#ifdef VC2_DEBUG_TIMING
+namespace vc2 {
+__device__ unsigned long long g_dbg_t[512];
+__device__ int g_dbg_v[512];
+__device__ int g_dbg_n;
+__device__ __forceinline__ void dbg_stamp(int tag) {      // (one lane) wall clock, 100 MHz
+  const int i = atomicAdd(&g_dbg_n, 1);
+  if (i < 512) { g_dbg_t[i] = wall_clock64(); g_dbg_v[i] = tag; }
+}
+}
+#define VC2_STAMP(tag) dbg_stamp(tag)
+#else
+#define VC2_STAMP(tag) ((void)0)
+#endif
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -296,11 +311,14 @@ template <int DT>
 __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
                                                                 int64_t n_each, int64_t n_last, int D,
                                                                 void* __restrict__ var_T, float* __restrict__ var_f32,
-                                                                int* __restrict__ counters, PartSrc ps) {
+                                                                int* __restrict__ counters, PartSrc ps,
+                                                                unsigned long long* __restrict__ fixq = nullptr,
+                                                                int nfixq = 0) {
   // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
   // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
   __shared__ double sm[3][kRedGL][64];
-  if (counters && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;   // strict-mode queues of this pass
+  if (counters && blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;  // strict-mode queues of this pass
+  if (fixq) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfixq; i += gridDim.x * blockDim.x) fixq[i] = 0ull;
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   ChanAgg a{0.0, 0.0, 0.0};
@@ -837,6 +855,73 @@ __host__ __device__ constexpr int acc_dist_ulps(int nplb) { return nplb + 8; }
 constexpr uint32_t kBf16SpanLo = 0x2000u;     // bf16 bits of 2^-63
 constexpr uint32_t kBf16SpanLen = 0x3880u;    // ... up to 2^50 (0x5880)
 
+// Strict-mode fix-up of sweep 2: for every queued row replay torch's norm accumulation (the row's selected
+// values scattered to their SORTED positions, then the 8-chain / sequential fp32 sum).  Almost always the
+// T-rounded norm equals the exactly-rounded one already in den[]; when it does not, den[] is corrected and
+// the row is recorded so that k_centres can correct the column sums of its frame.  One wave per entry.
+struct NormCorr { int row; float den_old; float den_new; int frame; };   // capacity: one per row (cannot overflow)
+
+// The queue of rows whose norm sits next to a T rounding boundary: 8-byte granules (row + 1) | den bits << 32 (den =
+// the denominator the sweep computed from the exactly rounded norm), each written by ONE store; the list is zeroed at
+// the start of every pass.  (Round 3 tried to let the ORDER riders consume this queue inside the sweep's own launch:
+// correct, but never faster than the separate kernel -- NOTES_r03.md.)
+__device__ __forceinline__ unsigned long long fixq_pack(int64_t row, float dn) {
+  return (static_cast<unsigned long long>(__float_as_uint(dn)) << 32) | static_cast<unsigned long long>(uint32_t(row) + 1u);
+}
+// ticket words (ints at Plan::o_ticket)
+constexpr int kTkFixCount = 2, kTkCorrCount = 3, kTkVcFragile = 5, kTkStatus = 6;
+constexpr int kStatusSpinExpired = 1;    // a bounded wait inside a launch ran out (reported through K_out[1])
+
+// One queued row, by one wave: replay torch's norm accumulation (the row's selected values scattered to their SORTED
+// positions, then the 8-chain / sequential fp32 sum).  Almost always the T-rounded norm equals the exactly rounded one;
+// when it does not, the row is recorded so that k_frame_centres can correct the column sums of its frame.
+// owner = the wave writes den[row] and the row's materialised x^ in any case; else only when the norm changed (the
+// sweep stored everything).
+template <int DT, int VEC, int NPLB>
+struct NormFixer {
+  int coff[NPLB], sp[NPLB];
+  __device__ __forceinline__ void init(const int* __restrict__ cols, const int* __restrict__ spos, int C, int pad_elem, int lane) {
+    load_col_offsets<NPLB>(cols, C, pad_elem, lane, coff);
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; sp[i] = p < C ? (spos ? spos[p] : p) : -1; }
+  }
+  // the row's DMA into buf0 must have been issued (row_issue); buf0's zero pad element must be in place
+  __device__ __forceinline__ void row(unsigned char* buf0, size_t rowb, int64_t row, float dn_old, bool owner, int C, int N,
+                                      float* __restrict__ den, void* __restrict__ xh, int* __restrict__ corr_count,
+                                      NormCorr* __restrict__ corr, int max_entries, int lane) {
+    const int Cp = xh_stride(C);
+    row_wait();
+    float xv[NPLB];
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) xv[i] = lds_elem<DT>(buf0, coff[i]);
+    wave_lds_fence();
+    float* sv = reinterpret_cast<float*>(buf0);
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) if (sp[i] >= 0) sv[sp[i]] = xv[i];
+    wave_lds_fence();
+    const float norm = rnT<DT>(norm_torch_order<DT>(sv, C, lane));
+    float dn = rnT<DT>(fmaxf(norm, 1e-12f));
+    if (norm != norm) dn = norm;
+    const bool changed = !(dn == dn_old) && !(dn != dn && dn_old != dn_old);
+    if (lane == 0 && (changed || owner)) den[row] = dn;
+    if (lane == 0 && changed) {
+      const int j = atomicAdd(corr_count, 1);
+      if (j < max_entries) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
+    }
+    if ((changed || owner) && xh) {                              // the row's materialised x^ follows the final norm
+      const double inv = 1.0 / double(dn);
+#pragma unroll
+      for (int i = 0; i < NPLB; ++i) {
+        const int p = i * 64 + lane;
+        if (p < C) stT<DT>(xh, row * Cp + p, div_via_f64(xv[i], inv));
+        else if (p < Cp) stT<DT>(xh, row * Cp + p, 0.f);
+      }
+    }
+    wave_lds_fence();
+    if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+  }
+};
+
 // sweep 2: denominators den[r] = RN_T(max(RN_T(||x_r||), 1e-12f)) (F.normalize, vidcom2.py:48) and the
 // per-(frame,split) column sums of x^ = RN_T(x / den) over the selected channels (compact order).
 // NPLB = compile-time bound on compact positions per lane (ceil(C/64) <= NPLB).
@@ -847,8 +932,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
                                                                 int C, const int* __restrict__ cols,
                                                                 int strict, int S, int nhi,
                                                                 float* __restrict__ den_out, double* __restrict__ part,
-                                                                int* __restrict__ nfix_count, int* __restrict__ nfix_list,
-                                                                int nfix_cap, uint8_t* __restrict__ rflag,
+                                                                int* __restrict__ tk, unsigned long long* __restrict__ fixq,
+                                                                int nfix_cap, NormCorr* __restrict__ corr,
                                                                 void* __restrict__ xh, OrderArgs rider) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
@@ -901,13 +986,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     // the norm rounded to T, the "torch order" queue, the denominator (F.normalize's clamp_min), den[row]
     auto finish_norm = [&](float nrm32, int margin) -> float {
       const float norm = rnT<DT>(nrm32);
-      // strict mode: where the norm sits within a few fp32 ulps of a T rounding boundary, torch's own
-      // fp32 accumulation order decides the result -> queue the row for k_norm_fix (a few per thousand)
-      if (strict && lane == 0 && (strict >= 2 || near_T_boundary<DT>(nrm32, margin)))
-        { const int j = atomicAdd(nfix_count, 1); if (j < nfix_cap) nfix_list[j] = int(row); }
       // clamp_min(1e-12) is evaluated in fp32 then cast to T (fp16: 1e-12 -> 0 => 0/0 = NaN, as torch)
       float dn = rnT<DT>(fmaxf(norm, 1e-12f));
       if (norm != norm) dn = norm;
+      // strict mode: where the norm sits within a few fp32 ulps of a T rounding boundary, torch's own fp32
+      // accumulation order decides the result -> queue the row (a few per thousand) for k_norm_fix
+      const bool flagged = strict && (strict >= 2 || near_T_boundary<DT>(nrm32, margin));
+      if (flagged && lane == 0) {
+        const int j = atomicAdd(tk + kTkFixCount, 1);
+        if (j < nfix_cap) __hip_atomic_store(fixq + j, fixq_pack(row, dn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (lane == 0) den_out[row] = dn;
       return dn;
     };
@@ -1018,65 +1106,30 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   }
 }
 
-// Strict-mode fix-up of sweep 2: for every queued row replay torch's norm accumulation (the row's selected
-// values scattered to their SORTED positions, then the 8-chain / sequential fp32 sum).  Almost always the
-// T-rounded norm equals the exactly-rounded one already in den[]; when it does not, den[] is corrected and
-// the row is recorded so that k_centres can correct the column sums of its frame.  One wave per entry.
-struct NormCorr { int row; float den_old; float den_new; int frame; };   // capacity: one per row (cannot overflow)
-
+// Fix-up of sweep 2: one wave per queued row.
 template <int DT, int VEC, int NPLB>
 __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int D, int CV, int C,
                                                  const int* __restrict__ cols, const int* __restrict__ spos,
                                                  float* __restrict__ den, const int* __restrict__ nfix_count,
-                                                 const int* __restrict__ nfix_list, int max_entries,
+                                                 const unsigned long long* __restrict__ fixq, int max_entries,
                                                  int* __restrict__ corr_count, NormCorr* __restrict__ corr,
                                                  int N, void* __restrict__ xh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
   const int lane = threadIdx.x;
-  const int Cp = xh_stride(C);
   unsigned char* buf0 = smem;
   const int count = min(*nfix_count, max_entries);
   if (int(blockIdx.x) >= count) return;
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-  int64_t row = nfix_list[blockIdx.x];
-  row_issue<DT, VEC>(x, row, D, CV, buf0, lane);                // first row's DMA overlaps the index loads below
-  int coff[NPLB], sp[NPLB];
-  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
-#pragma unroll
-  for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; sp[i] = p < C ? (spos ? spos[p] : p) : -1; }
+  unsigned long long g = fixq[blockIdx.x];
+  row_issue<DT, VEC>(x, int64_t(uint32_t(g)) - 1, D, CV, buf0, lane);   // first row's DMA overlaps the index loads below
+  NormFixer<DT, VEC, NPLB> fx;
+  fx.init(cols, spos, C, int((rowb - 16) / ES), lane);
   for (int e = blockIdx.x; e < count; e += gridDim.x) {
-    if (e != int(blockIdx.x)) { row = nfix_list[e]; row_issue<DT, VEC>(x, row, D, CV, buf0, lane); }
-    const float dn_old = den[row];
-    row_wait();
-    float xv[NPLB];
-#pragma unroll
-    for (int i = 0; i < NPLB; ++i) xv[i] = lds_elem<DT>(buf0, coff[i]);
-    wave_lds_fence();
-    float* sv = reinterpret_cast<float*>(buf0);
-#pragma unroll
-    for (int i = 0; i < NPLB; ++i) if (sp[i] >= 0) sv[sp[i]] = xv[i];
-    wave_lds_fence();
-    const float norm = rnT<DT>(norm_torch_order<DT>(sv, C, lane));
-    float dn = rnT<DT>(fmaxf(norm, 1e-12f));
-    if (norm != norm) dn = norm;
-    const bool changed = !(dn == dn_old) && !(dn != dn && dn_old != dn_old);
-    if (lane == 0 && changed) {
-      den[row] = dn;
-      const int j = atomicAdd(corr_count, 1);
-      if (j < max_entries) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
-    }
-    if (changed && xh) {                                       // the row's materialised x^ follows the corrected norm
-      const double inv = 1.0 / double(dn);
-#pragma unroll
-      for (int i = 0; i < NPLB; ++i) {
-        const int p = i * 64 + lane;
-        if (p < C) stT<DT>(xh, row * Cp + p, div_via_f64(xv[i], inv));
-      }
-    }
-    wave_lds_fence();
-    if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+    if (e != int(blockIdx.x)) { g = fixq[e]; row_issue<DT, VEC>(x, int64_t(uint32_t(g)) - 1, D, CV, buf0, lane); }
+    fx.row(buf0, rowb, int64_t(uint32_t(g)) - 1, __uint_as_float(uint32_t(g >> 32)), false, C, N, den, xh, corr_count, corr,
+           max_entries, lane);
   }
 }
 
@@ -2025,7 +2078,8 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
                                                      int64_t* __restrict__ idx_out, int64_t* __restrict__ K_out,
                                                      const double* __restrict__ vpart, int S2,
                                                      const float* __restrict__ frame_scores, float base,
-                                                     float temp, float* __restrict__ scales_out) {
+                                                     float temp, float* __restrict__ scales_out,
+                                                     const int* __restrict__ status = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float smf[4];
   __shared__ double smd[4];
@@ -2152,7 +2206,9 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
     if (fl == FS - 1) {
       offs[FS] = Ktot;
       K_out[0] = Ktot;
-      K_out[1] = Ktot > cap ? 1 : 0;
+      // status word: 1 = capacity exceeded, 2 = a bounded wait inside a launch of this pass expired (kTkStatus),
+      // 4 = a loop bound of the selection engine expired since the last pass that reported (vc2_select2.h)
+      K_out[1] = (Ktot > cap ? 1 : 0) | ((status && *status) ? 2 : 0) | (atomicExch(&g_sel2_dirty, 0) ? 4 : 0);
     }
   }
   if constexpr (DT == VC2_F32) select_frame_body<DT, uint64_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
@@ -2364,7 +2420,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
     // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
     // that the 10 exp per token of the fused epilogue are ONE round over the workgroup's 256 threads
 #ifndef VC2_DIST_WGS
-#define VC2_DIST_WGS 1024
+#define VC2_DIST_WGS 1400
 #endif
 #ifndef VC2_DIST_RPS_MIN
 #define VC2_DIST_RPS_MIN 16
@@ -2411,8 +2467,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_scales_f32 = take(size_t(std::max<int64_t>(F, kMaxFramesTotal)) * 4);  // (frame-sharded case)
   p->o_scales_T = take(size_t(F) * 4);
   p->o_offs = take(size_t(F + 1) * 8);
-  p->o_ticket = take(64);
-  p->o_nfixlist = take(size_t(p->R) * 4);
+  p->o_ticket = take(256);                                    // 64 ints (kTk*)
+  p->o_nfixlist = take(size_t(p->R) * 8);                     // 8-byte queue granules (fixq_pack)
   p->o_corr = take(size_t(p->R) * sizeof(NormCorr));
   p->vstride = int(cdiv(cdiv(std::min<int64_t>(p->R, int64_t(1) << 19), 16), 16) + 1);
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
@@ -2514,7 +2570,9 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, vo
     const int64_t n_each = int64_t(p.BF) * p.N, n_last = p.R - int64_t(p.NB - 1) * n_each;
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
                                              0, st, (const double*)nullptr, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
-                                             zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src));
+                                             zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src,
+                                             zero_queue_counters ? wsp<unsigned long long>(ws, p.o_nfixlist) : nullptr,
+                                             int(p.R)));
   } }
   return check_launch("chan_stats");
 }
@@ -2593,8 +2651,9 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
   hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(int64_t(p.S_nhi) * p.S + (p.F - p.S_nhi) * (p.S - 1) + (rider.perm ? (rider.parts & 0xFF) : 0))),
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_nhi,
-                     wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket) + 2,
-                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), wsp<void>(ws, p.o_xh), rider);
+                     wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<NormCorr>(ws, p.o_corr),
+                     wsp<void>(ws, p.o_xh), rider);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -2612,8 +2671,8 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   // fp16 queues ~3 % of the rows (its T ulp is 2^13 fp32 ulps) and replays ONE sequential chain per row: more waves
   const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(p.R, 4096)) : (p.dt == VC2_F16 ? 2048 : 512);
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
-                     cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + 2,
-                     wsp<int>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + 3,
+                     cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + kTkFixCount,
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + kTkCorrCount,
                      wsp<NormCorr>(ws, p.o_corr), int(p.N), wsp<void>(ws, p.o_xh));
   return VC2_OK;
 }
@@ -2708,7 +2767,8 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
 }
 
 int zero_counters(const Plan& p, void* ws, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(wsp<int>(ws, p.o_ticket), 0, 32, st);
+  hipError_t e = hipMemsetAsync(wsp<int>(ws, p.o_ticket), 0, 64, st);
+  if (e == hipSuccess) e = hipMemsetAsync(wsp<char>(ws, p.o_nfixlist), 0, size_t(p.R) * 8, st);
   if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
   return VC2_OK;
 }
@@ -2742,7 +2802,8 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 // F budget frames, of which this launch selects [f0, f0 + F_sel) (total / ks / offs are indexed by the local frame).
 // Budgets: vpart (sweep-3 partials, S2 per frame) or frame_scores -> compute_scales in the kernel; else scales_f32[F].
 struct BudgetSrc { const float* scales_f32; const double* vpart; int S2; const float* frame_scores; double base; double temp;
-                   float* scales_out; int64_t tpf = 0; };      // tpf: the multiplier of vidcom2.py:72 (0: N)
+                   float* scales_out; int64_t tpf = 0;         // tpf: the multiplier of vidcom2.py:72 (0: N)
+                   const int* status = nullptr; };             // the pass's kTkStatus word (reported in K_out[1])
 int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_sel, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   const BudgetSrc& b, hipStream_t st) {
@@ -2754,7 +2815,7 @@ int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_s
     hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F_sel)), dim3(kFrameNT), smem, st, total, b.scales_f32, int(F),
                        int(f0), int(N), int(b.tpf > 0 ? b.tpf : N), map_mode, int(grid_h), N, cap, ks, offs, idx_out, K_out,
                        b.vpart, b.S2,
-                       b.frame_scores, float(b.base), float(b.temp), b.scales_out);
+                       b.frame_scores, float(b.base), float(b.temp), b.scales_out, b.status);
   });
   return check_launch("select");
 }
@@ -3165,11 +3226,12 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   if ((rc = launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st))) return rc;
   if (fused_budget) {
     rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
-                       BudgetSrc{nullptr, wsp<double>(ws, p.o_vpart), p.S2, nullptr, bs, 0.01, scales}, st);
+                       BudgetSrc{nullptr, wsp<double>(ws, p.o_vpart), p.S2, nullptr, bs, 0.01, scales, 0,
+                                 wsp<int>(ws, p.o_ticket) + kTkStatus}, st);
   } else {
     if ((rc = launch_scales(dtype, s, F, bs, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
     rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
-                       BudgetSrc{scales, nullptr, 0, nullptr, bs, 0.01, nullptr}, st);
+                       BudgetSrc{scales, nullptr, 0, nullptr, bs, 0.01, nullptr, 0, wsp<int>(ws, p.o_ticket) + kTkStatus}, st);
   }
   if (rc) return rc;
   if (out_rows && gather_src)

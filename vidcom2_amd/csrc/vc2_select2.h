@@ -49,7 +49,8 @@ __device__ __forceinline__ bool key_fits_u32(float f) {
 // self-check: every loop of the engine is bounded; a bound that actually expires is counted here (read back by
 // vc2_selftest_counters; the test-suite asserts zeros)
 __device__ int g_sel2_guard_hits[8];
-__device__ __forceinline__ void guard_hit(int which) { atomicAdd(&g_sel2_guard_hits[which], 1); }
+__device__ int g_sel2_dirty;             // set by a hit, read-and-cleared by the pass's last kernel -> K_out[1] bit 2
+__device__ __forceinline__ void guard_hit(int which) { atomicAdd(&g_sel2_guard_hits[which], 1); atomicExch(&g_sel2_dirty, 1); }
 
 #ifdef VC2_SEL2_DEBUG
 __device__ unsigned long long g_sel2_dbg[128];

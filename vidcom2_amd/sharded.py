@@ -142,7 +142,8 @@ class HipStages:
     def result(self, f0):
         K, overflow, vc_fragile, _ = self.kout.tolist()     # the path's single host sync
         if overflow:
-            raise RuntimeError(f"vidcom2_amd: kept-token capacity {self.cap} exceeded (K={K})")
+            from .vidcom2 import _raise_status
+            _raise_status(int(overflow), self.cap, int(K))
         self.vc_fragile = int(vc_fragile)
         if vc_fragile and _ffi.get_mode() == "torch":
             import warnings

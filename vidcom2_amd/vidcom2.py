@@ -139,12 +139,26 @@ class CompressPlan:
         check(rc, "vc2_compress")
 
     def finish(self) -> CompressionResult:
-        K, overflow = self.kout.tolist()                 # the single host sync of the path
-        if overflow:
-            raise RuntimeError(f"vidcom2_amd: kept-token capacity {self.cap} exceeded (K={K}); "
-                               "vc2_kept_capacity bound violated -- please report")
+        K, status = self.kout.tolist()                   # the single host sync of the path
+        if status:
+            _raise_status(status, self.cap, K)
         rows = self.rows[:K + self.tail_rows] if self.rows is not None else None      # (kept rows, then the tail)
         return CompressionResult(rows, self.idx[:K], self.ks, int(K), self.v, self.f)
+
+
+def _raise_status(status: int, cap: int, K: int) -> None:
+    """K_out[1] of a pass (include/vc2.h): every bit is a 'cannot happen' condition the kernels check for instead of
+    returning a silently wrong kept set."""
+    why = []
+    if status & 1:
+        why.append(f"kept-token capacity {cap} exceeded (K={K}): vc2_kept_capacity bound violated")
+    if status & 2:
+        why.append("a bounded wait between workgroups of one launch expired")
+    if status & 4:
+        why.append("a loop bound of the selection replay expired (vc2_selftest_counters has the details)")
+    if status & ~7:
+        why.append(f"unknown status bits {status:#x}")
+    raise RuntimeError("vidcom2_amd: " + "; ".join(why) + " -- please report")
 
 
 @_guarded
