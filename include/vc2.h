@@ -57,13 +57,8 @@ const char* vc2_version(void);
  * other's mode; a worker thread that wants another mode sets it itself. */
 int vc2_set_mode(int mode);
 int vc2_get_mode(void);
-/* Workspace (bytes) needed by any entry point below for an [F*N, D] input (scoring up to D channels). */
+/* Workspace (bytes) needed by any entry point below for an [F*N, D] input. */
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes);
-/* The same for calls that score at most C_max channels: the workspace ends with the materialised normalised rows
- * x^[F*N][C rounded up to 128] in T (sweep 2 writes them once, sweep 3 and the replays stream them), so the whole
- * pass (vidcom2.py:41: C = int(D * 0.5)) needs about half of what C_max = D does; C_max = 0: the entry points that
- * score nothing (vc2_chan_stats, vc2_chan_var, vc2_pool_stats, vc2_select_sharded). */
-int vc2_workspace_bytes_c(int64_t F, int64_t N, int64_t D, int dtype, int64_t C_max, size_t* out_bytes);
 
 /* Upper bound on the number of kept tokens sum(ks) for a given base_scale: lets the caller
  * allocate the output of vc2_compress before the budgets are known (the reference learns K

@@ -67,11 +67,7 @@ def test_no_cpu_fallback():
 
 
 def test_workspace_and_limits():
-    assert _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16, C=0) < 64 << 20
-    # the materialised normalised rows x^[F*N, C] close the workspace
-    assert _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16, C=1792) - _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16, C=0) \
-        == 128 * 196 * 1792 * 2
-    assert _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16) == _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16, C=3584)
+    assert _ffi.workspace_bytes(128, 196, 3584, torch.bfloat16) < 64 << 20
     with pytest.raises(NotImplementedError):
         _ffi.workspace_bytes(2, 10, 16384, torch.float32)       # > 1024 column vectors per row
     with pytest.raises(RuntimeError):

@@ -26,7 +26,6 @@ _vp, _i64, _i32, _dbl, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctyp
 # name -> argtypes (restype int unless listed in _RESTYPES); mirrors include/vc2.h one to one
 _SIGNATURES = {
     "vc2_workspace_bytes": [_i64, _i64, _i64, _i32, ctypes.POINTER(_sz)],
-    "vc2_workspace_bytes_c": [_i64, _i64, _i64, _i32, _i64, ctypes.POINTER(_sz)],
     "vc2_kept_capacity": [_i64, _i64, _dbl],
     "vc2_chan_var": [_vp, _i64, _i64, _i32, _vp, _sz, _vp, _vp, _vp],
     "vc2_chan_select": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -132,19 +131,14 @@ def stream_ptr(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def workspace_bytes(F: int, N: int, D: int, dtype, C: Optional[int] = None) -> int:
-    """Workspace for an [F*N, D] input; C = the most channels a call will score (None: up to D; the whole pass scores
-    int(D * 0.5), vidcom2.py:41).  The materialised normalised rows x^[F*N, C] are the bulk of it."""
+def workspace_bytes(F: int, N: int, D: int, dtype) -> int:
     out = _sz(0)
-    if C is None:
-        check(lib().vc2_workspace_bytes(F, N, D, DTYPE_CODE[dtype], ctypes.byref(out)), "vc2_workspace_bytes")
-    else:
-        check(lib().vc2_workspace_bytes_c(F, N, D, DTYPE_CODE[dtype], C, ctypes.byref(out)), "vc2_workspace_bytes_c")
+    check(lib().vc2_workspace_bytes(F, N, D, DTYPE_CODE[dtype], ctypes.byref(out)), "vc2_workspace_bytes")
     return int(out.value)
 
 
-def workspace(F: int, N: int, D: int, dtype, device, C: Optional[int] = None) -> torch.Tensor:
-    return torch.empty(workspace_bytes(F, N, D, dtype, C), dtype=torch.uint8, device=device)
+def workspace(F: int, N: int, D: int, dtype, device) -> torch.Tensor:
+    return torch.empty(workspace_bytes(F, N, D, dtype), dtype=torch.uint8, device=device)
 
 
 def profile_enable(on: bool) -> None:

@@ -648,8 +648,7 @@ __device__ __forceinline__ void row_wait() {
 }
 
 // Compact positions a lane owns.  PAIR = 0: p = i*64 + lane (k_norm_fix).  PAIR = 1 (sweep 2): ADJACENT positions two by
-// two, p = 128*(i/2) + 2*lane + (i&1), so that a lane's pair (i, i+1) is one 4-byte (8-byte for fp32) element of the
-// materialised x^ row and a wave's store of it is 256 (512) contiguous bytes.
+// two, p = 128*(i/2) + 2*lane + (i&1): a lane's pair (i, i+1) is two neighbours of the compacted row.
 template <int PAIR> __device__ __forceinline__ int compact_pos(int i, int lane) {
   return PAIR ? 128 * (i >> 1) + 2 * lane + (i & 1) : i * 64 + lane;
 }
@@ -665,25 +664,6 @@ __device__ __forceinline__ void load_col_offsets(const int* __restrict__ cols, i
   }
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) coff[i] = compact_pos<PAIR>(i, lane) < C ? t[i] : D;
-}
-
-// ---- the materialised x^ rows (round 3) -------------------------------------------------------------------------
-// Sweep 2 stores x^ = RN_T(x[:, cols] / den) once, channel-compacted (ascending cols order), as xh[R][Cp] in T with
-// Cp = C rounded up to 128 elements (zero padded: a whole wave stores every pair slot): sweep 3, the replays and the centre fix-ups stream these 16-byte
-// aligned rows instead of gathering from X and dividing again.
-__host__ __device__ inline int xh_stride(int C) { return (C + 127) & ~127; }
-template <int DT> __device__ __forceinline__ void xh_store_pair(void* __restrict__ xh, int64_t row, int Cp, int p,
-                                                               float a, float b) {   // a, b: T-representable
-  if constexpr (DT == VC2_F32) {
-    *reinterpret_cast<float2*>(static_cast<float*>(xh) + row * Cp + p) = make_float2(a, b);
-  } else if constexpr (DT == VC2_BF16) {
-    *reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(xh) + row * Cp + p) =
-        (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
-  } else {
-    union { uint32_t u; _Float16 h[2]; } c;
-    c.h[0] = static_cast<_Float16>(a); c.h[1] = static_cast<_Float16>(b);
-    *reinterpret_cast<uint32_t*>(static_cast<uint16_t*>(xh) + row * Cp + p) = c.u;
-  }
 }
 
 // ---- strict mode: torch's own fp32 accumulation order for the tokens where it matters -----------------
@@ -875,8 +855,6 @@ constexpr int kStatusSpinExpired = 1;    // a bounded wait inside a launch ran o
 // One queued row, by one wave: replay torch's norm accumulation (the row's selected values scattered to their SORTED
 // positions, then the 8-chain / sequential fp32 sum).  Almost always the T-rounded norm equals the exactly rounded one;
 // when it does not, the row is recorded so that k_frame_centres can correct the column sums of its frame.
-// owner = the wave writes den[row] and the row's materialised x^ in any case; else only when the norm changed (the
-// sweep stored everything).
 template <int DT, int VEC, int NPLB>
 struct NormFixer {
   int coff[NPLB], sp[NPLB];
@@ -886,10 +864,9 @@ struct NormFixer {
     for (int i = 0; i < NPLB; ++i) { const int p = i * 64 + lane; sp[i] = p < C ? (spos ? spos[p] : p) : -1; }
   }
   // the row's DMA into buf0 must have been issued (row_issue); buf0's zero pad element must be in place
-  __device__ __forceinline__ void row(unsigned char* buf0, size_t rowb, int64_t row, float dn_old, bool owner, int C, int N,
-                                      float* __restrict__ den, void* __restrict__ xh, int* __restrict__ corr_count,
+  __device__ __forceinline__ void row(unsigned char* buf0, size_t rowb, int64_t row, float dn_old, int C, int N,
+                                      float* __restrict__ den, int* __restrict__ corr_count,
                                       NormCorr* __restrict__ corr, int max_entries, int lane) {
-    const int Cp = xh_stride(C);
     row_wait();
     float xv[NPLB];
 #pragma unroll
@@ -903,19 +880,10 @@ struct NormFixer {
     float dn = rnT<DT>(fmaxf(norm, 1e-12f));
     if (norm != norm) dn = norm;
     const bool changed = !(dn == dn_old) && !(dn != dn && dn_old != dn_old);
-    if (lane == 0 && (changed || owner)) den[row] = dn;
     if (lane == 0 && changed) {
+      den[row] = dn;
       const int j = atomicAdd(corr_count, 1);
       if (j < max_entries) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
-    }
-    if ((changed || owner) && xh) {                              // the row's materialised x^ follows the final norm
-      const double inv = 1.0 / double(dn);
-#pragma unroll
-      for (int i = 0; i < NPLB; ++i) {
-        const int p = i * 64 + lane;
-        if (p < C) stT<DT>(xh, row * Cp + p, div_via_f64(xv[i], inv));
-        else if (p < Cp) stT<DT>(xh, row * Cp + p, 0.f);
-      }
     }
     wave_lds_fence();
     if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
@@ -933,8 +901,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
                                                                 int strict, int S, int nhi,
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ tk, unsigned long long* __restrict__ fixq,
-                                                                int nfix_cap, NormCorr* __restrict__ corr,
-                                                                void* __restrict__ xh, OrderArgs rider) {
+                                                                int nfix_cap, uint8_t* __restrict__ rflag,
+                                                                OrderArgs rider) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
@@ -971,7 +939,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   }
   int coff[NPLB];
   load_col_offsets<NPLB, 1>(cols, C, int((rowb - 16) / ES), lane, coff);
-  const int Cp = xh_stride(C);
   double acc[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
@@ -999,6 +966,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
       if (lane == 0) den_out[row] = dn;
       return dn;
     };
+    // rflag[row] = 1 marks the rows that divide exactly (consumed by sweep 3; bf16 in "torch order" mode)
     float xv[NPLB];
     bool done = false;
     if constexpr (kFastBf16) {
@@ -1035,16 +1003,13 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
         const float nrm32 = float(sqrt(double(wave_sum_bcast_f32(ssq))));   // correctly rounded fp32 square root
         const float dn = finish_norm(nrm32, kFragileUlpsNorm + acc_norm_ulps(NPLB));
         const float r = __builtin_amdgcn_rcpf(dn);
-        uint32_t* __restrict__ orow = static_cast<uint32_t*>(xh) + (row * Cp >> 1) + lane;
+        if (lane == 0 && rflag) rflag[row] = 0;
 #pragma unroll
         for (int k = 0; k < NPLB / 2; ++k) {
           union { b2_t b; uint32_t u; } q;
           q.b = __builtin_convertvector((f2_t){__uint_as_float(P[k] << 16) * r, __uint_as_float(P[k] & 0xFFFF0000u) * r}, b2_t);
           acc[2 * k] += double(__uint_as_float(q.u << 16));
           acc[2 * k + 1] += double(__uint_as_float(q.u & 0xFFFF0000u));
-#if VC2_PROBE_S2 != 1
-          if (128 * k < Cp) orow[64 * k] = q.u;                   // (padded positions: x = 0 -> +0)
-#endif
         }
         done = true;
       } else {
@@ -1074,18 +1039,10 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
         nrm32 = float(sqrt(wave_sum_bcast(t)));
       }
       const float dn = finish_norm(nrm32, margin);
+      if (kFastBf16 && lane == 0 && rflag) rflag[row] = 1;
       const double inv = 1.0 / double(dn);
-      static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
 #pragma unroll
-      for (int i = 0; i < NPLB; i += 2) {
-        const int p = compact_pos<1>(i, lane);
-        float a = rnT<DT>(div_via_f64(xv[i], inv)), b = rnT<DT>(div_via_f64(xv[i + 1], inv));
-        acc[i] += double(a);
-        acc[i + 1] += double(b);
-        if (p >= C) a = 0.f;                                     // padding stays zero whatever den is (NaN rows)
-        if (p + 1 >= C) b = 0.f;
-        if (128 * (i >> 1) < Cp) xh_store_pair<DT>(xh, row, Cp, p, a, b);
-      }
+      for (int i = 0; i < NPLB; ++i) acc[i] += double(rnT<DT>(div_via_f64(xv[i], inv)));
     }
     unsigned char* tbuf = buf0; buf0 = buf1; buf1 = tbuf;
   }
@@ -1113,7 +1070,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
                                                  float* __restrict__ den, const int* __restrict__ nfix_count,
                                                  const unsigned long long* __restrict__ fixq, int max_entries,
                                                  int* __restrict__ corr_count, NormCorr* __restrict__ corr,
-                                                 int N, void* __restrict__ xh) {
+                                                 int N) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -1128,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   fx.init(cols, spos, C, int((rowb - 16) / ES), lane);
   for (int e = blockIdx.x; e < count; e += gridDim.x) {
     if (e != int(blockIdx.x)) { g = fixq[e]; row_issue<DT, VEC>(x, int64_t(uint32_t(g)) - 1, D, CV, buf0, lane); }
-    fx.row(buf0, rowb, int64_t(uint32_t(g)) - 1, __uint_as_float(uint32_t(g >> 32)), false, C, N, den, xh, corr_count, corr,
+    fx.row(buf0, rowb, int64_t(uint32_t(g)) - 1, __uint_as_float(uint32_t(g >> 32)), C, N, den, corr_count, corr,
            max_entries, lane);
   }
 }
@@ -1533,29 +1490,8 @@ __device__ __forceinline__ float gauss_sum(float dist) {
 //         v_pk_mul_f16 keep subnormals (IEEE, measured) -- v_pk_add_f16, v_pk_mul_f16, v_dot2c_f32_f16: 3 instructions
 //         per two channels and centre, with the centres as packed fp16 pairs;
 //   fp32 / "exact" mode: the plain sequence, fp64 accumulators.
-template <int DT, int ACC> struct DistArith {                     // generic: centres as fp32, accumulators acc_t
-  static constexpr int VEC = Tr<DT>::VEC;
-  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
-  struct Cen { float v[VEC], f[VEC]; };
-  static __device__ __forceinline__ void set(Cen& c, int e, float a, float b) { c.v[e] = a; c.f[e] = b; }
-  static __device__ __forceinline__ void vec(const RawVec<DT, VEC>& raw, const Cen& c, acc_t& pv, acc_t& pf) {
-    float xv[VEC];
-    unpack<DT, VEC>(raw, xv);
-#pragma unroll
-    for (int e = 0; e < VEC; e += 2) {
-      const f2_t d0 = rnT2v<DT>((f2_t){xv[e] - c.v[e], xv[e] - c.f[e]});
-      const f2_t d1 = rnT2v<DT>((f2_t){xv[e + 1] - c.v[e + 1], xv[e + 1] - c.f[e + 1]});
-      const f2_t q0 = rnT2v<DT>(d0 * d0), q1 = rnT2v<DT>(d1 * d1);
-      pv += acc_t(q0.x); pf += acc_t(q0.y);
-      pv += acc_t(q1.x); pf += acc_t(q1.y);
-    }
-  }
-};
+template <int DT, int ACC> struct DistArith;
 template <> struct DistArith<VC2_BF16, 1> {
-  static constexpr int VEC = 8;
-  using acc_t = float;
-  struct Cen { float v[VEC], f[VEC]; };
-  static __device__ __forceinline__ void set(Cen& c, int e, float a, float b) { c.v[e] = a; c.f[e] = b; }
   static __device__ __forceinline__ uint32_t pk(float a, float b) {                // (RN_bf16(a) | RN_bf16(b) << 16)
     typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
     union { b2_t h; uint32_t u; } c;
@@ -1567,41 +1503,6 @@ template <> struct DistArith<VC2_BF16, 1> {
     union { b2_t h; uint32_t u; } a, one;
     a.u = q; one.u = 0x3F803F80u;
     return __builtin_amdgcn_fdot2_f32_bf16(a.h, one.h, acc, false);
-  }
-  static __device__ __forceinline__ void vec(const RawVec<VC2_BF16, 8>& raw, const Cen& c, float& pv, float& pf) {
-    const uint32_t w[4] = {raw.v.x, raw.v.y, raw.v.z, raw.v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float xa = __uint_as_float(w[q] << 16), xb = __uint_as_float(w[q] & 0xFFFF0000u);
-      const uint32_t dv = pk(xa - c.v[2 * q], xb - c.v[2 * q + 1]);
-      const uint32_t df = pk(xa - c.f[2 * q], xb - c.f[2 * q + 1]);
-      const float va = __uint_as_float(dv << 16), vb = __uint_as_float(dv & 0xFFFF0000u);
-      const float fa = __uint_as_float(df << 16), fb = __uint_as_float(df & 0xFFFF0000u);
-      pv = dot_ones(pk(va * va, vb * vb), pv);
-      pf = dot_ones(pk(fa * fa, fb * fb), pf);
-    }
-  }
-};
-template <> struct DistArith<VC2_F16, 1> {
-  static constexpr int VEC = 8;
-  using acc_t = float;
-  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-  struct Cen { h2_t v[4], f[4]; };
-  static __device__ __forceinline__ void set(Cen& c, int e, float a, float b) {    // a, b: fp16-representable
-    c.v[e >> 1][e & 1] = static_cast<_Float16>(a);
-    c.f[e >> 1][e & 1] = static_cast<_Float16>(b);
-  }
-  static __device__ __forceinline__ void vec(const RawVec<VC2_F16, 8>& raw, const Cen& c, float& pv, float& pf) {
-    const uint32_t w[4] = {raw.v.x, raw.v.y, raw.v.z, raw.v.w};
-    const h2_t ones = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      union { uint32_t u; h2_t h; } x;
-      x.u = w[q];
-      const h2_t dv = x.h - c.v[q], df = x.h - c.f[q];
-      pv = __builtin_amdgcn_fdot2(dv * dv, ones, pv, false);
-      pf = __builtin_amdgcn_fdot2(df * df, ones, pf, false);
-    }
   }
 };
 
@@ -1635,175 +1536,196 @@ __device__ __forceinline__ void wave_totals_f32(float (&v)[K]) {
 }
 
 // sweep 3 (vidcom2.py:61-62, :32-33): per token dist_v = RN_T(sum_c RN_T(RN_T(x^ - vc)^2)), dist_f likewise with
-// the frame centre; then -- still inside the workgroup -- the 5-scale Gaussian sums v, f, total = RN_T(v + f) and the
-// workgroup's partial sum of v (for the per-frame uniqueness score).
-// Round 3: x^ is READ (the rows sweep 2 materialised, xh[R][Cp] in T: half the bytes of X, no gather, no division).
-// A row is spread over the whole workgroup: lane l of wave w owns the 16-byte vectors (w*per + l) + j*4*per, j < NVL,
-// of every row (per = ceil(vectors per row / 4 / NVL) <= 64), i.e. the SAME <= 8 * NVL channels for all rows -- both
-// centres of those channels stay in fp32 registers, and U rows' loads are in flight per lane.  Phases per workgroup
-// (one frame split, <= kDistMaxRows rows):
-//   1. row loop: per row and wave one partial pair (video, frame) -- per-lane sequential sum, fixed DPP tree (ACC = 1:
-//      fp32, bounded error, see acc_dist3_ulps; ACC = 0: fp64) -- parked in LDS; then the four wave partials of every
-//      row are added in wave order.  In "torch order" mode a sum within the replay margin of a T rounding boundary is
-//      put on a workgroup-local list;
-//   2. the (rare) listed sums are replayed in torch's cascade order by the whole workgroup: every thread scatters a
-//      few squares to their SORTED positions (spos) in LDS, wave 0 adds them;
-//   3. 10 exp per token spread over the workgroup's threads, the two running sums, outputs.
+// the frame centre, x^ recomputed from X and den; then -- still inside the workgroup -- the 5-scale Gaussian sums
+// v, f, total = RN_T(v + f) and the workgroup's partial sum of v (for the per-frame uniqueness score).
+// Column offsets and both centres of the lane's compact positions live in registers for the whole workgroup; the
+// row loop touches LDS only for the row itself.  Three phases per workgroup (one frame split, <= 64 rows):
+//   1. row loop, one wave per row.  The sweep is bound by VALU ISSUE (see DistPair), so the lane's elements are
+//      handled two by two; the totals of TWO rows (4 values) are reduced together (wave_totals_f32).  In "torch
+//      order" mode a sum within the replay margin of a T rounding boundary is put on a workgroup-local list;
+//   2. the (rare) listed sums are replayed in torch's cascade order by the whole workgroup: every thread recomputes
+//      a few squares from X and scatters them to their SORTED positions (spos) in LDS, wave 0 adds them;
+//   3. 10 Gaussian terms per token spread over the workgroup's threads (v_exp_f32, fp64 next to a rounding
+//      boundary), the two running sums, outputs.
+// (Round 3 also built the other data flow -- sweep 2 materialising x^ for a sweep 3 that streams it: same bytes per
+// pass, measured 3 % SLOWER at the target shape, 90 MB more workspace; NOTES_r03.md.)
 constexpr int kDistMaxRows = 64;
-__host__ __device__ constexpr int dist_rows_in_flight(int nvl) { return nvl == 1 ? 4 : 2; }   // per batch; two batches
-// roundings on the way from a square to the row sum: VEC*NVL - 1 sequential adds, six tree levels, three wave adds
-__host__ __device__ constexpr int acc_dist3_ulps(int per_lane) { return per_lane + 8 + 3; }
 
-template <int DT, int NVL, int ACC>
-__global__ __launch_bounds__(kRowWaves * 64) void k_dist3(const void* __restrict__ xh, int N, int C, int per,
-                                                          const int* __restrict__ spos, int strict, int S,
-                                                          int rows_per_split, const float* __restrict__ vc,
-                                                          const float* __restrict__ fc,
-                                                          void* __restrict__ v_T, void* __restrict__ f_T,
-                                                          float* __restrict__ total, double* __restrict__ vpart) {
+template <int DT, int VEC, int NPLB, int ACC>
+__global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
+                                                         const int* __restrict__ cols,
+                                                         const int* __restrict__ spos, int strict, int S,
+                                                         int rows_per_split, const float* __restrict__ den,
+                                                         const uint8_t* __restrict__ rflag,
+                                                         const float* __restrict__ vc,
+                                                         const float* __restrict__ fc,
+                                                         void* __restrict__ v_T, void* __restrict__ f_T,
+                                                         float* __restrict__ total, double* __restrict__ vpart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int VEC = Tr<DT>::VEC;
-  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
+  constexpr int ES = Tr<DT>::ES;
+  constexpr bool kFast = ACC == 1 && DT == VC2_BF16;
+  const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int f = blockIdx.x / S, sp = blockIdx.x % S;
   const int n0 = sp * rows_per_split;
   const int n1 = min(N, n0 + rows_per_split);
   const int nrows = n1 - n0;
-  const int Cp = xh_stride(C), nvp = Cp / VEC;                    // vectors per materialised row
-  constexpr int kDistU = dist_rows_in_flight(NVL);                // rows in flight per lane
-  // LDS: phase 1 partials [kDistMaxRows][4][2] acc_t; phase 2 float sq[C]; then the small arrays
-  const size_t area = (std::max(size_t(kDistMaxRows) * 8 * sizeof(acc_t), size_t(C) * 4 + 16) + 15) / 16 * 16;
-  acc_t* psum = reinterpret_cast<acc_t*>(smem);
-  float* dists = reinterpret_cast<float*>(smem + area);           // [kDistMaxRows][2]  RN_T distances (v, f)
+  // One row buffer per wave and no intra-wave prefetch: measured faster than double buffering here
+  // (45 vs 50 us at 128x196x3584) because the smaller LDS footprint doubles the resident waves.
+  unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]; phase 2: float sq[C]
+  const size_t area = (std::max(size_t(kRowWaves) * rowb, size_t(C) * 4 + 16) + 15) / 16 * 16;
+  float* dens = reinterpret_cast<float*>(smem + area);             // [kDistMaxRows]
+  float* dists = dens + kDistMaxRows;                             // [kDistMaxRows][2]  RN_T distances (v, f)
   float* ebuf = dists + 2 * kDistMaxRows;                         // [kDistMaxRows][10] Gaussian terms
   int* list = reinterpret_cast<int*>(ebuf + 10 * kDistMaxRows);   // [2 * kDistMaxRows] (local row) * 2 + centre
   int* lcount = list + 2 * kDistMaxRows;                          // [0] phase-2 list, [1] phase-3 list
   uint16_t* elist = reinterpret_cast<uint16_t*>(lcount + 4);      // [10 * kDistMaxRows] exp terms for the fp64 path
+  uint8_t* rfl = reinterpret_cast<uint8_t*>(elist + 10 * kDistMaxRows);   // [kDistMaxRows]
+  int n = n0 + wave;
+  if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   if (tid < 2) lcount[tid] = 0;
-  // my vectors and the centres of their channels (padding and idle lanes: zeros -> they add +0)
-  using AR = DistArith<DT, ACC>;
-  int vi[NVL];
-  bool act[NVL];
-  typename AR::Cen cen[NVL];
-  const float* __restrict__ fcf = fc + int64_t(f) * C;
-#pragma unroll
-  for (int j = 0; j < NVL; ++j) {
-    vi[j] = wave * per + lane + j * 4 * per;
-    act[j] = lane < per && vi[j] < nvp;
-    vi[j] = act[j] ? vi[j] : nvp - 1;                             // idle: any valid vector (its partial is dropped)
-    float a[VEC], b[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {                               // unconditional (clamped) loads, all in flight
-      const int pch = vi[j] * VEC + e, pc = pch < C ? pch : C - 1;
-      a[e] = vc[pc];
-      b[e] = fcf[pc];
-    }
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const bool in = act[j] && vi[j] * VEC + e < C;
-      AR::set(cen[j], e, in ? a[e] : 0.f, in ? b[e] : 0.f);
-    }
+  for (int r = tid; r < nrows; r += kRowWaves * 64) {
+    dens[r] = den[int64_t(f) * N + n0 + r];
+    rfl[r] = (kFast && rflag) ? rflag[int64_t(f) * N + n0 + r] : 1;
   }
-  const unsigned char* __restrict__ base = static_cast<const unsigned char*>(xh) + (int64_t(f) * N + n0) * Cp * Tr<DT>::ES;
-  // ---- phase 1 -------------------------------------------------------------------------------------------
-  // Batches of kDistU rows, software-pipelined: the loads of batch k + 1 are in flight while batch k is computed (all
-  // workgroups start together and do the same work, so without the prefetch the whole chip alternates between a
-  // memory burst and a compute burst: measured 32 us against 15 us for the arithmetic alone).
-  auto load = [&](RawVec<DT, VEC> (&raw)[kDistU][NVL], int r0) {
-#pragma unroll
-    for (int u = 0; u < kDistU; ++u) {
-      const int r = min(r0 + u, nrows - 1);                       // (clamped: the surplus rows are not stored)
-#pragma unroll
-      for (int j = 0; j < NVL; ++j) {
-#if VC2_PROBE_D3 == 4
-        raw[u][j] = zero_raw<DT, VEC>();
-        if constexpr (DT != VC2_F32) raw[u][j].v = make_uint4(0x3c003c00u + r + lane, 0x3c003c00u + (r ^ lane), 0x3c003c00u + r * 3 + lane, 0x3c003c00u + lane - r);
-#else
-        raw[u][j] = load_raw<DT, VEC>(base, (int64_t(r) * nvp + vi[j]) * VEC);
-#endif
-      }
-    }
-  };
-  auto compute = [&](const RawVec<DT, VEC> (&raw)[kDistU][NVL], int r0) {
-    constexpr int U = kDistU;
-    acc_t part[2 * U];                                            // (video, frame) of row r0 + u at [2u], [2u + 1]
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc_t pv = 0, pf = 0;
-#pragma unroll
-      for (int j = 0; j < NVL; ++j) {
-        acc_t tv = 0, tf = 0;
-#if VC2_PROBE_D3 == 3
-        if constexpr (DT != VC2_F32) { tv = acc_t(raw[u][j].v.x ^ raw[u][j].v.y); tf = acc_t(raw[u][j].v.z ^ raw[u][j].v.w); }
-#else
-        AR::vec(raw[u][j], cen[j], tv, tf);
-#endif
-        pv += act[j] ? tv : acc_t(0);                             // (an idle lane's vector is somebody else's)
-        pf += act[j] ? tf : acc_t(0);
-      }
-      part[2 * u] = pv;
-      part[2 * u + 1] = pf;
-    }
-    if constexpr (ACC == 0) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double sv = wave_sum_bcast(part[2 * u]), sf = wave_sum_bcast(part[2 * u + 1]);
-        if (lane == 0 && r0 + u < nrows) { psum[((r0 + u) * 4 + wave) * 2] = sv; psum[((r0 + u) * 4 + wave) * 2 + 1] = sf; }
-      }
-    } else {
-      wave_totals_f32<2 * U>(part);
-      // register m, row rr of the wave: value 4m + {0, 2, 1, 3}[rr] = row r0 + (idx >> 1), centre idx & 1
-      const int rr = lane >> 4;
-      const int sub = ((rr & 1) << 1) | (rr >> 1);
-      if ((lane & 15) == 0) {
-#pragma unroll
-        for (int m = 0; m < 2 * U / 4; ++m) {
-          const int idx = 4 * m + sub, r = r0 + (idx >> 1);
-          if (r < nrows) psum[(r * 4 + wave) * 2 + (idx & 1)] = part[m];
-        }
-      }
-    }
-  };
+  int coff[NPLB];
+  float cv[NPLB], cf[NPLB];                                       // video / frame centre of the lane's compact positions
+  load_col_offsets<NPLB>(cols, C, int((rowb - 16) / ES), lane, coff);
   {
-    RawVec<DT, VEC> rawA[kDistU][NVL], rawB[kDistU][NVL];
-    const int nb = (nrows + kDistU - 1) / kDistU;
-    load(rawA, 0);
-    int b = 0;
-    for (; b + 2 < nb; b += 2) {                                  // (no branch in here: a join would cost a vmcnt(0))
-      load(rawB, (b + 1) * kDistU);
-      compute(rawA, b * kDistU);
-      load(rawA, (b + 2) * kDistU);
-      compute(rawB, (b + 1) * kDistU);
-    }
-    if (b + 1 < nb) {
-      load(rawB, (b + 1) * kDistU);
-      compute(rawA, b * kDistU);
-      compute(rawB, (b + 1) * kDistU);
-    } else {
-      compute(rawA, b * kDistU);
+    // unconditional loads (clamped index), batched; a load inside a conditional is waited for on the spot, and
+    // 2 * NPLB serialised L2 round trips cost the whole workgroup ~10 us.  (Batches of 8: the temporaries must
+    // not become the kernel's register peak.)
+    constexpr int B = NPLB % 8 == 0 ? 8 : NPLB % 7 == 0 ? 7 : 2;
+    const float* __restrict__ fcf = fc + int64_t(f) * C;
+#pragma unroll
+    for (int i0 = 0; i0 < NPLB; i0 += B) {
+      float a[B], b[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const uint32_t p = uint32_t((i0 + j) * 64 + lane), pc = p < uint32_t(C) ? p : uint32_t(C - 1);
+        a[j] = vc[pc];                                             // (32-bit offsets: scalar base + VGPR offset loads)
+        b[j] = fcf[pc];
+      }
+      asm volatile("" ::: "memory");                               // keep the batches apart
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const bool in = (i0 + j) * 64 + lane < C;
+        cv[i0 + j] = in ? a[j] : 0.f;
+        cf[i0 + j] = in ? b[j] : 0.f;
+      }
     }
   }
+  // (plain loads first: behind an in-flight global_load_lds the compiler waits for EVERY load separately)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (n < n1) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
   __syncthreads();
-  if (tid < nrows) {
-    const acc_t* q = psum + tid * 8;
-    const acc_t sv = ((q[0] + q[2]) + q[4]) + q[6], sf = ((q[1] + q[3]) + q[5]) + q[7];   // wave order
-    const float dvv = float(sv), dff = float(sf);
-    const int margin = ACC == 0 ? kFragileUlpsDist : kFragileUlpsDist + acc_dist3_ulps(VEC * NVL);
+  // ---- phase 1 ---------------------------------------------------------------------------------------
+  // The rows' results stay in registers (lane `it` holds row it of this wave) until the loop is over: the compiler
+  // orders every LDS access behind an in-flight global_load_lds with vmcnt(0).
+  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
+  float res_v = 0.f, res_f = 0.f;
+  uint32_t res_flag = 0u;
+  const int margin = ACC == 0 ? kFragileUlpsDist : kFragileUlpsDist + acc_dist_ulps(NPLB);
+  auto settle = [&](float dvv, float dff, int it) {               // one row's two sums -> lane `it`
     // rare: a sum within a few fp32 ulps of a T rounding boundary, where torch's own fp32 accumulation order
     // decides the result -> phase 2
     const uint32_t fl = !strict ? 0u
                                 : ((strict >= 2 || near_T_boundary<DT>(dvv, margin)) ? 1u : 0u) |
                                       ((strict >= 2 || near_T_boundary<DT>(dff, margin)) ? 2u : 0u);
-    dists[2 * tid] = rnT<DT>(dvv);
-    dists[2 * tid + 1] = rnT<DT>(dff);
-    if (fl & 1u) list[atomicAdd(lcount, 1)] = tid * 2;
-    if (fl & 2u) list[atomicAdd(lcount, 1)] = tid * 2 + 1;
+    if (lane == it) { res_v = rnT<DT>(dvv); res_f = rnT<DT>(dff); res_flag = fl; }
+  };
+  float held_v = 0.f, held_f = 0.f;                               // (fast path) the previous row's lane partials
+  int it = 0;
+  for (; n < n1; n += kRowWaves, ++it) {
+    // issue the row's DMA, wait, compute straight from LDS
+    if (it) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+    row_wait();
+    const float dn = dens[n - n0];
+    const bool exact_div = !kFast || rfl[n - n0] != 0;
+    static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
+    if constexpr (kFast) {
+      typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+      using AR = DistArith<VC2_BF16, 1>;
+      float pv = 0.f, pf = 0.f;
+      auto body = [&](auto exact_tag) {
+        constexpr bool kExact = decltype(exact_tag)::value;
+        const double inv = kExact ? 1.0 / double(dn) : 0.0;
+        const float r = kExact ? 0.f : __builtin_amdgcn_rcpf(dn);
+#pragma unroll
+        for (int k = 0; k < NPLB / 2; ++k) {
+          const float a = __uint_as_float(uint32_t(reinterpret_cast<const uint16_t*>(buf0)[coff[2 * k]]) << 16);
+          const float b = __uint_as_float(uint32_t(reinterpret_cast<const uint16_t*>(buf0)[coff[2 * k + 1]]) << 16);
+          // x^ pair, rounded by ONE packed conversion; then the DistArith sequence on it
+          const uint32_t xh = kExact ? AR::pk(div_via_f64(a, inv), div_via_f64(b, inv)) : AR::pk(a * r, b * r);
+          const float xa = __uint_as_float(xh << 16), xb = __uint_as_float(xh & 0xFFFF0000u);
+          const uint32_t dv = AR::pk(xa - cv[2 * k], xb - cv[2 * k + 1]);
+          const uint32_t df = AR::pk(xa - cf[2 * k], xb - cf[2 * k + 1]);
+          const float va = __uint_as_float(dv << 16), vb = __uint_as_float(dv & 0xFFFF0000u);
+          const float fa = __uint_as_float(df << 16), fb = __uint_as_float(df & 0xFFFF0000u);
+          pv = AR::dot_ones(AR::pk(va * va, vb * vb), pv);
+          pf = AR::dot_ones(AR::pk(fa * fa, fb * fb), pf);
+        }
+      };
+      if (exact_div) body(std::true_type{}); else body(std::false_type{});
+      // two rows' lane partials are reduced together (four values: one permlane32 / permlane16 fold each)
+      if (it & 1) {
+        float q[4] = {held_v, held_f, pv, pf};
+        wave_totals_f32<4>(q);                                    // row r of the wave's 16-lane rows: value {0, 2, 1, 3}[r]
+        auto at = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[0]), l)); };
+        const float t0 = at(0), t2 = at(16), t1 = at(32), t3 = at(48);
+        settle(t0, t1, it - 1);
+        settle(t2, t3, it);
+      } else {
+        held_v = pv; held_f = pf;
+      }
+    } else if constexpr (ACC == 1 && DT == VC2_F16) {
+      // fp16: the hardware's packed fp16 subtract / multiply ARE the reference's roundings here (DistArith)
+      typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+      const h2_t ones = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
+      const double inv = 1.0 / double(dn);
+      float pv = 0.f, pf = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPLB / 2; ++k) {
+        const float v0 = lds_elem<DT>(buf0, coff[2 * k]), v1 = lds_elem<DT>(buf0, coff[2 * k + 1]);
+        const h2_t xh = __builtin_convertvector((f2_t){div_via_f64(v0, inv), div_via_f64(v1, inv)}, h2_t);
+        const h2_t cvp = __builtin_convertvector((f2_t){cv[2 * k], cv[2 * k + 1]}, h2_t);    // (loop-invariant: hoisted)
+        const h2_t cfp = __builtin_convertvector((f2_t){cf[2 * k], cf[2 * k + 1]}, h2_t);
+        const h2_t dv = xh - cvp, df = xh - cfp;
+        pv = __builtin_amdgcn_fdot2(dv * dv, ones, pv, false);
+        pf = __builtin_amdgcn_fdot2(df * df, ones, pf, false);
+      }
+      settle(wave_sum_bcast_f32(pv), wave_sum_bcast_f32(pf), it);
+    } else {
+      acc_t pv = 0, pf = 0;                                       // accumulation order: i, then i + 1
+      const double inv = 1.0 / double(dn);
+#pragma unroll
+      for (int i = 0; i < NPLB; i += 2) {
+        const float v0 = lds_elem<DT>(buf0, coff[i]), v1 = lds_elem<DT>(buf0, coff[i + 1]);
+        float xh0, xh1;
+        rnT2<DT>(div_via_f64(v0, inv), div_via_f64(v1, inv), xh0, xh1);
+        const f2_t d0 = rnT2v<DT>((f2_t){xh0 - cv[i], xh0 - cf[i]});
+        const f2_t d1 = rnT2v<DT>((f2_t){xh1 - cv[i + 1], xh1 - cf[i + 1]});
+        const f2_t q0 = rnT2v<DT>(pk_square(d0)), q1 = rnT2v<DT>(pk_square(d1));
+        pv += acc_t(q0.x); pf += acc_t(q0.y);
+        pv += acc_t(q1.x); pf += acc_t(q1.y);
+      }
+      if constexpr (ACC == 0) settle(float(wave_sum_bcast(pv)), float(wave_sum_bcast(pf)), it);
+      else settle(wave_sum_bcast_f32(pv), wave_sum_bcast_f32(pf), it);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // LDS reads done before the buffer is refilled
+  }
+  if constexpr (kFast) {
+    if (it & 1) settle(wave_sum_bcast_f32(held_v), wave_sum_bcast_f32(held_f), it - 1);   // the odd row out
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < it) {
+    const int nl = wave + lane * kRowWaves;
+    dists[2 * nl] = res_v;
+    dists[2 * nl + 1] = res_f;
+    if (res_flag & 1u) list[atomicAdd(lcount, 1)] = nl * 2;
+    if (res_flag & 2u) list[atomicAdd(lcount, 1)] = nl * 2 + 1;
   }
   __syncthreads();
-#if VC2_PROBE_D3 == 1
-  if (tid == 0) vpart[blockIdx.x] = dists[0];
-  return;
-#endif
   // ---- phase 2: replay torch's cascade sum for the listed (row, centre) pairs ---------------------------
   if (strict) {
     const int cnt = *lcount;
@@ -1811,10 +1733,13 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist3(const void* __restrict
     for (int e = 0; e < cnt; ++e) {
       const int ent = list[e];
       const int nl = ent >> 1, which = ent & 1;
-      const float* cen = which ? fcf : vc;
+      const int64_t row = int64_t(f) * N + n0 + nl;
+      const double inv = 1.0 / double(dens[nl]);
+      const float* cen = which ? fc + int64_t(f) * C : vc;
       for (int p = tid; p < C; p += kRowWaves * 64) {
-        const int spp = spos ? spos[p] : p;
-        const float a = rnT<DT>(ldT<DT>(base, int64_t(nl) * Cp + p) - cen[p]);
+        const int col = cols ? cols[p] : p, spp = spos ? spos[p] : p;
+        const float xh = rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), inv));
+        const float a = rnT<DT>(xh - cen[p]);
         sq[spp] = rnT<DT>(a * a);
       }
       __syncthreads();
@@ -1826,16 +1751,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist3(const void* __restrict
     }
   }
   // ---- phase 3: Gaussian sums, total, partial frame sum ---------------------------------------------
-  for (int it = tid; it < nrows * 10; it += kRowWaves * 64) {
-    const int nl = it / 10, j = it - nl * 10;
+  for (int t = tid; t < nrows * 10; t += kRowWaves * 64) {
+    const int nl = t / 10, j = t - nl * 10;
     float e;
-    if (!gauss_term_fast<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j, e)) elist[atomicAdd(lcount + 1, 1)] = uint16_t(it);
-    ebuf[it] = e;
+    if (!gauss_term_fast<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j, e)) elist[atomicAdd(lcount + 1, 1)] = uint16_t(t);
+    ebuf[t] = e;
   }
   __syncthreads();
   for (int k = tid; k < lcount[1]; k += kRowWaves * 64) {         // the few terms next to a rounding boundary: fp64 exp
-    const int it = elist[k], nl = it / 10, j = it - nl * 10;
-    ebuf[it] = gauss_term<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j);
+    const int t = elist[k], nl = t / 10, j = t - nl * 10;
+    ebuf[t] = gauss_term<DT>(dists[2 * nl + (j >= 5 ? 1 : 0)], j >= 5 ? j - 5 : j);
   }
   __syncthreads();
   if (wave == 0) {
@@ -2370,7 +2295,7 @@ struct Plan {
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_tmp_f32, o_xh, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
   int vstride;
 };
 
@@ -2420,24 +2345,14 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
     // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
     // that the 10 exp per token of the fused epilogue are ONE round over the workgroup's 256 threads
 #ifndef VC2_DIST_WGS
-#define VC2_DIST_WGS 1400
+#define VC2_DIST_WGS 1024
 #endif
 #ifndef VC2_DIST_RPS_MIN
 #define VC2_DIST_RPS_MIN 16
 #endif
-    // rows per workgroup: 16 .. 32, at least ~768 workgroups when the video allows, and among those the split whose
-    // batches (4 rows) compute the fewest surplus rows; ties: fewer, longer splits
-    auto padded = [](int64_t n) { return (n + 3) / 4 * 4; };
-    const int64_t lo = std::min<int64_t>(N, VC2_DIST_RPS_MIN), hi = std::min<int64_t>(N, 32);
-    int64_t best = -1, best_cost = 0;
-    for (int64_t rps = hi; rps >= lo; --rps) {
-      const int64_t S2 = cdiv(N, rps), r2 = cdiv(N, S2), last = N - (S2 - 1) * r2;
-      if (F * S2 < std::min<int64_t>(VC2_DIST_WGS * 3 / 4, F * cdiv(N, lo)) && rps > lo) continue;   // too few workgroups
-      const int64_t cost = (S2 - 1) * padded(r2) + padded(last);
-      if (best < 0 || cost < best_cost) { best = rps; best_cost = cost; }
-    }
-    if (best < 0) best = lo;
-    p->S2 = int(cdiv(N, best));
+    int64_t rps = std::max<int64_t>(VC2_DIST_RPS_MIN, std::min<int64_t>(25, cdiv(p->R, VC2_DIST_WGS)));
+    rps = std::min<int64_t>(rps, N);
+    p->S2 = int(cdiv(N, rps));
     p->rows_per_split2 = int(cdiv(N, p->S2));
   }
   size_t o = 0;
@@ -2474,8 +2389,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
   p->o_vticket = take(size_t(D) * 4);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
-  p->o_xh = o;                                                // materialised x^ rows: LAST, sized by the call's C
-  p->total_bytes = o + align_up(size_t(p->R) * size_t(xh_stride(int(D))) * p->ES);   // (any C <= D)
+  p->total_bytes = o;
   return VC2_OK;
 }
 
@@ -2523,16 +2437,10 @@ struct ProfScope {
   VC2_DISPATCH_DT((p).dt, if ((p).VEC == 1) { constexpr int VEC = 1; __VA_ARGS__; } \
                   else { constexpr int VEC = Tr<DT>::VEC; __VA_ARGS__; })
 
-// bytes a call needs that scores C channels (the materialised x^ rows close the workspace: C = 0 -> none of them)
-size_t ws_bytes_for(const Plan& p, int64_t C) {
-  return p.o_xh + align_up(size_t(p.R) * size_t(xh_stride(int(std::min<int64_t>(std::max<int64_t>(C, 0), p.D)))) * p.ES);
-}
-int need_ws(const Plan& p, void* ws, size_t ws_bytes, int64_t C) {
+int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
   if (!ws) return fail(VC2_ERR_ARG, "workspace pointer is null");
-  const size_t need = ws_bytes_for(p, C);
-  if (ws_bytes < need)
-    return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes (vc2_workspace_bytes_c with C = %lld)", ws_bytes,
-                need, (long long)C);
+  if (ws_bytes < p.total_bytes)
+    return fail(VC2_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, p.total_bytes);
   return VC2_OK;
 }
 
@@ -2652,8 +2560,7 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_nhi,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
-                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<NormCorr>(ws, p.o_corr),
-                     wsp<void>(ws, p.o_xh), rider);
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -2673,42 +2580,31 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
                      cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + kTkFixCount,
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + kTkCorrCount,
-                     wsp<NormCorr>(ws, p.o_corr), int(p.N), wsp<void>(ws, p.o_xh));
+                     wsp<NormCorr>(ws, p.o_corr), int(p.N));
   return VC2_OK;
 }
 struct DistOut { void* v_T; void* f_T; float* total; };
 
-template <int DT, int NVL, int ACC>
-int launch_dist_nvl(const Plan& p, const ChanSet& cs, void* ws, const DistOut& o, int per, hipStream_t st) {
-  using acc_t = typename std::conditional<ACC == 0, double, float>::type;
-  const int C = cs.C;
-  const size_t area = (std::max(size_t(kDistMaxRows) * 8 * sizeof(acc_t), size_t(C) * 4 + 16) + 15) / 16 * 16;
-  const size_t smem = area + size_t(kDistMaxRows) * (8 + 40 + 8 + 20) + 64;
-  int rc = allow_big_lds(&k_dist3<DT, NVL, ACC>, smem, "k_dist3");
+template <int DT, int VEC, int NPLB, int ACC>
+int launch_dist_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
+  const int* cols = cs.cols; const int C = cs.C;
+  const size_t area = (std::max(size_t(kRowWaves) * row_lds_bytes(int(p.D), Tr<DT>::ES), size_t(C) * 4 + 16) + 15) / 16 * 16;
+  const size_t smem = area + size_t(kDistMaxRows) * (4 + 8 + 40 + 8 + 20 + 1) + 64;
+  int rc = allow_big_lds(&k_dist<DT, VEC, NPLB, ACC>, smem, "k_dist");
   if (rc) return rc;
   ProfScope ps_(KID_DIST, st);
-  hipLaunchKernelGGL((k_dist3<DT, NVL, ACC>), dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st,
-                     wsp<const void>(ws, p.o_xh), int(p.N), C, per, cs.spos, cs.strict, p.S2, p.rows_per_split2,
-                     wsp<float>(ws, p.o_vc), wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total,
-                     wsp<double>(ws, p.o_vpart));
+  hipLaunchKernelGGL((k_dist<DT, VEC, NPLB, ACC>), dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st, x,
+                     int(p.N), int(p.D), p.CV, C, cols, cs.spos, cs.strict, p.S2, p.rows_per_split2,
+                     wsp<float>(ws, p.o_den), wsp<uint8_t>(ws, p.o_rflag), wsp<float>(ws, p.o_vc),
+                     wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total, wsp<double>(ws, p.o_vpart));
   return VC2_OK;
 }
-template <int DT, int ACC>
-int launch_dist_acc(const Plan& p, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
-  const int nvp = xh_stride(cs.C) / Tr<DT>::VEC;                 // 16-byte vectors per materialised row
-  const int nvl = nvp <= 256 ? 1 : nvp <= 512 ? 2 : 4;
-  const int per = int(cdiv(nvp, 4 * nvl));
-  if (per > 64) return fail(VC2_ERR_UNSUPPORTED, "more than 4096 scored channels");
-  if (nvl == 1) return launch_dist_nvl<DT, 1, ACC>(p, cs, ws, o, per, st);
-  if (nvl == 2) return launch_dist_nvl<DT, 2, ACC>(p, cs, ws, o, per, st);
-  return launch_dist_nvl<DT, 4, ACC>(p, cs, ws, o, per, st);
-}
-template <int DT>
-int launch_dist_t(const Plan& p, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
+template <int DT, int VEC, int NPLB>
+int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, const DistOut& o, hipStream_t st) {
   if constexpr (DT != VC2_F32) {
-    if (fast_acc(p, cs)) return launch_dist_acc<DT, 1>(p, cs, ws, o, st);
+    if (fast_acc(p, cs)) return launch_dist_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, o, st);
   }
-  return launch_dist_acc<DT, 0>(p, cs, ws, o, st);
+  return launch_dist_acc<DT, VEC, NPLB, 0>(p, x, cs, ws, o, st);
 }
 // compact positions per lane -> compile-time bucket (28 = 3584-d, 32 = 4096-d models)
 #define VC2_DISPATCH_NPL(npl, FN, ...)                                   \
@@ -2780,8 +2676,9 @@ int launch_phase2(const Plan& p, const void* x, const ChanSet& cs, void* ws, voi
   const int C = cs.C;
   if (p.rows_per_split2 > kDistMaxRows) return fail(VC2_ERR_UNSUPPORTED, "internal: sweep-3 split too long");
   { int rc = VC2_OK;
+  const int npl = int(cdiv(C, 64));
   const DistOut o{v_T, f_T, total};
-  VC2_DISPATCH_DT(p.dt, rc = launch_dist_t<DT>(p, cs, ws, o, st));
+  VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_dist_t, p, x, cs, ws, o, st));
   if (rc) return rc; }
   if (s) {
     ProfScope ps_(KID_EPILOGUE, st);
@@ -2857,16 +2754,11 @@ int vc2_set_mode(int mode) {
 int vc2_get_mode(void) { return g_strict; }
 
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
-  return vc2_workspace_bytes_c(F, N, D, dtype, D, out_bytes);
-}
-
-int vc2_workspace_bytes_c(int64_t F, int64_t N, int64_t D, int dtype, int64_t C_max, size_t* out_bytes) {
   if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
-  if (C_max < 0 || C_max > D) return fail(VC2_ERR_ARG, "C_max=%lld outside [0, D]", (long long)C_max);
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
-  *out_bytes = ws_bytes_for(p, C_max);
+  *out_bytes = p.total_bytes;
   return VC2_OK;
 }
 
@@ -2889,7 +2781,7 @@ int vc2_chan_stats(const void* x, int64_t F, int64_t N, int64_t D, int dtype, in
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, F_total, block_frames);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   return launch_chan_stats(p, x, ws, bstats, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -2911,7 +2803,7 @@ int vc2_chan_var(const void* x, int64_t R, int64_t D, int dtype, void* ws, size_
   Plan p;
   int rc = make_plan(1, R, D, dtype, &p);   // the variance does not depend on the frame structure
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   float* vf = var_f32 ? var_f32 : wsp<float>(ws, p.o_var_f32);
   return launch_chan_stats(p, x, ws, nullptr, var_T, vf, static_cast<hipStream_t>(stream));
 }
@@ -2961,7 +2853,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, F_total);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((rc = zero_counters(p, ws, st))) return rc;
   const ChanSet cs = make_chanset(p, cols, spos, C);
@@ -2992,7 +2884,7 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, R_total / N);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
   if (!vc_blocks_ok(p, R_total, cs0.strict)) return VC2_OK;      // nothing to exchange: phase 2 keeps the exact means
@@ -3025,7 +2917,7 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, R_total / N);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
   const bool have_blocks = blocks_all && world > 0 && cap > 0 && vc_blocks_ok(p, R_total, cs0.strict) &&
@@ -3056,7 +2948,7 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, C))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
@@ -3129,7 +3021,7 @@ int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, 
                 (long long)D, dtype == VC2_F32 ? 8 : 16);
   Plan p;
   if ((rc = make_plan(F, h * w, D, dtype, &p))) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   const PoolSrc pool{xin, int(H), int(W), int(h), int(w), mode};
   return launch_stats_sweep(p, x_out, ws, pool, static_cast<hipStream_t>(stream));
 }
@@ -3192,7 +3084,7 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, int64_t(double(D) * 0.5)))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
@@ -3251,7 +3143,7 @@ int vc2_select_sharded(const float* total_f32, const float* s_all_f32, int64_t F
   Plan p;
   int rc = make_plan(F_local, N, D, dtype, &p, F_total);
   if (rc) return rc;
-  if ((rc = need_ws(p, ws, ws_bytes, 0))) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* scales = wsp<float>(ws, p.o_scales_f32);
   // budgets over ALL frames of the video (softmax + mean are global, vidcom2.py:66-67), selection only for this

@@ -165,7 +165,7 @@ def pool_stats(image_feature: torch.Tensor, height: int, width: int, mode: str =
     check(lib().vc2_pool_out_tokens(int(height), int(width), POOL_MODES[mode], ctypes.byref(h), ctypes.byref(w)),
           "vc2_pool_out_tokens")
     n = int(h.value) * int(w.value)
-    ws = _ffi.workspace(F, n, D, x.dtype, x.device, C=int(D * 0.5))     # (the pass that follows scores D/2 channels)
+    ws = _ffi.workspace(F, n, D, x.dtype, x.device)
     out = torch.empty((F, n, D), dtype=x.dtype, device=x.device)
     with on_device(x.device):
         rc = lib().vc2_pool_stats(ptr(x), F, int(height), int(width), D, DTYPE_CODE[x.dtype], POOL_MODES[mode], ptr(ws),

@@ -47,7 +47,7 @@ class HipStages:
         self.F, self.N, self.D, self.dtype, self.device, self.base = F, N, D, dtype, torch.device(device), base_scale
         self.code = DTYPE_CODE[dtype]
         L = lib()
-        self.ws = _ffi.workspace(F, N, D, dtype, self.device, C=int(D * 0.5))
+        self.ws = _ffi.workspace(F, N, D, dtype, self.device)
         # canonical partials: per stat block of `bf` frames (mean, M2); per group of 16 frames the
         # sums of the normalised tokens.  bf = 8 whenever F is a multiple of 8 (then the gathered blocks are exactly
         # the unsharded pass's blocks and every world size reduces to the same bits)

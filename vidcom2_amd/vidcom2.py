@@ -109,7 +109,7 @@ class CompressPlan:
                           "accumulation order (2^19 tokens per video, 2^17 per frame); boundary-near centre values "
                           "keep their exactly rounded mean and may differ from the CPU reference by one ulp",
                           RuntimeWarning, stacklevel=3)
-        self.ws = ws if ws is not None else _ffi.workspace(self.F, self.N, self.D, dtype, self.device, C=int(self.D * 0.5))
+        self.ws = ws if ws is not None else _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
         self.idx = torch.empty(cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(self.F, dtype=torch.int64, device=self.device)
         self.kout = torch.empty(2, dtype=torch.int64, device=self.device)    # both words written by every pass
@@ -193,7 +193,7 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
     if tail is not None:
         tail = _prep(tail if tail.dim() == 2 else tail[None], "tail")
     if stats_ws is not None and (x.data_ptr() != flattened_feat.data_ptr()
-                                 or stats_ws.numel() < _ffi.workspace_bytes(R // tpf, tpf, D, x.dtype, C=int(D * 0.5))):
+                                 or stats_ws.numel() < _ffi.workspace_bytes(R // tpf, tpf, D, x.dtype)):
         stats_ws = None                                   # a copy was made / another shape: the statistics are not its
     plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather,
                         tail_rows=0 if tail is None else tail.shape[0], ws=stats_ws)
@@ -265,7 +265,7 @@ def vidcom2_compression(flattened_feat: torch.Tensor, model: str = "llava_ov", b
 def _channel_variance(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """x.var(dim=0, unbiased=False) (vidcom2.py:40): returns (var in T, fp32-widened copy)."""
     R, D = x.shape
-    ws = _ffi.workspace(1, R, D, x.dtype, x.device, C=0)
+    ws = _ffi.workspace(1, R, D, x.dtype, x.device)
     var_T = torch.empty(D, dtype=x.dtype, device=x.device)
     var_f = torch.empty(D, dtype=torch.float32, device=x.device)
     check(lib().vc2_chan_var(ptr(x), R, D, DTYPE_CODE[x.dtype], ptr(ws), ws.numel(), ptr(var_T), ptr(var_f),
