@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the VidCom2 token-compression pass on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--workload target|cfg4|cfg5|...]
+      N > 1 without WORLD_SIZE in the environment: the script re-launches itself under torch.distributed.run with N
+      ranks on 127.0.0.1 (one rank per GPU; fails loudly when the node has fewer than N devices).  Under a launcher
+      (WORLD_SIZE set) --gpus must equal WORLD_SIZE.
 
 A "step" = one whole pass over one batch of synthetic frame-token embeddings already resident in
 HBM: channel selection, scoring, budgets, per-frame selection and the kept-row gather
@@ -11,8 +14,12 @@ every run before timing).
 
 N = 1 : workload "target" = 128 frames x 196 tokens x 3584-d bf16, 25 % retain (the shape
         BASELINE.json's north-star target is quoted on); cfg2 (32x196x3584) is reported beside it.
-N > 1 : weak scaling -- every rank holds 128 frames of ONE long video of 128*N frames, frame-sharded
-        with three small RCCL all-gathers (stat blocks, centre sums, per-frame uniqueness scores).
+N > 1 : "target": weak scaling -- every rank holds 128 frames of ONE long video of 128*N frames, frame-sharded
+        with three (+1) small RCCL all-gathers (stat blocks, centre sums, replay blocks, per-frame uniqueness scores);
+        "cfg4" (BASELINE configs[3]): STRONG scaling -- one 512-frame video, 512/N frames per rank, same exchanges;
+        "cfg5" (configs[4]): 16 clips of 128x196x4096 fp16, 16/N clips per rank, replicas (no collective: the
+        reference's document-level data parallelism), two clips in flight per GPU.
+        The sharded lines carry "exchanges_us": the mean time of every all-gather with its message size.
 
 One JSON line on rank 0 (see the repo prompt for the contract), with extra objects:
   "roofline"      the dominant kernel's achieved algorithmic HBM rate (hipEvent-timed inside this run)
@@ -45,7 +52,10 @@ WORKLOADS = {
     "target_fp32": (128, 196, 3584, torch.float32, 0.25),
     "cfg5clip": (128, 196, 4096, torch.float16, 0.25),
     "cfg1": (8, 196, 1024, torch.float32, 0.25),
+    "cfg4": (512, 196, 3584, torch.bfloat16, 0.25),       # one long video; frame-sharded: 512 / world frames per rank
+    "cfg5": (128, 196, 4096, torch.float16, 0.25),        # per CLIP; the workload is 16 of them, 16 / world per rank
 }
+CFG5_CLIPS = 16
 DT_NAME = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}
 
 
@@ -177,6 +187,70 @@ def roofline_of(kern, F, N, D, es, K, workload, world):
                     ("X (%d MB) exceeds the 256 MiB Infinity Cache: every sweep streams from HBM" % (X >> 20))}
 
 
+def relaunch_under_launcher(args) -> int:
+    """`python bench.py --gpus N` (N > 1, no launcher): run the same command as N ranks of ONE node."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s): refusing to report a "
+                         f"{args.gpus}-GPU number from fewer devices")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (the host driver supports nothing else)
+    return subprocess.call(cmd, env=env)
+
+
+def bench_replicas(args, rank, world, dev, vc, _ffi, synth):
+    """cfg5: 16 independent clips, 16 / world per rank, no collective (the reference's document-level DP,
+    lmms-eval evaluator.py:488-491); every rank keeps two clips in flight on two streams."""
+    F, N, D, dtype, base = WORKLOADS["cfg5"]
+    if CFG5_CLIPS % world:
+        raise SystemExit(f"[bench] cfg5: {CFG5_CLIPS} clips do not split over {world} ranks")
+    mine = CFG5_CLIPS // world
+    # distinct clips (different seeds); generated on the host once, resident in HBM before anything is timed
+    clips = [synth.make(F, N, D, dtype, seed=rank * mine + i, dist="drift").to(dev) for i in range(min(mine, 4))]
+    clips = [clips[i % len(clips)] for i in range(mine)]        # (>4 clips per rank: the same four again -- timing only)
+    res0 = vc.vidcom2.compress_batch(clips[:1], N, base)[0]
+    if rank == 0 and not args.no_cpu_baseline:                  # parity gate on the first clip
+        import oracle
+        oracle.set_mode("torch")
+        ref = oracle.compress_indices(clips[0].cpu(), N, base)
+        if res0.ks.cpu().tolist() != ref["ks"].tolist() or not torch.equal(res0.global_idx.cpu(), ref["global_idx"]):
+            raise SystemExit("[bench] PARITY FAILURE (cfg5 clip 0): kept indices / budgets differ from the oracle")
+    step = lambda: vc.vidcom2.compress_batch(clips, N, base, in_flight=2)      # noqa: E731
+    for _ in range(args.warmup):
+        step()
+    dist_on = world > 1
+    elapsed = time_steps(step, args.steps, dist_on)
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    es = 2
+    out = {
+        "metric": "video-tokens compressed/sec at 25% retain; kept-index bit-exact vs ref",
+        "value": round(CFG5_CLIPS * F * N / (elapsed / args.steps), 1), "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": DT_NAME[dtype], "data": "synthetic",
+        "config": {"workload": f"cfg5: {CFG5_CLIPS} clips x {F} frames x {N} tokens x {D}-d {DT_NAME[dtype]}, retain {base}, "
+                               f"{mine} clip(s) per GPU, two in flight, no collective (replicas)",
+                   "kept_tokens_clip0": res0.K, "parallelism": f"replicas x{world}"},
+        "roofline": None, "cpu_baseline": None,
+        "pass_roofline": {"alg_bytes": alg_bytes_pass(F, N, D, es, base) * CFG5_CLIPS,
+                          "achieved_GBs": round(alg_bytes_pass(F, N, D, es, base) * CFG5_CLIPS / (ms * 1e-3) / 1e9, 1),
+                          "frac_of_8TBs_per_gpu": round(alg_bytes_pass(F, N, D, es, base) * mine / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        "mode": _ffi.get_mode(),
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,15 +261,22 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and os.environ.get("VC2_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(relaunch_under_launcher(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1 or os.environ.get("VC2_BENCH_FORCE_DIST") == "1"   # (the override exercises the
-    #                                 sharded code path on one GPU; used by the single-GPU smoke run only)
-    if args.gpus != world and rank == 0 and dist_on:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s): the line "
+                         "would report a GPU count it did not run on")
+    force = os.environ.get("VC2_BENCH_FORCE_DIST") == "1"       # the sharded code path + its collectives at world 1
+    dist_on = world > 1 or force
     if os.environ.get("VC2_BENCH_ONE_GPU") == "1":    # test knob: every rank on cuda:0 (with VC2_BENCH_BACKEND=gloo;
         local = 0                                     # RCCL refuses two ranks on one device)
+    elif torch.cuda.device_count() <= local:
+        raise SystemExit(f"[bench] rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
@@ -210,9 +291,20 @@ def main():
     import vidcom2_amd as vc
     from vidcom2_amd import _ffi, synth
 
+    if args.workload == "cfg5":
+        bench_replicas(args, rank, world, dev, vc, _ffi, synth)
+        if dist_on:
+            torch.distributed.destroy_process_group()
+        return
     F, N, D, dtype, base = WORKLOADS[args.workload]
     es = 4 if dtype == torch.float32 else 2
-    F_total = F * world
+    strong = args.workload == "cfg4"                   # one video of F frames, F / world per rank
+    if strong:
+        if F % world or (F // world) % 8:
+            raise SystemExit(f"[bench] cfg4: {F} frames do not split into multiples of 8 over {world} ranks")
+        F_total, F = F, F // world
+    else:
+        F_total = F * world                            # weak scaling: every rank brings F frames
 
     # ---- synthetic input, resident in HBM before any timed region --------------------------------
     x_cpu = None
@@ -224,6 +316,8 @@ def main():
         x32 = synth.make_fp32_frames(F_total, N, D, rank * F, F, seed=0, dist="drift")
         x = synth.to_torch(x32, dtype).reshape(F * N, D).to(dev)
         del x32
+        if force and world == 1:
+            x_cpu = x.cpu()                            # (one rank: the CPU reference can check the sharded path too)
 
     if not dist_on:
         plan = vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base)
@@ -231,7 +325,7 @@ def main():
         finish = plan.finish
     else:
         from vidcom2_amd.sharded import ShardedCompressor
-        sc = ShardedCompressor(F, N, D, dtype, dev, base, group=None)
+        sc = ShardedCompressor(F, N, D, dtype, dev, base, group=None, always_collective=force)
         step = lambda: sc.enqueue(x)            # noqa: E731
         finish = sc.finish
 
@@ -239,8 +333,8 @@ def main():
     cpu = None
     step()
     res = finish()
-    if not dist_on and not args.no_cpu_baseline:
-        cpu, ref = cpu_baselines(x_cpu, N, base)
+    if x_cpu is not None and not args.no_cpu_baseline:
+        cpu, ref = cpu_baselines(x_cpu, N, base, budget_s=10.0 if F_total * N <= 30000 else 3.0)
         ok = res.ks.cpu().tolist() == ref["ks"].tolist() and torch.equal(res.global_idx.cpu(), ref["global_idx"])
         if not ok:
             raise SystemExit("[bench] PARITY FAILURE: kept indices / budgets differ from the oracle")
@@ -264,10 +358,12 @@ def main():
     out = {
         "metric": "video-tokens compressed/sec at 25% retain; kept-index bit-exact vs ref",
         "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": DT_NAME[dtype], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {F_total} frames x {N} tokens x {D}-d {DT_NAME[dtype]}, "
                                f"retain {base}" + (f", frame-sharded {F} frames/GPU, 4 RCCL all-gathers" if dist_on else ""),
+                   "frames_per_gpu": F,
                    "kept_tokens": K, "parallelism": f"frame-shard x{world}" if dist_on else "single GPU"},
         "roofline": roof,
         "cpu_baseline": cpu,
@@ -280,6 +376,13 @@ def main():
                                      "accumulation order)" if _ffi.get_mode() == "torch" else "")
     if not dist_on:
         out["median_ms_per_step"] = round(median_step_ms(step, max(args.steps, 20)), 4)
+    else:
+        # the exchanges of the sharded pass, one by one: hipEvents around every all-gather of `steps` more passes
+        sc.profile_exchanges(True)
+        for _ in range(max(5, args.steps // 2)):
+            step()
+        out["exchanges_us"] = sc.exchange_times_us()
+        sc.profile_exchanges(False)
 
     extra = not dist_on and not args.no_extra
     # ---- side: the pass replayed from a hipGraph (serving loops capture it once) ------------------------
@@ -413,6 +516,33 @@ def main():
         out["two_clips_in_flight"] = {"ms_per_round": round(e4 / args.steps * 1e3, 4),
                                       "tokens_per_s": round(2 * F * N / (e4 / args.steps), 1)}
 
+    # ---- side: the other dtypes of BASELINE.json's shapes, each behind its own parity gate (C++ oracle, same tensor):
+    #      the target shape in fp32, and ONE clip of the batched-eval config (128 x 196 x 4096 fp16) --------------
+    if extra and args.workload == "target":
+        import oracle
+        oracle.set_mode("torch")
+        for wl in ("target_fp32", "cfg5clip"):
+            Fo, No, Do, dto, bo = WORKLOADS[wl]
+            xo_cpu = synth.make(Fo, No, Do, dto, seed=0, dist="drift")
+            xo = xo_cpu.to(dev)
+            po = vc.vidcom2.CompressPlan(Fo, No, Do, dto, dev, bo)
+            po.enqueue(xo)
+            ro = po.finish()
+            leg = {"workload": f"{Fo}x{No}x{Do} {DT_NAME[dto]} retain {bo}"}
+            if not args.no_cpu_baseline:
+                ref = oracle.compress_indices(xo_cpu, No, bo)
+                leg["parity"] = bool(ro.ks.cpu().tolist() == ref["ks"].tolist() and torch.equal(ro.global_idx.cpu(), ref["global_idx"]))
+                if not leg["parity"]:
+                    raise SystemExit(f"[bench] PARITY FAILURE ({wl}): kept indices / budgets differ from the oracle")
+            for _ in range(args.warmup):
+                po.enqueue(xo)
+            eo = time_steps(lambda: po.enqueue(xo), args.steps, False)
+            eso = 4 if dto == torch.float32 else 2
+            leg.update({"ms_per_step": round(eo / args.steps * 1e3, 4), "tokens_per_s": round(Fo * No / (eo / args.steps), 1),
+                        "pass_alg_GBs": round(alg_bytes_pass(Fo, No, Do, eso, bo) / (eo / args.steps) / 1e9, 1),
+                        "pass_frac_of_8TBs": round(alg_bytes_pass(Fo, No, Do, eso, bo) / (eo / args.steps) / 1e9 / HBM_PEAK_GBS, 4)})
+            out[wl] = leg
+            del xo, po, xo_cpu
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -444,3 +444,29 @@ def test_gather_source_too_small_raises_like_the_reference():
     x = make_input(4, 169, 128, "bf16", 0, "drift").to(dev())
     with pytest.raises(IndexError):
         vc.vidcom2_compression(x, model="llava_vid", img_feat=x[:100])       # needs 4 * 13 * 14 rows
+
+
+@pytest.mark.gpu
+def test_plan_cache_returns_independent_results():
+    """The one-shot API re-uses a cached plan (workspace, status words) per shape / stream / thread, but every call
+    hands out fresh tensors, like the reference: a second call must not overwrite the first call's result."""
+    from vidcom2_amd import vidcom2 as V
+    V.clear_plan_cache()
+    xa = synth.make(8, 49, 256, torch.bfloat16, 1, "drift").cuda()
+    xb = synth.make(8, 49, 256, torch.bfloat16, 2, "drift").cuda()
+    ra = V.compress(xa, 49, 0.25)
+    rows_a, idx_a, ks_a = ra.rows.clone(), ra.global_idx.clone(), ra.ks.clone()
+    n_plans = len(V._PLAN_CACHE)
+    rb = V.compress(xb, 49, 0.25)
+    assert len(V._PLAN_CACHE) == n_plans == 1                       # same shape, stream, thread: one plan
+    assert torch.equal(ra.rows, rows_a) and torch.equal(ra.global_idx, idx_a) and torch.equal(ra.ks, ks_a)
+    assert ra.rows.data_ptr() != rb.rows.data_ptr() and ra.global_idx.data_ptr() != rb.global_idx.data_ptr()
+    assert not torch.equal(rb.global_idx, idx_a) or not torch.equal(rb.rows, rows_a)
+    # the same input again gives the same answer from the re-used workspace
+    rc = V.compress(xa, 49, 0.25)
+    assert torch.equal(rc.rows, rows_a) and torch.equal(rc.global_idx, idx_a)
+    # another stream gets its own plan
+    with torch.cuda.stream(torch.cuda.Stream()):
+        rd = V.compress(xa, 49, 0.25)
+    torch.cuda.synchronize()
+    assert len(V._PLAN_CACHE) == 2 and torch.equal(rd.global_idx, idx_a)

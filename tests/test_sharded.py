@@ -205,3 +205,70 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert len(lines) == 1                                   # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "frame-shard x2"
+
+
+def _run_bench(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root, capture_output=True,
+                         text=True, timeout=timeout)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, (json.loads(lines[0]) if len(lines) == 1 else None)
+
+
+@pytest.mark.gpu
+def test_bench_sharded_pass_on_rccl_at_world_one():
+    """VC2_BENCH_FORCE_DIST=1: the frame-sharded pass with its four all-gathers on the `nccl` (= RCCL) backend, one
+    rank -- all_gather_into_tensor on fp64 / fp32 device tensors really executes -- behind the CPU parity gate; the
+    line reports the GPU count it ran on and the time of every exchange."""
+    out, d = _run_bench(["--gpus", "1", "--workload", "cfg2", "--steps", "3", "--warmup", "1", "--no-extra"],
+                        {"VC2_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert d is not None and d["n_gpus"] == 1 and d["config"]["parallelism"] == "frame-shard x1"
+    assert d["cpu_baseline"] is not None                      # the parity gate ran (and passed) on the sharded result
+    ex = d["exchanges_us"]
+    assert set(ex) >= {"stats", "csum", "s"} and all(v["us"] > 0 and v["bytes_per_rank"] > 0 for v in ex.values())
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` without a launcher spawns its own ranks -- and must not print a line when the node
+    has fewer devices (round 2: it silently ran on one GPU)."""
+    import torch as _t
+    n = _t.cuda.device_count() + 1
+    out, d = _run_bench(["--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"])
+    assert out.returncode != 0 and d is None and "refusing" in (out.stderr + out.stdout)
+    # and under a launcher the line's n_gpus cannot differ from --gpus
+    out, d = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                        {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert out.returncode != 0 and d is None
+
+
+@pytest.mark.gpu
+def test_bench_cfg4_strong_scaling_two_ranks_on_one_gpu():
+    """BASELINE configs[3] (one 512-frame video, frame-sharded: 256 frames per rank here) through bench.py's own code
+    path: two ranks on cuda:0 with gloo collectives."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VC2_BENCH_ONE_GPU="1", VC2_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--workload", "cfg4"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_gpu"] == 256
+    assert d["config"]["workload"].startswith("cfg4: 512 frames")
+
+
+@pytest.mark.gpu
+def test_bench_cfg5_replicas():
+    """BASELINE configs[4]: 16 clips, replicas, no collective; parity gate on clip 0."""
+    out, d = _run_bench(["--gpus", "1", "--workload", "cfg5", "--steps", "1", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "replicas x1" and d["dtype"] == "f16" and d["value"] > 0

@@ -171,8 +171,12 @@ class ShardedCompressor:
     """Frame-sharded pass; every rank calls enqueue(x_local) + finish() collectively."""
 
     def __init__(self, F_local: int, N: int, D: int, dtype, device, base_scale: float = 0.25, group=None,
-                 stages=None, gather: bool = True):
+                 stages=None, gather: bool = True, always_collective: bool = False):
+        """always_collective: issue the all-gathers even at world size 1 (a process group must be initialised) -- the
+        only way to put the RCCL exchanges themselves under test on a single-GPU box."""
         self.group = group
+        self.always_collective = bool(always_collective)
+        self._xev = None                                  # per-exchange hipEvent pairs (profile_exchanges)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.F, self.N, self.D = int(F_local), int(N), int(D)
@@ -186,12 +190,39 @@ class ShardedCompressor:
         self._gbuf = {}
 
     def _gather(self, key: str, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return t.unsqueeze(0)
         buf = self._gbuf.get(key)
         if buf is None or buf.shape[1:] != t.shape or buf.dtype != t.dtype or buf.device != t.device:
             buf = self._gbuf[key] = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if self._xev is None or not t.is_cuda:
+            return self._collect(t, buf)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = self._collect(t, buf)
+        b.record()
+        self._xev.setdefault(key, []).append((a, b))
+        return out
+
+    def _collect(self, t: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:                                # (always_collective: the collective itself, one rank)
+            dist.all_gather_into_tensor(buf.view(-1), t.contiguous().view(-1), group=self.group)
+            return buf
         return _all_gather(t, self.group, self.world, buf)
+
+    def profile_exchanges(self, on: bool = True) -> None:
+        """hipEvents around every exchange of the passes that follow (stats / csum / blocks / s)."""
+        self._xev = {} if on else None
+
+    def exchange_times_us(self) -> dict:
+        """Mean microseconds per exchange since profile_exchanges(True) (synchronises); the message sizes with them."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, evs in (self._xev or {}).items():
+            buf = self._gbuf.get(key)
+            out[key] = {"us": round(sum(a.elapsed_time(b) for a, b in evs) / len(evs) * 1e3, 1),
+                        "bytes_per_rank": int(buf[0].numel() * buf.element_size()) if buf is not None else None}
+        return out
 
     def enqueue(self, x_local: torch.Tensor) -> None:
         st = self.stages

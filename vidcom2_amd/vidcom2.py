@@ -11,7 +11,10 @@ input's device.  Tensors must live on a ROCm device: there is no CPU fallback.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
+import os
+import threading
 import warnings
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
@@ -110,14 +113,22 @@ class CompressPlan:
                           "keep their exactly rounded mean and may differ from the CPU reference by one ulp",
                           RuntimeWarning, stacklevel=3)
         self.ws = ws if ws is not None else _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
-        self.idx = torch.empty(cap, dtype=torch.int64, device=self.device)
-        self.ks = torch.empty(self.F, dtype=torch.int64, device=self.device)
         self.kout = torch.empty(2, dtype=torch.int64, device=self.device)    # both words written by every pass
         # tail_rows: extra rows (LLaVA's newline embedding) the gather launch appends behind the kept ones
         self.tail_rows = int(tail_rows) if gather else 0
-        self.rows = torch.empty((cap + self.tail_rows, self.D), dtype=dtype, device=self.device) if gather else None
-        self.v = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
-        self.f = torch.empty((self.F, self.N), dtype=dtype, device=self.device) if want_scores else None
+        self._gather, self._want_scores = bool(gather), bool(want_scores)
+        self.new_outputs()
+
+    def new_outputs(self) -> None:
+        """Fresh output tensors (kept rows, indices, budgets, scores) for the next pass.  A plan that is re-used for
+        independent calls (the one-shot API's plan cache) calls this before every enqueue, so that a result handed out
+        earlier is never overwritten -- the reference returns fresh tensors as well; workspace and status words stay."""
+        dt, dev = self.dtype, self.device
+        self.idx = torch.empty(self.cap, dtype=torch.int64, device=dev)
+        self.ks = torch.empty(self.F, dtype=torch.int64, device=dev)
+        self.rows = torch.empty((self.cap + self.tail_rows, self.D), dtype=dt, device=dev) if self._gather else None
+        self.v = torch.empty((self.F, self.N), dtype=dt, device=dev) if self._want_scores else None
+        self.f = torch.empty((self.F, self.N), dtype=dt, device=dev) if self._want_scores else None
 
     def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None,
                 tail: Optional[torch.Tensor] = None, have_stats: bool = False) -> None:
@@ -144,6 +155,38 @@ class CompressPlan:
             _raise_status(status, self.cap, K)
         rows = self.rows[:K + self.tail_rows] if self.rows is not None else None      # (kept rows, then the tail)
         return CompressionResult(rows, self.idx[:K], self.ks, int(K), self.v, self.f)
+
+
+# ---- plan cache of the one-shot API --------------------------------------------------------------------------
+# `compress()` / `vidcom2_compression()` / the model hooks run one pass per call; building a CompressPlan (a ~30 MB
+# workspace, status words) costs more than a quarter of the pass.  Plans are therefore kept per (shape, dtype, device,
+# options, HIP stream, thread): work enqueued on ONE stream is ordered, so re-using a plan's workspace there is safe;
+# another stream or thread gets its own plan.  Outputs are NOT cached (CompressPlan.new_outputs).
+_PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
+_PLAN_CACHE_MAX = int(os.environ.get("VC2_PLAN_CACHE", "8"))       # 0 disables the cache
+
+
+def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores, gather, tail_rows) -> "CompressPlan":
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    key = (F, N, D, dtype, device, float(base_scale), mapper, int(grid_h), bool(want_scores), bool(gather),
+           int(tail_rows), torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), _ffi.get_mode())
+    plan = _PLAN_CACHE.get(key) if _PLAN_CACHE_MAX > 0 else None
+    if plan is None:
+        plan = CompressPlan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores, gather, tail_rows)
+        if _PLAN_CACHE_MAX > 0:
+            _PLAN_CACHE[key] = plan
+            while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+                _PLAN_CACHE.popitem(last=False)
+    else:
+        _PLAN_CACHE.move_to_end(key)
+        plan.new_outputs()
+    return plan
+
+
+def clear_plan_cache() -> None:
+    _PLAN_CACHE.clear()
 
 
 def _raise_status(status: int, cap: int, K: int) -> None:
@@ -195,8 +238,12 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
     if stats_ws is not None and (x.data_ptr() != flattened_feat.data_ptr()
                                  or stats_ws.numel() < _ffi.workspace_bytes(R // tpf, tpf, D, x.dtype)):
         stats_ws = None                                   # a copy was made / another shape: the statistics are not its
-    plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather,
-                        tail_rows=0 if tail is None else tail.shape[0], ws=stats_ws)
+    ntail = 0 if tail is None else tail.shape[0]
+    if stats_ws is not None:          # (the statistics live in the caller's workspace: a plan around it, not cached)
+        plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather,
+                            tail_rows=ntail, ws=stats_ws)
+    else:
+        plan = _cached_plan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather, ntail)
     plan.enqueue(x, src, tail, have_stats=stats_ws is not None)
     return plan.finish()
 
@@ -226,7 +273,8 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2
             with torch.cuda.stream(ps):
                 results[j] = pl.finish()
         with torch.cuda.stream(st):       # the plan's buffers are allocated (and owned) on the lane's stream
-            plan = CompressPlan(x.shape[0] // int(tpf), int(tpf), x.shape[1], x.dtype, dev, base_scale, gather=gather)
+            plan = _cached_plan(x.shape[0] // int(tpf), int(tpf), x.shape[1], x.dtype, dev, base_scale, "linear", 0,
+                                False, gather, 0)
             plan.enqueue(x)
         pending.append((i, plan, st))
     for j, pl, ps in pending:
