@@ -53,9 +53,13 @@ const char* vc2_version(void);
  *                variance-sorted channels / cascade sum / outer-sum cascade over the rows) is replayed for that
  *                token or centre element -> bit-exact to the CPU reference;
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
- * fp32 inputs are unaffected.  The setting is per calling thread (default 1): concurrent callers cannot change each
- * other's mode; a worker thread that wants another mode sets it itself. */
+ * fp32 inputs are unaffected.  vc2_set_mode is PROCESS-WIDE (default 1) and also drops the calling thread's own
+ * override; vc2_set_thread_mode(mode) overrides it for the calling thread only (-1: follow the process-wide setting
+ * again), so that a worker thread follows the application's choice unless it asks otherwise; vc2_get_mode returns
+ * what a pass issued by the calling thread would use.  (All ranks / threads of a frame-sharded pass must use the
+ * same mode: it decides which exchanges take place.) */
 int vc2_set_mode(int mode);
+int vc2_set_thread_mode(int mode);
 int vc2_get_mode(void);
 /* Workspace (bytes) needed by any entry point below for an [F*N, D] input. */
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes);
@@ -181,14 +185,17 @@ int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, 
  * vc2_keep_positions (models/qwen2_5_vl.py:153-160): keep_out = ascending positions s in [0, S) with
  * !video_mask[s] or (ordinal of s among the video positions) in kept[0..K) (ascending); K = min(K_dev[0], K_max) or
  * K_max; vis_rows_out (optional, needs visual_mask) = ordinals, among the positions flagged in visual_mask, of the
- * kept ones; counts_out (optional, device int64[2]) = {len(keep_out), len(vis_rows_out)}. */
+ * kept ones.  keep_cap / vis_cap = entries the two outputs hold: nothing is written past them.  counts_out (optional,
+ * device int64[3]) = {positions found, visual rows found, error bits}: 1 = more positions than keep_cap, 2 = more
+ * visual rows than vis_cap, 4 = kept[] not strictly ascending inside [0, video positions), 8 = fewer positions than
+ * keep_cap (the rest of keep_out is then filled with -1, which vc2_gather_scatter reports instead of reading). */
 int vc2_gather_scatter(const void* const* srcs, const int64_t* src_rows, void* const* dsts, const int64_t* dst_rows,
                        int n_src, int64_t D, int dtype, const int64_t* idx, const int64_t* n_dev, int64_t n_max,
                        const int64_t* dst_pos, int64_t dst_row0, const void* tail, int64_t tail_rows,
                        int32_t* status, void* stream);
-int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept, const int64_t* K_dev,
-                       int64_t K_max, const uint8_t* visual_mask, int64_t* keep_out, int64_t* vis_rows_out,
-                       int64_t* counts_out, void* stream);
+int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept, const int64_t* K_dev, int64_t K_max,
+                       const uint8_t* visual_mask, int64_t* keep_out, int64_t keep_cap, int64_t* vis_rows_out,
+                       int64_t vis_cap, int64_t* counts_out, void* stream);
 
 /* ---- frame-sharded multi-GPU building blocks -------------------------
  * A rank holds frames [f0, f0+F_local) of a video with F_total frames.  Between the local sweeps the Python

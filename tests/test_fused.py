@@ -3,6 +3,7 @@
 models/qwen3_vl.py:140-165).  Pure copies and index arithmetic: bit-exact."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 from vidcom2_amd import synth
 
@@ -78,6 +79,33 @@ def test_keep_positions_matches_torch(S, seed):
     assert torch.equal(keep.cpu(), want_keep) and torch.equal(rows.cpu(), want_rows)
     keep2, rows2 = keep_positions(vm.cuda()[None], kept.cuda())                  # counts taken on the device
     assert torch.equal(keep2.cpu(), want_keep) and rows2 is None
+
+
+def test_keep_positions_and_gather_report_bad_indices():
+    """What the fused ops replace raises on a bad index (torch indexing); so do they: the kernels never write past
+    the buffers they were given and the host raises instead of handing out uninitialised rows."""
+    from vidcom2_amd.fused import gather_scatter, keep_positions
+    vm = (torch.arange(200) % 3 != 0).cuda()                        # 133 video positions
+    n_video = int(vm.sum())
+    kept = torch.arange(0, 40, 2).cuda()
+    keep, _ = keep_positions(vm, kept, n_video)                     # sound call
+    assert keep.numel() == 200 - n_video + 20 and int(keep.min()) >= 0
+    with pytest.raises(IndexError, match="video positions"):
+        keep_positions(vm, kept, n_video + 7)                        # the caller's count is too large ...
+    with pytest.raises(IndexError, match="video positions"):
+        keep_positions(vm, kept, n_video - 5)                        # ... or too small: nothing is written past keep
+    with pytest.raises(IndexError, match="ascending"):
+        keep_positions(vm, torch.tensor([3, 3, 9]).cuda(), n_video)  # duplicates
+    with pytest.raises(IndexError, match="ascending"):
+        keep_positions(vm, torch.tensor([9, 3]).cuda(), n_video)     # unsorted
+    with pytest.raises(IndexError, match="ascending"):
+        keep_positions(vm, torch.tensor([5, n_video]).cuda(), n_video)   # ordinal out of range
+    src = _rand(50, 32, torch.bfloat16, 4)
+    with pytest.raises(IndexError, match="out of range"):
+        gather_scatter([src], torch.tensor([0, 50, 3]).cuda(), check=True)
+    st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gather_scatter([src], torch.tensor([0, -1, 3]).cuda(), status=st)   # caller-owned status word: reported there
+    assert int(st.item()) & 2
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
@@ -213,3 +241,19 @@ def test_llava_hook_with_fused_pooling_equals_unfused(newline, side, mode, monke
         assert side // 2 == 13
     fused, plain = run(""), run("off")
     assert fused.shape == plain.shape and torch.equal(fused, plain)
+
+
+def test_pool_stats_bilinear_refuses_grids_torch_pools_with_another_kernel():
+    """Pinned torch behaviour (2.10, x86): an NCHW-contiguous input goes through the vectorised channels-last bilinear
+    kernel -- whose association vc2_pool_stats reproduces -- only while out_h + out_w <= 128."""
+    from vidcom2_amd.fused import pool_stats
+    a = torch.randn(1, 16, 127, 127)
+    same = F.interpolate(a, size=[64, 64], mode="bilinear")
+    assert torch.equal(same, F.interpolate(a.contiguous(memory_format=torch.channels_last), size=[64, 64], mode="bilinear"))
+    b = torch.randn(1, 16, 129, 129)
+    assert not torch.equal(F.interpolate(b, size=[65, 65], mode="bilinear"),
+                           F.interpolate(b.contiguous(memory_format=torch.channels_last), size=[65, 65], mode="bilinear"))
+    x = torch.zeros(1, 129 * 129, 16, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(NotImplementedError, match="128"):
+        pool_stats(x, 129, 129, "bilinear")
+    pool_stats(x, 129, 129, "average")                                # (the other modes have no such switch)

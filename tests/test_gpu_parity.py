@@ -470,3 +470,31 @@ def test_plan_cache_returns_independent_results():
         rd = V.compress(xa, 49, 0.25)
     torch.cuda.synchronize()
     assert len(V._PLAN_CACHE) == 2 and torch.equal(rd.global_idx, idx_a)
+
+
+@pytest.mark.gpu
+def test_mode_is_process_wide_with_a_per_thread_override():
+    """vc2_set_mode applies to passes issued from ANY thread (HF generate streams from a worker thread);
+    vc2_set_thread_mode overrides it for one thread without disturbing the others."""
+    import threading
+    seen = {}
+
+    def worker(name, override):
+        if override is not None:
+            _ffi.set_thread_mode(override)
+        seen[name] = _ffi.get_mode()
+
+    try:
+        _ffi.set_mode("exact")
+        t = threading.Thread(target=worker, args=("follows", None)); t.start(); t.join()
+        t = threading.Thread(target=worker, args=("own", "torch")); t.start(); t.join()
+        assert seen == {"follows": "exact", "own": "torch"} and _ffi.get_mode() == "exact"
+        _ffi.set_thread_mode("torch")
+        assert _ffi.get_mode() == "torch"
+        t = threading.Thread(target=worker, args=("other", None)); t.start(); t.join()
+        assert seen["other"] == "exact"                              # this thread's override is its own
+        _ffi.set_mode("torch")                                       # process-wide; drops the caller's override
+        assert _ffi.get_mode() == "torch"
+    finally:
+        _ffi.set_mode("torch")
+        _ffi.set_thread_mode(None)

@@ -42,7 +42,7 @@ _SIGNATURES = {
     "vc2_pool_out_tokens": [_i64, _i64, _i32, _vp, _vp],
     "vc2_pool_stats": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _vp],
     "vc2_gather_scatter": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
-    "vc2_keep_positions": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
+    "vc2_keep_positions": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp],
     "vc2_stat_block_frames": [],
     "vc2_chan_stats": [_vp, _i64, _i64, _i64, _i32, _i64, _i32, _vp, _sz, _vp, _vp],
     "vc2_chan_var_from_stats": [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp],
@@ -59,6 +59,7 @@ _SIGNATURES = {
     "vc2_kat_exp": [_vp, _i64, _i32, _vp, _vp],
     "vc2_kat_round": [_vp, _i64, _i32, _vp, _vp],
     "vc2_set_mode": [_i32],
+    "vc2_set_thread_mode": [_i32],
     "vc2_get_mode": [],
     "vc2_profile_enable": [_i32],
     "vc2_profile_collect": [_i32, _vp, _vp, _vp],
@@ -159,6 +160,11 @@ def set_mode(mode: str) -> None:
     """'torch' (default): bit-exact to the CPU reference in half precision (replays torch's fp32 accumulation
     order where it decides a rounding); 'exact': every reduction correctly rounded."""
     check(lib().vc2_set_mode({"exact": 0, "torch": 1}[mode]), "vc2_set_mode")
+
+
+def set_thread_mode(mode: Optional[str]) -> None:
+    """Override the process-wide mode for the calling thread only; None: follow the process-wide setting again."""
+    check(lib().vc2_set_thread_mode({None: -1, "exact": 0, "torch": 1}[mode]), "vc2_set_thread_mode")
 
 
 def get_mode() -> str:

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2222,13 +2223,15 @@ __global__ __launch_bounds__(kKeepNT) void k_keep_positions(const uint8_t* __res
                                                             const int64_t* __restrict__ kept,
                                                             const int64_t* __restrict__ K_dev, int64_t K_max,
                                                             const uint8_t* __restrict__ visual_mask,
-                                                            int64_t* __restrict__ keep_out,
-                                                            int64_t* __restrict__ vis_rows_out,
+                                                            int64_t* __restrict__ keep_out, int64_t keep_cap,
+                                                            int64_t* __restrict__ vis_rows_out, int64_t vis_cap,
                                                             int64_t* __restrict__ counts_out) {
   __shared__ uint32_t xch[16];
+  __shared__ int err_s;
   constexpr int NW = kKeepNT / 64;
   const int tid = threadIdx.x;
   const int64_t K = K_dev ? min(K_dev[0], K_max) : K_max;
+  if (tid == 0) err_s = 0;
   const int64_t E = (S + kKeepNT - 1) / kKeepNT;
   const int64_t b = min(S, tid * E), e = min(S, b + E);
   uint32_t nv = 0;
@@ -2236,6 +2239,14 @@ __global__ __launch_bounds__(kKeepNT) void k_keep_positions(const uint8_t* __res
   uint32_t tot;
   const int64_t ord0 = block_excl_scan<NW>(nv, xch, tot);        // video ordinal of my first video token
   __syncthreads();
+  {   // kept[] must be strictly ascending ordinals of video positions: anything else would leave holes in keep_out
+    int bad = 0;
+    for (int64_t i = tid; i < K; i += kKeepNT) {
+      const int64_t v = kept[i];
+      if (v < 0 || v >= int64_t(tot) || (i + 1 < K && kept[i + 1] <= v)) bad = 1;
+    }
+    if (bad) atomicOr(&err_s, 4);
+  }
   int64_t q;                                                     // first entry of kept[] that is >= ord0
   { int64_t lo = 0, hi = K; while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (kept[m] < ord0) lo = m + 1; else hi = m; } q = lo; }
   // pass 1: how many positions / visual rows do I keep, how many visual positions precede mine
@@ -2256,14 +2267,23 @@ __global__ __launch_bounds__(kKeepNT) void k_keep_positions(const uint8_t* __res
   __syncthreads();
   const int64_t vk0 = block_excl_scan<NW>(nvk, xch, tot);
   const uint32_t tot_vk = tot;
-  if (tid == 0 && counts_out) { counts_out[0] = tot_k; counts_out[1] = tot_vk; }
+  __syncthreads();
+  if (tid == 0 && counts_out) {
+    // counts_out[2]: 1 = more kept positions than keep_cap, 2 = more visual rows than vis_cap (neither is written
+    // past its capacity), 4 = kept[] not strictly ascending inside [0, video positions), 8 = fewer positions than
+    // keep_cap (the caller's count of video positions was wrong: the rest of keep_out is filled with -1)
+    counts_out[0] = tot_k; counts_out[1] = tot_vk;
+    counts_out[2] = err_s | (int64_t(tot_k) > keep_cap ? 1 : 0) | ((vis_rows_out && int64_t(tot_vk) > vis_cap) ? 2 : 0) |
+                    ((keep_out && int64_t(tot_k) < keep_cap) ? 8 : 0);
+  }
+  if (keep_out) for (int64_t i = int64_t(tot_k) + tid; i < keep_cap; i += kKeepNT) keep_out[i] = -1;
   {
     int64_t o = ord0, qq = q, kk = k0, vv = v0, vk = vk0;
     for (int64_t p = b; p < e; ++p) {
       bool keep = true;
       if (video_mask[p]) { while (qq < K && kept[qq] < o) ++qq; keep = qq < K && kept[qq] == o; ++o; }
-      if (keep && keep_out) keep_out[kk++] = p;
-      if (visual_mask && visual_mask[p]) { if (keep && vis_rows_out) vis_rows_out[vk++] = vv; ++vv; }
+      if (keep && keep_out) { if (kk < keep_cap) keep_out[kk] = p; ++kk; }
+      if (visual_mask && visual_mask[p]) { if (keep && vis_rows_out) { if (vk < vis_cap) vis_rows_out[vk] = vv; ++vk; } ++vv; }
     }
   }
 }
@@ -2301,7 +2321,12 @@ struct Plan {
 
 // 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
 // result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
-thread_local int g_strict = 1;      // per calling thread (vc2_set_mode): concurrent callers cannot change each other's mode
+// A process-wide setting (vc2_set_mode) that a thread may override for itself (vc2_set_thread_mode): a pass issued from
+// a worker thread (HF generate's streaming thread) follows what the application set, and two threads that need
+// different modes cannot disturb each other.
+std::atomic<int> g_mode_default{1};
+thread_local int g_mode_thread = -1;             // -1: follow the process-wide setting
+inline int cur_mode() { return g_mode_thread >= 0 ? g_mode_thread : g_mode_default.load(std::memory_order_relaxed); }
 
 int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total = 0, int block_frames = 0) {
   if (F <= 0 || N <= 0 || D <= 0) return fail(VC2_ERR_ARG, "F, N, D must be positive (got %lld, %lld, %lld)",
@@ -2329,7 +2354,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   // workgroup lives for the whole sweep.  The ORDER riders ("torch order" mode, 16-bit inputs) are workgroups of the
   // same launch, so the splits are chosen to leave them slots -- with 512 + 16 workgroups the last 16 start when the
   // riders end and the sweep takes 51 instead of 36 us; with 384 + 16 it takes 41.
-  const int64_t riders = (g_strict && dt != VC2_F32) ? VC2_RIDER_PARTS : 0;
+  const int64_t riders = (cur_mode() && dt != VC2_F32) ? VC2_RIDER_PARTS : 0;
   // S is chosen from THIS rank's frames (occupancy), not from the whole video's: the frame sums are fp64 sums of
   // T-rounded x^ in [-1, 1] -- exact (so independent of how the rows are cut) for fp16 by range (2^-24 .. 1, <= 8192
   // rows: 48 bits), and for bf16 unless a nonzero |x^| < 2^-39 meets a frame sum > 2^6
@@ -2534,7 +2559,7 @@ struct ChanSet {
 };
 inline ChanSet make_chanset(const Plan& p, const int* cols, const int* spos, int64_t C) {
   ChanSet cs{cols, spos, int(C), 0};
-  cs.strict = (g_strict && p.ES == 2 && (cols == nullptr || spos)) ? g_strict : 0;   // 2 = replay always
+  cs.strict = (cur_mode() && p.ES == 2 && (cols == nullptr || spos)) ? cur_mode() : 0;   // 2 = replay always
   return cs;
 }
 
@@ -2748,10 +2773,16 @@ const char* vc2_version(void) { return "vidcom2_amd 0.1 (gfx950)"; }
 
 int vc2_set_mode(int mode) {
   if (mode < 0 || mode > 3) return fail(VC2_ERR_ARG, "mode must be 0 (exact) or 1 (torch order)");   // 2, 3: debug
-  g_strict = mode;
+  g_mode_default.store(mode, std::memory_order_relaxed);
+  g_mode_thread = -1;                               // (the caller sees what it just set)
   return VC2_OK;
 }
-int vc2_get_mode(void) { return g_strict; }
+int vc2_set_thread_mode(int mode) {
+  if (mode < -1 || mode > 3) return fail(VC2_ERR_ARG, "mode must be -1 (follow the process), 0 (exact) or 1 (torch order)");
+  g_mode_thread = mode;
+  return VC2_OK;
+}
+int vc2_get_mode(void) { return cur_mode(); }
 
 int vc2_workspace_bytes(int64_t F, int64_t N, int64_t D, int dtype, size_t* out_bytes) {
   if (!out_bytes) return fail(VC2_ERR_ARG, "out_bytes is null");
@@ -3019,6 +3050,12 @@ int vc2_pool_stats(const void* xin, int64_t F, int64_t H, int64_t W, int64_t D, 
   if (mode == VC2_POOL_BILINEAR && D % (dtype == VC2_F32 ? 8 : 16) != 0)
     return fail(VC2_ERR_UNSUPPORTED, "bilinear pooling: D=%lld is not a multiple of torch's vector width (%d)",
                 (long long)D, dtype == VC2_F32 ? 8 : 16);
+  // ATen hands an NCHW-contiguous input (what get_2dPool builds) to the vectorised channels-last kernel -- the one whose
+  // association is reproduced here -- only while out_h + out_w <= 128 (UpSampleKernel.cpp
+  // _use_vectorized_kernel_cond_2d); larger grids take upsample_generic_Nd, which adds in another order
+  if (mode == VC2_POOL_BILINEAR && h + w > 128)
+    return fail(VC2_ERR_UNSUPPORTED, "bilinear pooling to %lld x %lld: torch switches kernels (and summation order) "
+                "beyond out_h + out_w = 128", (long long)h, (long long)w);
   Plan p;
   if ((rc = make_plan(F, h * w, D, dtype, &p))) return rc;
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
@@ -3047,13 +3084,14 @@ int vc2_gather_scatter(const void* const* srcs, const int64_t* src_rows, void* c
 }
 
 int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept, const int64_t* K_dev, int64_t K_max,
-                       const uint8_t* visual_mask, int64_t* keep_out, int64_t* vis_rows_out, int64_t* counts_out,
-                       void* stream) {
-  if (!video_mask || S <= 0 || K_max < 0 || (K_max > 0 && !kept))      // (keep_out may be null when nothing is kept)
-    return fail(VC2_ERR_ARG, "bad keep_positions arguments");
+                       const uint8_t* visual_mask, int64_t* keep_out, int64_t keep_cap, int64_t* vis_rows_out,
+                       int64_t vis_cap, int64_t* counts_out, void* stream) {
+  if (!video_mask || S <= 0 || K_max < 0 || (K_max > 0 && !kept) || keep_cap < 0 || vis_cap < 0)
+    return fail(VC2_ERR_ARG, "bad keep_positions arguments");          // (keep_out may be null when nothing is kept)
   if (S > (int64_t(1) << 31) - 1) return fail(VC2_ERR_UNSUPPORTED, "S=%lld positions", (long long)S);
   hipLaunchKernelGGL(k_keep_positions, dim3(1), dim3(kKeepNT), 0, static_cast<hipStream_t>(stream), video_mask, S, kept,
-                     K_dev, K_max, visual_mask, keep_out, vis_rows_out, counts_out);
+                     K_dev, K_max, visual_mask, keep_out, keep_out ? keep_cap : 0, vis_rows_out,
+                     vis_rows_out ? vis_cap : 0, counts_out);
   return check_launch("keep_positions");
 }
 
@@ -3093,7 +3131,7 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
                               /*have_partials=*/(flags & VC2_FLAG_HAVE_STATS) != 0)))
     return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
-  const bool strict = g_strict && p.ES == 2;
+  const bool strict = cur_mode() && p.ES == 2;
   int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;
   int* perm = strict ? wsp<int>(ws, p.o_perm) : nullptr;
   // (wperm / wcpos live in the o_tmp_f32 scratch, free until the selection stage: 2 * kc words <= R or D floats)
@@ -3183,14 +3221,14 @@ int vc2_multi_scale_gaussian(const void* x, int64_t F, int64_t N, int64_t C, int
   for (int i = 0; i < n_alphas; ++i) al.two_a[i] = float(2.0 * alphas[i]);   // python: -d / (2 * a), scalar -> fp32
   const int64_t R = F * N;
   const unsigned grid = unsigned(std::min<int64_t>(cdiv(R, kMsgWaves), 65535 * 16));
-  const size_t smem = g_strict ? size_t(kMsgWaves) * size_t(C) * 4 : 0;
+  const size_t smem = cur_mode() ? size_t(kMsgWaves) * size_t(C) * 4 : 0;
   VC2_DISPATCH_DT(dtype, {
     if (smem > 48 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_multi_scale_gaussian<DT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, int(smem));
     hipLaunchKernelGGL((k_multi_scale_gaussian<DT>), dim3(grid), dim3(kMsgWaves * 64), smem,
                        static_cast<hipStream_t>(stream), x, R, int(C), centre, n_centres == 1 ? 0 : 1, int(N), al,
-                       g_strict ? 1 : 0, out_T);
+                       cur_mode() ? 1 : 0, out_T);
   });
   return check_launch("multi_scale_gaussian");
 }

@@ -23,6 +23,8 @@ import torch
 
 from ._ffi import DTYPE_CODE, check, lib, on_device, ptr, require_device, stream_ptr
 
+_check_rc = check          # (gather_scatter has a keyword argument named `check`)
+
 __all__ = ["gather_scatter", "keep_positions", "pool_stats", "POOL_MODES"]
 
 MAX_SOURCES = 8
@@ -39,12 +41,16 @@ def _i64_array(vs: Sequence[int]):
 def gather_scatter(srcs: Sequence[torch.Tensor], idx: Optional[torch.Tensor] = None, n: Optional[int] = None,
                    n_dev: Optional[torch.Tensor] = None, dst_pos: Optional[torch.Tensor] = None,
                    dsts: Optional[Sequence[torch.Tensor]] = None, dst_row0: int = 0,
-                   tail: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+                   tail: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
+                   check: bool = False) -> List[torch.Tensor]:
     """dsts[t][dst_pos[j] or dst_row0 + j] = srcs[t][idx[j] or j] for j < n, every tensor in ONE launch; `tail`
     rows ([m, D]) are appended to dsts[0] behind the gathered ones.
 
     srcs: 2-D tensors [rows_t, D] of one dtype / feature size.  n defaults to len(idx) (or rows of srcs[0]); n_dev
     (device int64[1]) caps it on the device.  dsts default to fresh [n + m, D] (first) / [n, D] tensors.
+    A row index outside its tensor is skipped on the device and reported: in `status` (device int32[1], bit 1) when
+    the caller passes one, and -- check=True, what the hooks use -- by an IndexError after one small read-back, like
+    the torch indexing this replaces (an unreported skip would leave an uninitialised row in a fresh destination).
     """
     srcs = list(srcs)
     if not 1 <= len(srcs) <= MAX_SOURCES:
@@ -92,12 +98,16 @@ def gather_scatter(srcs: Sequence[torch.Tensor], idx: Optional[torch.Tensor] = N
         for i, d in enumerate(dsts):
             if d.dim() != 2 or d.shape[1] != D or d.dtype != x0.dtype or d.device != x0.device or not d.is_contiguous():
                 raise RuntimeError(f"dsts[{i}] must be a contiguous [rows, {D}] {x0.dtype} tensor on {x0.device}")
+    if check and status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=x0.device)
     with on_device(x0.device):
         rc = lib().vc2_gather_scatter(_ptr_array(srcs), _i64_array([s.shape[0] for s in srcs]), _ptr_array(dsts),
                                       _i64_array([d.shape[0] for d in dsts]), len(srcs), D, DTYPE_CODE[x0.dtype],
                                       ptr(idx), ptr(n_dev), n, ptr(dst_pos), int(dst_row0), ptr(tail), m, ptr(status),
                                       stream_ptr(x0.device))
-    check(rc, "vc2_gather_scatter")
+    _check_rc(rc, "vc2_gather_scatter")
+    if check and int(status.item()) & 2:
+        raise IndexError("gather_scatter: a row index is out of range for its source or destination tensor")
     return dsts
 
 
@@ -118,6 +128,8 @@ def keep_positions(video_mask: torch.Tensor, kept: torch.Tensor, n_video: Option
     if n_video is None:
         n_video = int(vm.sum().item())
     n_keep = S - int(n_video) + K
+    if n_keep < 0 or int(n_video) < K:
+        raise IndexError(f"keep_positions: {K} kept ordinals for {n_video} video positions among {S}")
     keep = torch.empty(n_keep, dtype=torch.int64, device=vm.device)
     vis = vis_rows = None
     if visual_mask is not None:
@@ -126,15 +138,28 @@ def keep_positions(video_mask: torch.Tensor, kept: torch.Tensor, n_video: Option
         if vis.numel() != S or vis.device != vm.device:
             raise RuntimeError("visual_mask must cover the same positions as video_mask")
         vis_rows = torch.empty(S, dtype=torch.int64, device=vm.device)
-    counts = torch.empty(2, dtype=torch.int64, device=vm.device)
+    counts = torch.empty(3, dtype=torch.int64, device=vm.device)
     with on_device(vm.device):
-        rc = lib().vc2_keep_positions(ptr(vm), S, ptr(kept), None, K, ptr(vis), ptr(keep), ptr(vis_rows), ptr(counts),
-                                      stream_ptr(vm.device))
+        rc = lib().vc2_keep_positions(ptr(vm), S, ptr(kept), None, K, ptr(vis), ptr(keep), n_keep, ptr(vis_rows),
+                                      S if vis_rows is not None else 0, ptr(counts), stream_ptr(vm.device))
     check(rc, "vc2_keep_positions")
+    # One small read-back (the kernel is a single workgroup): what the index lists are worth.  torch indexing -- what
+    # this replaces -- raises on a bad index; an unchecked list would gather rows from wherever it points.
+    found, found_vis, err = (int(v) for v in counts.tolist())
+    if err:
+        why = []
+        if err & 1 or err & 8:
+            why.append(f"video_mask holds {S - (found - K)} video positions, the caller said {n_video}")
+        if err & 4:
+            why.append("kept must be strictly ascending ordinals of video positions")
+        if err & 2:
+            why.append("more visual rows than positions")
+        raise IndexError("keep_positions: " + "; ".join(why))
     if vis_rows is not None:
         # video tokens are visual tokens: the kept visual rows are the non-video visual ones plus the K kept
-        n_rows = int(counts[1].item()) if n_visual is None else int(n_visual) - int(n_video) + K
-        vis_rows = vis_rows[:n_rows]
+        if n_visual is not None and int(n_visual) - int(n_video) + K != found_vis:
+            raise IndexError(f"keep_positions: visual_mask flags {found_vis + int(n_video) - K} positions, the caller said {n_visual}")
+        vis_rows = vis_rows[:found_vis]
     return keep, vis_rows
 
 
@@ -171,4 +196,7 @@ def pool_stats(image_feature: torch.Tensor, height: int, width: int, mode: str =
         rc = lib().vc2_pool_stats(ptr(x), F, int(height), int(width), D, DTYPE_CODE[x.dtype], POOL_MODES[mode], ptr(ws),
                                   ws.numel(), ptr(out), stream_ptr(x.device))
     check(rc, "vc2_pool_stats")
+    # the partials' layout depends on (frames, tokens per frame): the workspace says what it was written for, and
+    # `compress` / `CompressPlan.enqueue(have_stats=True)` use the statistics only for exactly that tensor and shape
+    ws._vc2_stats_for = (int(F), int(n), int(D), x.dtype, out.data_ptr())
     return out, ws

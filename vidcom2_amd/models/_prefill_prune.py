@@ -92,7 +92,7 @@ class _LanguageModelShim:
                     keep, vis_rows = keep_positions(vm, kept, n_video, vpm[0].to(embeds.device) if want_vis else None,
                                                     int(deep[0].shape[0]) if want_vis else None)
                     keep_flags = None
-                    kwargs["inputs_embeds"] = gather_scatter([embeds[0]], keep)[0][None]
+                    kwargs["inputs_embeds"] = gather_scatter([embeds[0]], keep, check=True)[0][None]
                 else:
                     video_pos = vm.nonzero(as_tuple=False).squeeze(-1)
                     keep_flags = ~vm
@@ -130,7 +130,7 @@ class _LanguageModelShim:
                 if torch.is_tensor(vpm):
                     if vis_rows is not None:
                         # the deep-stack tensors share ONE index list: one launch for all of them
-                        kwargs["deepstack_visual_embeds"] = gather_scatter(list(deep), vis_rows)
+                        kwargs["deepstack_visual_embeds"] = gather_scatter(list(deep), vis_rows, check=True)
                     else:
                         if keep_flags is None:
                             keep_flags = torch.zeros(vm.numel(), dtype=torch.bool, device=keep.device)

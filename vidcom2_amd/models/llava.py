@@ -90,7 +90,8 @@ class _PooledWithStats(torch.Tensor):
 def _fused_pool(model, pool_inner, image_feature, args, kwargs):
     """get_2dPool + sweep 1 in one kernel when the configuration allows a bit-identical pooled tensor (average / max
     / bilinear with a feature size that is a multiple of torch's vector width).  None: not applicable.
-    VC2_FUSED_POOL=off keeps the model's own pooling."""
+    VC2_FUSED_POOL=off keeps the model's own pooling (the fused one reproduces torch's x86 CPU bits, which differ
+    by rounding from what the model's pooling computes on the GPU)."""
     import os
     stride = args[0] if args else kwargs.get("stride", 2)
     mode = getattr(model.config, "mm_spatial_pool_mode", None)
@@ -110,6 +111,8 @@ def _fused_pool(model, pool_inner, image_feature, args, kwargs):
         return None
     if side * side != image_feature.shape[1]:
         return None
+    if mode == "bilinear" and 2 * ((side + 1) // 2) > 128:
+        return None          # torch's other bilinear kernel (out_h + out_w > 128): another summation order
     from ..fused import pool_stats
     out, ws = pool_stats(image_feature, side, side, mode)
     return out, ws

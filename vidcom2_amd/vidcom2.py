@@ -135,6 +135,11 @@ class CompressPlan:
         """have_stats: `self.ws` already holds flat's sweep-1 partials (fused.pool_stats wrote them on this
         stream), so the pass starts at the variance reduction."""
         src = flat if gather_src is None else gather_src
+        if have_stats:
+            tag = getattr(self.ws, "_vc2_stats_for", None)
+            if tag is not None and tag != (self.F, self.N, self.D, self.dtype, flat.data_ptr()):
+                raise RuntimeError(f"have_stats: the workspace holds the statistics of a {tag[:4]} tensor, not of this "
+                                   f"({self.F}, {self.N}, {self.D}, {self.dtype}) one")
         if self.tail_rows:
             if tail is None or tail.shape != (self.tail_rows, self.D) or tail.dtype != self.dtype \
                     or tail.device != self.device:
@@ -235,9 +240,11 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
                              if src.dim() == 2 else "img_feat must be 2-D [rows, dim]")
     if tail is not None:
         tail = _prep(tail if tail.dim() == 2 else tail[None], "tail")
-    if stats_ws is not None and (x.data_ptr() != flattened_feat.data_ptr()
+    if stats_ws is not None and (getattr(stats_ws, "_vc2_stats_for", None) != (R // tpf, tpf, D, x.dtype, x.data_ptr())
                                  or stats_ws.numel() < _ffi.workspace_bytes(R // tpf, tpf, D, x.dtype)):
-        stats_ws = None                                   # a copy was made / another shape: the statistics are not its
+        # another tensor (a copy was made), another (frames, tokens per frame) split -- e.g. a tpf that is not the
+        # pooled grid -- or a workspace of unknown origin: its partials are not this call's, sweep 1 runs again
+        stats_ws = None
     ntail = 0 if tail is None else tail.shape[0]
     if stats_ws is not None:          # (the statistics live in the caller's workspace: a plan around it, not cached)
         plan = CompressPlan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather,
