@@ -501,6 +501,28 @@ def main():
         res["pool_alg_GBs"] = round(res["pool_alg_bytes"] / (res["pool_stats_kernel_only_us"] * 1e-6) / 1e9, 1)
         out["llava_pool_fused"] = res
         del xin, pl_a
+    # ---- side: the fused hook operations at a Qwen2.5-VL-7B prefill shape: 64 frames x 324 video tokens + 96 text
+    #      tokens, 3584-d bf16, 12.5 % of the video kept -- the keep-list construction (vc2_keep_positions, one
+    #      workgroup) and the ONE launch that writes text rows + kept video rows (vc2_gather_scatter) ------------
+    if extra and args.workload == "target":
+        from vidcom2_amd.fused import gather_scatter, keep_positions
+        nvid, ntext = 64 * 324, 96
+        Sq = nvid + ntext
+        vm = torch.zeros(Sq, dtype=torch.bool, device=dev)
+        vm[32:32 + nvid] = True
+        kept = torch.arange(0, nvid, 8, device=dev, dtype=torch.int64)
+        emb = torch.randn(Sq, D, device=dev, dtype=torch.float32).to(dtype)
+        keep, _ = keep_positions(vm, kept, nvid)
+        st_word = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_keep = time_steps(lambda: keep_positions(vm, kept, nvid), 20, False) / 20
+        outb = gather_scatter([emb], keep, status=st_word)
+        t_gs = time_steps(lambda: gather_scatter([emb], keep, dsts=outb, status=st_word), 50, False) / 50
+        nbytes = 2 * keep.numel() * D * es + 8 * keep.numel()
+        out["hook_fused_ops"] = {"shape": f"{Sq} positions ({nvid} video, {kept.numel()} kept), {D}-d {DT_NAME[dtype]}",
+                                 "keep_positions_us_incl_readback": round(t_keep * 1e6, 1),
+                                 "gather_scatter_us": round(t_gs * 1e6, 1), "gather_scatter_bytes": nbytes,
+                                 "gather_scatter_GBs": round(nbytes / t_gs / 1e9, 1)}
+        del emb, outb
     # ---- side: two clips in flight, one stream each (serving / batched eval) --------------------------
     if extra and args.workload == "target":
         streams = [torch.cuda.current_stream(), torch.cuda.Stream()]

@@ -455,3 +455,23 @@ def test_qwen_hook_four_row_position_ids_and_cache_position(monkeypatch):
     assert got[0, 0].tolist() == list(range(keep.numel()))
     assert torch.equal(got[1:, 0], (pos3 * 2 + 1)[:, 0][:, keep])
     assert seen["cache_position"].tolist() == list(range(keep.numel()))
+
+
+def test_hook_signatures_are_the_references():
+    """inspect.signature(model.model.forward) on a hooked model shows the reference's explicit parameter lists
+    (token_compressor/vidcom2/models/qwen2_5_vl.py:36-55, qwen3_vl.py:36-48, qwen2_vl.py:46-64 without `labels`), not
+    (*args, **kwargs): HF generate's argument validation and tracing tools read them."""
+    import inspect
+    from vidcom2_amd.models import qwen2_5_vl, qwen2_vl, qwen3_vl
+    q25 = ["self", "input_ids", "attention_mask", "position_ids", "past_key_values", "inputs_embeds", "use_cache",
+           "output_attentions", "output_hidden_states", "return_dict", "pixel_values", "pixel_values_videos",
+           "image_grid_thw", "video_grid_thw", "rope_deltas", "cache_position", "second_per_grid_ts", "kwargs"]
+    q3 = ["self", "input_ids", "attention_mask", "position_ids", "past_key_values", "inputs_embeds", "pixel_values",
+          "pixel_values_videos", "image_grid_thw", "video_grid_thw", "cache_position", "kwargs"]
+    assert list(inspect.signature(qwen2_5_vl.Qwen2_5_VLModel_forward).parameters) == q25
+    assert list(inspect.signature(qwen3_vl.Qwen3VLModel_forward).parameters) == q3
+    assert list(inspect.signature(qwen2_vl.Qwen2VLModel_forward).parameters) == q25[:16] + ["kwargs"]
+    for fn in (qwen2_5_vl.Qwen2_5_VLModel_forward, qwen3_vl.Qwen3VLModel_forward, qwen2_vl.Qwen2VLModel_forward):
+        ps = inspect.signature(fn).parameters
+        assert all(p.default is None for n, p in ps.items() if n not in ("self", "kwargs"))
+        assert ps["kwargs"].kind is inspect.Parameter.VAR_KEYWORD

@@ -82,5 +82,47 @@ def hooked_forward(self, hook, args, kwargs, keep_fn_name: str = "_compute_keep_
     return run_with_pruning(self, lambda: original(*args, **kwargs), choose)
 
 
-def Qwen2_5_VLModel_forward(self, *args, **kwargs):
-    return hooked_forward(self, Qwen2_5_VLModel_forward, args, kwargs)
+def named_call_kwargs(self, hook, named: dict, extra: dict) -> dict:
+    """The hooks carry the reference's EXPLICIT parameter lists (inspect.signature consumers -- HF generate's argument
+    validation, tracing tools -- see the names they expect); the installed transformers' forward is then called by
+    NAME.  A reference-era parameter the installed forward no longer has (e.g. `return_dict`, `second_per_grid_ts`) is
+    dropped when it was left at None and passed through otherwise (the model's own TypeError is the right answer)."""
+    original = original_method(self, "forward", hook)
+    params = inspect.signature(original).parameters
+    open_kw = any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+    out = {k: v for k, v in named.items() if v is not None or k in params}
+    if not open_kw:
+        out = {k: v for k, v in out.items() if k in params or v is not None}
+    out.update(extra)
+    return out
+
+
+def Qwen2_5_VLModel_forward(
+    self,
+    input_ids=None,
+    attention_mask=None,
+    position_ids=None,
+    past_key_values=None,
+    inputs_embeds=None,
+    use_cache=None,
+    output_attentions=None,
+    output_hidden_states=None,
+    return_dict=None,
+    pixel_values=None,
+    pixel_values_videos=None,
+    image_grid_thw=None,
+    video_grid_thw=None,
+    rope_deltas=None,
+    cache_position=None,
+    second_per_grid_ts=None,
+    **kwargs,
+):
+    """Same parameter list as the reference's hook (models/qwen2_5_vl.py:36-55)."""
+    named = dict(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                 past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache,
+                 output_attentions=output_attentions, output_hidden_states=output_hidden_states, return_dict=return_dict,
+                 pixel_values=pixel_values, pixel_values_videos=pixel_values_videos, image_grid_thw=image_grid_thw,
+                 video_grid_thw=video_grid_thw, rope_deltas=rope_deltas, cache_position=cache_position,
+                 second_per_grid_ts=second_per_grid_ts)
+    return hooked_forward(self, Qwen2_5_VLModel_forward, (),
+                          named_call_kwargs(self, Qwen2_5_VLModel_forward, named, kwargs))

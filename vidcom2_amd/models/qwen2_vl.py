@@ -122,14 +122,36 @@ class _TowerShim:
         return out
 
 
-def Qwen2VLModel_forward(self, *args, **kwargs):
+def Qwen2VLModel_forward(
+    self,
+    input_ids=None,
+    attention_mask=None,
+    position_ids=None,
+    past_key_values=None,
+    inputs_embeds=None,
+    use_cache=None,
+    output_attentions=None,
+    output_hidden_states=None,
+    return_dict=None,
+    pixel_values=None,
+    pixel_values_videos=None,
+    image_grid_thw=None,
+    video_grid_thw=None,
+    rope_deltas=None,
+    cache_position=None,
+    **kwargs,
+):
+    """The parameter list of the reference's Qwen2-VL hook (models/qwen2_vl.py:46-64, there on the CausalLM and with
+    `labels`; this one sits on the inner model like the other Qwen hooks)."""
+    from .qwen2_5_vl import named_call_kwargs
     original = original_method(self, "forward", Qwen2VLModel_forward)
-    try:
-        bound = inspect.signature(original).bind_partial(*args, **kwargs).arguments
-    except TypeError:
-        bound = dict(kwargs)
-    video_grid_thw = bound.get("video_grid_thw")
-    if bound.get("pixel_values_videos") is None or video_grid_thw is None:
+    named = dict(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                 past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache,
+                 output_attentions=output_attentions, output_hidden_states=output_hidden_states, return_dict=return_dict,
+                 pixel_values=pixel_values, pixel_values_videos=pixel_values_videos, image_grid_thw=image_grid_thw,
+                 video_grid_thw=video_grid_thw, rope_deltas=rope_deltas, cache_position=cache_position)
+    args, kwargs = (), named_call_kwargs(self, Qwen2VLModel_forward, named, kwargs)
+    if pixel_values_videos is None or video_grid_thw is None:
         return original(*args, **kwargs)
     merge_size = int(getattr(self.visual, "spatial_merge_size", 2))
 
