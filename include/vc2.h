@@ -53,6 +53,10 @@ const char* vc2_version(void);
  *                variance-sorted channels / cascade sum / outer-sum cascade over the rows) is replayed for that
  *                token or centre element -> bit-exact to the CPU reference;
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
+ *   3            mode 1 with a PROVEN bound deciding which centre means are replayed (forward error bound of torch's
+ *                cascade relative to sum |x^|, bounded from sweep 1's statistics) instead of mode 1's empirical 16 ulps:
+ *                flags 50x more means, costs a third more time; the test-suite runs every fixture in both.
+ *   (2: debug -- every value is replayed.)
  * fp32 inputs are unaffected.  vc2_set_mode is PROCESS-WIDE (default 1) and also drops the calling thread's own
  * override; vc2_set_thread_mode(mode) overrides it for the calling thread only (-1: follow the process-wide setting
  * again), so that a worker thread follows the application's choice unless it asks otherwise; vc2_get_mode returns
@@ -204,7 +208,8 @@ int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept
  * folds in the same fixed order, so the reduced bits do not depend on the world size (ranks holding a multiple of 16
  * frames; otherwise equal up to fp64 rounding):
  *   1. per stat block (mean, M2)   bstats[nb][2][D], nb = F_local / block_frames     -> vc2_chan_var_from_stats
- *   2. per 16-frame group sums of x^   csum_parts[ceil(F_local/16)][C]                 -> vc2_scores_phase2
+ *   2. per 16-frame group: sums of x^, then bounds of sum |x^|   csum_parts[2 * ceil(F_local/16)][C]   -> vc2_scores_phase2
+ *      (the bounds size the video centre's replay margin soundly, see mean_delta in the kernels)
  *   3. per-frame uniqueness   s[F_local]                                               -> vc2_select_sharded
  * F_total (the WHOLE video's frame count) fixes how frames are cut into row groups / splits on every rank. */
 int vc2_stat_block_frames(void);     /* 8: the unsharded pass's stat block */
@@ -221,10 +226,13 @@ int vc2_chan_var_from_stats(const double* bstats /*[NB][2][D]*/, int64_t NB, int
  * fix-up kernels; perm == NULL: spos must already be valid (or NULL: mode 0 / cols == NULL). */
 int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                       int64_t C, int32_t* spos, const int32_t* perm, const float* var_f32, int64_t F_total,
-                      void* ws, size_t ws_bytes, double* csum_parts /*[ceil(F/16)][C]*/, void* stream);
+                      void* ws, size_t ws_bytes, double* csum_parts /*[2 * ceil(F/16)][C]*/, void* stream);
+/* csum_all: the ranks' csum_parts in rank order, P rows in all; rows_per_rank = rows every rank contributed
+ * (2 * ceil(F_local/16): sums, then bounds), or 0 for sums only (then |x^| <= 1 bounds the margin: sound, but many
+ * more columns are treated as boundary-near). */
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                       int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
-                      int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
+                      int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
                       void* f_T, float* total_f32, float* s_f32, void* stream);
 /* Video-centre replay of the frame-sharded pass ("torch order" mode, 16-bit inputs, rows per rank % 16 == 0,
  * R_total <= 2^19).  Between exchange 2 and phase 2:
@@ -237,13 +245,13 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
  * When the conditions do not hold both calls fall back to vc2_scores_phase2's behaviour (exact means, counted). */
 int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                             int64_t C, const int32_t* spos, const double* csum_all, int64_t P,
-                            int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, float* blocks_out,
-                            int cap, void* stream);
+                            int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes,
+                            float* blocks_out, int cap, void* stream);
 int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                              int64_t C, const int32_t* spos, const double* csum_all, int64_t P,
-                             int64_t csum_stride, int64_t R_total, void* ws, size_t ws_bytes, void* v_T, void* f_T,
-                             float* total_f32, float* s_f32, const float* blocks_all, int world, int cap,
-                             void* stream);
+                             int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes,
+                             void* v_T, void* f_T, float* total_f32, float* s_f32, const float* blocks_all, int world,
+                             int cap, void* stream);
 
 /* Step 3 of the sharded path: s_all_f32[F_total] = the all-gathered per-frame uniqueness scores
  * (fp32-widened T values); budgets are computed over all F_total frames, selection + gather only for

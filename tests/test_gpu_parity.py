@@ -87,6 +87,27 @@ def test_full_pass(c, mode):
         assert synth.sha256_tensor(got.rows) == c["out_sha256"]
 
 
+@pytest.mark.parametrize("c", [c for c in CASES if c["dtype"] != "f32"], ids=case_id)
+def test_proven_centre_margins_agree_with_the_default(c):
+    """Mode 3 decides which centre means to replay with a PROVEN bound on the cascade's error (relative to sum |x^|),
+    mode 1 with the empirical 16-ulp margin.  Same scores, budgets and kept indices on every half-precision fixture:
+    the evidence that the empirical margin -- 50x fewer replays -- loses nothing (and the end-to-end test of the bound's
+    machinery: sweep-1 partials -> sum x^2, per-frame smallest denominator, the boundary-distance test)."""
+    x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"]).to(dev())
+    try:
+        _ffi.set_mode("torch")
+        a = vc.compress(x, c["N"], c["base"], want_scores=True)
+        _ffi.set_mode("torch_proven")
+        b = vc.compress(x, c["N"], c["base"], want_scores=True)
+    finally:
+        _ffi.set_mode("torch")
+    assert a.ks.tolist() == b.ks.tolist() and torch.equal(a.global_idx, b.global_idx)
+    assert nan_eq(a.v_score, b.v_score) and nan_eq(a.f_score, b.f_score)
+    key = (c["name"], c["dtype"], c["dist"], c["seed"])
+    if key not in KNOWN_RESIDUE:
+        assert b.global_idx.cpu().tolist() == c["global_idx"] and synth.sha256_tensor(b.v_score) == c["v_sha256"]
+
+
 def test_always_replay_equals_oracle():
     """Debug mode 2 replays torch's accumulation order for EVERY token: exercises the fix-up kernels on all rows."""
     O.set_mode("torch")

@@ -690,12 +690,27 @@ template <int DT> __device__ __forceinline__ bool near_T_boundary(float y, int m
   }
 }
 
-// Centre means (vidcom2.py:51-52): for half precision torch's mean_out sums an fp32 copy with the outer-
-// reduction cascade, divides by the count in fp32 and casts.  The cascade result sits within a few fp32 ulps
-// of the exact sum (measured < 2 ulp std at 25088 rows), so only means this close to a T rounding boundary
-// are replayed (k_centre_fix).
+// Centre means (vidcom2.py:51-52): for half precision torch's mean_out sums an fp32 copy with the outer-reduction
+// cascade of SumKernel.cpp, divides by the count in fp32 and casts.  We hold the EXACT sum S (fp64 over T values) and
+// q = RN_f32(RN_f32(S) / n); torch's m_t = RN_f32(S_t / n) with |S_t - S| <= k * u * A, where u = 2^-24, A = sum |x^|
+// over the reduced rows and k = the roundings along the deepest path of the cascade (standard forward bound of a
+// summation tree; A is what the error is relative to, NOT |S| -- under cancellation the two differ by orders of
+// magnitude, which is why a margin in ulps of the mean cannot be sound).  So RN_T(m_t) == RN_T(q) unless a T rounding
+// boundary lies within
+//       delta = (k * A / n + 4 |q|) * u            (the 4: the two fp32 roundings of q, the one of m_t, slack)
+// of q -- exactly those means are replayed in torch's order.  A is bounded from what the pass already has, at no
+// cost in the sweeps: |x^| <= (1 + 2^-8) |x| / den >= ..., so per frame and column
+//       A <= (1 + 2^-7) * sqrt(N * sum_r x[r,c]^2) / min_r den[r]        (Cauchy-Schwarz; sum x^2 from sweep 1's
+// shifted partials, the frame's smallest denominator from den[]), and the video's A is the sum of its frames'.
+// Cascade depth: level_power lp = max(4, ceil_log2(n) / 4) (SumKernel.cpp); every level adds at most 2^lp - 1 times
+// before it dumps, three levels, the top level once per 2^(3 lp) rows, plus the final four adds.
+// Default ("torch order", mode 1): an EMPIRICAL margin instead -- 16 fp32-ulps of the mean.  The bound above flags
+// 2.5 % of the frame means and 2 % of the video-centre columns of the `drift` workloads (8 % / 49 % on `iid` data, where
+// every mean is the residue of a cancellation), against 0.05 % with 16 ulps, and the replays that implies cost the
+// target pass +70 us.  Mode 3 uses the bound; the parity suite runs every fixture in both and asserts that they agree
+// -- which is the evidence for the empirical margin (the measured spread of torch's cascade around the exact sum is
+// < 2 ulp at 25088 rows; the bound assumes every rounding errs the same way).
 constexpr int kFragileUlpsMean = 16;
-
 template <int DT> __device__ __forceinline__ bool mean_near_T_boundary(float q) {
   if constexpr (DT == VC2_F32) {
     return false;
@@ -709,6 +724,44 @@ template <int DT> __device__ __forceinline__ bool mean_near_T_boundary(float q) 
     }
     return near_T_boundary<DT>(q, kFragileUlpsMean);
   }
+}
+__host__ __device__ inline int cascade_depth(int64_t n) {
+  int lg = 0;
+  while ((int64_t(1) << lg) < n) ++lg;
+  const int lp = lg / 4 > 4 ? lg / 4 : 4;
+  return 3 * ((1 << lp) - 1) + int((n >> (3 * lp)) + 1) + 4 + 4;      // (+4: row_sum's interleaved chains, C % 32 tail)
+}
+// is a T rounding boundary within `delta` (absolute, >= 0) of q?
+template <int DT> __device__ __forceinline__ bool T_boundary_within(float q, float delta) {
+  if constexpr (DT == VC2_F32) {
+    return false;
+  } else {
+    if (!(delta == delta) || !(fabsf(q) <= 3.0e38f) || delta >= 3.0e38f) return q == q;   // inf / nan bound: replay (NaN means stay)
+    constexpr int DROP = (DT == VC2_BF16) ? 16 : 13;            // fp32 mantissa bits the cast drops
+    const float a = fabsf(q);
+    if (DT == VC2_F16 && a < 6.103515625e-05f) {                 // fp16-subnormal result: values on the 2^-24 grid
+      const float t = a * 16777216.f;                            // exact scaling
+      return fabsf((t - floorf(t)) - 0.5f) <= delta * 16777216.f + 1e-6f;
+    }
+    const uint32_t bits = __float_as_uint(a);
+    if ((bits & 0x7F800000u) == 0u) return true;                 // fp32-subnormal mean: be safe
+    const float ulp = __uint_as_float(bits & 0x7F800000u) * 1.1920928955078125e-07f;   // 2^(e - 23)
+    const int low = int(bits & ((1u << DROP) - 1u));
+    const int d = low - (1 << (DROP - 1));
+    const float dist = float(d < 0 ? -d : d) * ulp;              // distance to the midpoint above trunc_T(q)
+    // (the next midpoint of this binade is 2^DROP ulps further ...
+    // ... and next to a power of two the midpoint BELOW is only a quarter of this binade's T-ulp away)
+    return dist <= delta || delta >= float(1 << (DROP - 2)) * ulp;
+  }
+}
+template <int DT> __device__ __forceinline__ float mean_delta(float q, double A, int64_t n) {
+  return float((double(cascade_depth(n)) * A / double(n) + 4.0 * double(fabsf(q))) * 5.9604644775390625e-08 * 1.01);
+}
+// per-frame bound of A = sum_r |x^[r, c]| from sweep 1's partials of the frame's groups: s = sum (x - K), q = sum (x - K)^2
+// with K the first row of the frame's stat block -> sum x^2 = q + 2 K s + n K^2
+__device__ __forceinline__ double abs_sum_bound(double sumsq, int64_t n, float den_min) {
+  if (!(sumsq >= 0.0)) sumsq = sumsq != sumsq ? sumsq : 0.0;      // (tiny negative from cancellation -> 0; NaN stays)
+  return 1.0078125 * sqrt(double(n) * sumsq * (1.0 + 1e-9)) / (double(den_min) * 0.9921875);   // (den may move by an ulp: k_norm_fix)
 }
 
 // sqrt(sum x^2) over the sorted channel order exactly as torch accumulates it (whole wave; same result on
@@ -850,7 +903,7 @@ __device__ __forceinline__ unsigned long long fixq_pack(int64_t row, float dn) {
   return (static_cast<unsigned long long>(__float_as_uint(dn)) << 32) | static_cast<unsigned long long>(uint32_t(row) + 1u);
 }
 // ticket words (ints at Plan::o_ticket)
-constexpr int kTkFixCount = 2, kTkCorrCount = 3, kTkVcFragile = 5, kTkStatus = 6;
+constexpr int kTkFixCount = 2, kTkCorrCount = 3, kTkVcFragile = 5, kTkStatus = 6, kTkFrameReplays = 7;
 constexpr int kStatusSpinExpired = 1;    // a bounded wait inside a launch ran out (reported through K_out[1])
 
 // One queued row, by one wave: replay torch's norm accumulation (the row's selected values scattered to their SORTED
@@ -959,7 +1012,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
       if (norm != norm) dn = norm;
       // strict mode: where the norm sits within a few fp32 ulps of a T rounding boundary, torch's own fp32
       // accumulation order decides the result -> queue the row (a few per thousand) for k_norm_fix
-      const bool flagged = strict && (strict >= 2 || near_T_boundary<DT>(nrm32, margin));
+      const bool flagged = strict && (strict == 2 || near_T_boundary<DT>(nrm32, margin));
       if (flagged && lane == 0) {
         const int j = atomicAdd(tk + kTkFixCount, 1);
         if (j < nfix_cap) __hip_atomic_store(fixq + j, fixq_pack(row, dn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1192,11 +1245,26 @@ __device__ float wave_column_solo(float* l1s, bool simple, const void* __restric
 //                   sweep 2 in order, norm corrections applied) -> frame_center[f][c] = mean_T; the 16 frame sums
 //                   added in frame order -> csum_part[g][c] (exchange 2 of the frame-sharded pass);
 // k_video_centre    one wave = 64 columns: the group sums added in group order -> vid_center[c] = mean_T.
-// "torch order" mode, half precision: a mean within kFragileUlpsMean fp32-ulps of a T rounding boundary goes on a
+// "torch order" mode, half precision: a mean with a T rounding boundary inside its error bound (mean_delta) goes on a
 // workgroup-local list and is replayed in torch's outer-sum cascade by the same workgroup -- frame entries one wave
 // each (video-centre columns: see k_video_centre).
 // No global queues, no separate fix-up kernel.
 constexpr int kCen2List = 1024;
+
+// where sweep 1's partials of this rank's frames live (part == nullptr: none): group g = piece g % splits of frame
+// g / splits holds (sum (x - K), sum (x - K)^2) per channel, K = the first row of the frame's stat block
+struct FrameStatSrc {
+  const double* part; int splits; int block_frames; int N; int* diag;
+  template <int DT> __device__ __forceinline__ double sumsq(int f, int col, const void* __restrict__ x, int D) const {
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = f * splits; g < (f + 1) * splits; ++g) {
+      s1 += part[(int64_t(g) * 2 + 0) * D + col];
+      s2 += part[(int64_t(g) * 2 + 1) * D + col];
+    }
+    const double K = double(ldT<DT>(x, int64_t(f / block_frames) * block_frames * N * D + col));
+    return s2 + 2.0 * K * s1 + double(N) * K * K;
+  }
+};
 
 template <int DT>
 __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_nhi, int N,
@@ -1208,8 +1276,10 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
                                                                    const float* __restrict__ den,
                                                                    const int* __restrict__ corr_count,
                                                                    const NormCorr* __restrict__ corr, int strict,
-                                                                   int* __restrict__ vtick) {
+                                                                   int* __restrict__ vtick, FrameStatSrc fs) {
   __shared__ double sm[kCentreFL][64];
+  __shared__ double sb[kCentreFL][64];
+  __shared__ float dmin_s[kCentreFL];
   __shared__ float l1s_all[kCentreFL][kCFixSolo];
   __shared__ uint32_t flist[kCen2List];            // local frame * 64 + local column
   __shared__ int count;
@@ -1218,13 +1288,20 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   const int g = blockIdx.y;
   const int f = g * kCentreFL + fl;
   const bool replay = strict != 0 && DT != VC2_F32;
-  const bool all = strict >= 2;
+  const bool all = strict == 2;
   if (tid == 0) {
     count = 0;
     if (g == 0) vtick[blockIdx.x] = 0;             // k_video_centre's arrival ticket of this column block
   }
+  if (strict == 3 && DT != VC2_F32) {              // the frame's smallest denominator (wave fl = frame f): |x^| <= |x| / it
+    float m = INFINITY;
+    if (f < F) for (int r = cl; r < N; r += 64) m = fminf(m, den[int64_t(f) * N + r]);   // (NaN rows do not enter)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if (cl == 0) dmin_s[fl] = m;
+  }
   __syncthreads();
-  double sf = 0.0;
+  double sf = 0.0, ab = 0.0;
   if (c < C && f < F) {
     const int Sf = f < S_nhi ? S : S - 1;                       // this frame's pieces (see make_plan)
     for (int s0 = 0; s0 < Sf; s0 += 8) {                        // (S <= 8: one batch of loads, added in split order)
@@ -1244,18 +1321,26 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       }
     }
     fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
-    if (replay && (all || mean_near_T_boundary<DT>(float(sf) / float(N)))) {
-      const int j = atomicAdd(&count, 1);
-      if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
+    if (replay) {
+      // A >= sum_r |x^[r, c]| over the frame (see mean_delta): from sweep 1's partials, or -- none at hand -- |x^| <= 1
+      ab = (fs.part && strict == 3) ? abs_sum_bound(fs.sumsq<DT>(f, cols ? cols[c] : c, x, D), N, dmin_s[fl]) : double(N);
+      const float q = float(sf) / float(N);
+      // mode 3 ("proven centre margins"): the bound; default: the empirical kFragileUlpsMean (see there)
+      if (all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N)) : mean_near_T_boundary<DT>(q))) {
+        const int j = atomicAdd(&count, 1);
+        if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
+      }
     }
   }
   sm[fl][cl] = sf;
+  sb[fl][cl] = ab;
   __syncthreads();
   if (fl == 0 && c < C) {
-    double t = 0.0;
+    double t = 0.0, tb = 0.0;
 #pragma unroll
-    for (int i = 0; i < kCentreFL; ++i) t += sm[i][cl];
+    for (int i = 0; i < kCentreFL; ++i) { t += sm[i][cl]; tb += sb[i][cl]; }
     csum_part[int64_t(g) * C + c] = t;
+    csum_part[(int64_t(gridDim.y) + g) * C + c] = tb;            // second half of the buffer: the groups' bounds
   }
   if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
   // ---- the boundary-near frame means in torch's cascade order: one wave per entry (the list holds every pair of the
@@ -1263,6 +1348,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
   const int nf = min(count, kCen2List);
+  if (tid == 0 && nf && fs.diag) atomicAdd(fs.diag, nf);       // (diagnostic: replayed frame means of this pass)
   for (int e = wave; e < nf; e += kCentreFL) {
     const int ff = g * kCentreFL + int(flist[e] >> 6), cc = blockIdx.x * 64 + int(flist[e] & 63u);
     const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
@@ -1272,6 +1358,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 }
 
 // parts[NP][stride]: the 16-frame group sums of one rank, or the all-gathered ones of every rank (frame order).
+// rpr > 0: every rank's block of rpr rows is [rpr / 2 group sums | rpr / 2 group bounds of sum |x^|] (k_frame_centres);
+// rpr = 0: sums only (then |x^| <= 1 bounds the replay margin: sound, but flags far more columns).
 // Workgroup (bx, y) = one wave; lane = column bx*64 + lane.  Every y computes the same means and the same set of
 // boundary-near columns; y = 0 stores the means.  replay_rows = 1 (single rank: x / den hold ALL R rows): the ~R/256
 // level-1 groups of a flagged column are spread over the gridDim.y waves of its column block -- one CU ingests a
@@ -1285,26 +1373,37 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       const int* __restrict__ spos, const float* __restrict__ den,
                                                       int strict, int replay_rows, int* __restrict__ fragile_count,
                                                       float* __restrict__ l1g, int vstride, int* __restrict__ vtick,
-                                                      uint8_t* __restrict__ vflag = nullptr) {
+                                                      uint8_t* __restrict__ vflag, int rpr) {
   __shared__ float l1s[2052];                        // level-1 groups of one column (R <= 2^19 rows)
   const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = gridDim.y;
   const bool replay = strict != 0 && DT != VC2_F32;
-  const bool all = strict >= 2;
+  const bool all = strict == 2;
   const int c = bx * 64 + lane;
   bool flag = false;
   const int cl = c < C ? c : C - 1;
   const int my_col = cols ? cols[cl] : cl, my_sp = spos ? spos[cl] : cl;   // (in flight with the partial sums)
   if (c < C) {
-    double t = 0.0;
-    for (int p0 = 0; p0 < NP; p0 += 8) {            // eight loads in flight, added in part order
-      double v[8];
+    double t = 0.0, ab = 0.0;
+    const int half = rpr > 0 ? rpr / 2 : NP;        // rows of sums in a rank's block
+    const int nblocks = rpr > 0 ? NP / rpr : 1;
+    for (int b = 0; b < nblocks; ++b) {
+      const double* __restrict__ blk = parts + int64_t(b) * (rpr > 0 ? rpr : 0) * stride;
+      for (int p0 = 0; p0 < half; p0 += 8) {        // eight loads in flight, added in part order
+        double v[8], w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = parts[int64_t(min(p0 + u, NP - 1)) * stride + c];
+        for (int u = 0; u < 8; ++u) {
+          v[u] = blk[int64_t(min(p0 + u, half - 1)) * stride + c];
+          w[u] = rpr > 0 ? blk[int64_t(half + min(p0 + u, half - 1)) * stride + c] : 0.0;
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (p0 + u < NP) t += v[u];
+        for (int u = 0; u < 8; ++u) if (p0 + u < half) { t += v[u]; ab += w[u]; }
+      }
     }
+    if (rpr <= 0) ab = double(R);
     if (y == 0) vc[c] = mean_T<DT>(t, R);
-    flag = replay && R <= (int64_t(1) << 19) && (all || mean_near_T_boundary<DT>(float(t) / float(R)));
+    const float q = float(t) / float(R);
+    flag = replay && R <= (int64_t(1) << 19) &&
+           (all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, ab, R)) : mean_near_T_boundary<DT>(q)));
   }
   if (vflag && y == 0 && c < C) vflag[c] = flag ? 1 : 0;         // (frame-sharded pass: which columns to replay)
   if (!replay) return;
@@ -1631,8 +1730,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     // rare: a sum within a few fp32 ulps of a T rounding boundary, where torch's own fp32 accumulation order
     // decides the result -> phase 2
     const uint32_t fl = !strict ? 0u
-                                : ((strict >= 2 || near_T_boundary<DT>(dvv, margin)) ? 1u : 0u) |
-                                      ((strict >= 2 || near_T_boundary<DT>(dff, margin)) ? 2u : 0u);
+                                : ((strict == 2 || near_T_boundary<DT>(dvv, margin)) ? 1u : 0u) |
+                                      ((strict == 2 || near_T_boundary<DT>(dff, margin)) ? 2u : 0u);
     if (lane == it) { res_v = rnT<DT>(dvv); res_f = rnT<DT>(dff); res_flag = fl; }
   };
   float held_v = 0.f, held_f = 0.f;                               // (fast path) the previous row's lane partials
@@ -2397,7 +2496,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_part_col = take(size_t(F) * 8 * D * 8);                // (S <= 8 whatever the mode: one workspace size per shape)
   p->o_fc = take(size_t(F) * D * 4);
   p->o_csum = take(size_t(D) * 8);
-  p->o_csum_part = take(size_t(cdiv(F, kCentreFL)) * D * 8);
+  p->o_csum_part = take(size_t(2) * size_t(cdiv(F, kCentreFL)) * D * 8);   // [sums | bounds of sum |x^|][groups][C]
   p->o_vc = take(size_t(D) * 4);
   p->o_rflag = take(size_t(p->R));
   p->o_vpart = take(size_t(F) * p->S2 * 8);
@@ -2601,7 +2700,7 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   int rc1 = allow_big_lds(&k_norm_fix<DT, VEC, NPLB>, smem1, "k_norm_fix");
   if (rc1) return rc1;
   // fp16 queues ~3 % of the rows (its T ulp is 2^13 fp32 ulps) and replays ONE sequential chain per row: more waves
-  const int nfix = cs.strict >= 2 ? int(std::min<int64_t>(p.R, 4096)) : (p.dt == VC2_F16 ? 2048 : 512);
+  const int nfix = cs.strict == 2 ? int(std::min<int64_t>(p.R, 4096)) : (p.dt == VC2_F16 ? 2048 : 512);
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
                      cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + kTkFixCount,
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + kTkCorrCount,
@@ -2643,6 +2742,10 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, con
 // rider: an ORDER job (chan_order_body) attached to sweep 2 -- it produces cs.spos for the fix-up kernels.
 int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, bool single_rank, hipStream_t st,
                   const OrderArgs& rider = OrderArgs{}) {
+  // (ws holds sweep 1's partials of x -- every caller ran the statistics sweep with this workspace: they bound
+  // sum |x^| for the centre-mean replay margins)
+  const FrameStatSrc fs{wsp<double>(ws, p.o_part_stats), p.stat_splits, p.BF, int(p.N),
+                        wsp<int>(ws, p.o_ticket) + kTkFrameReplays};
   const int C = cs.C;
   double* part = wsp<double>(ws, p.o_part_col);
   double* cpart = wsp<double>(ws, p.o_csum_part);
@@ -2674,14 +2777,16 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
                                            wsp<float>(ws, p.o_den),
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
-                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket)));
+                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs));
   if (single_rank) {
     const int G1v = int(cdiv(p.R >> 4, 16));
     const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 4))));
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y)), dim3(64), 0,
-                                             st, cpart, FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
-                                             cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1, (int*)nullptr,
-                                             wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket)));
+                                             st, cpart, 2 * FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
+                                             cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1,
+                                             wsp<int>(ws, p.o_ticket) + kTkVcFragile,
+                                             wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
+                                             (uint8_t*)nullptr, 2 * FG));
   }
   }
   return check_launch("scores phase 1");
@@ -2772,7 +2877,7 @@ const char* vc2_last_error(void) { return g_err; }
 const char* vc2_version(void) { return "vidcom2_amd 0.1 (gfx950)"; }
 
 int vc2_set_mode(int mode) {
-  if (mode < 0 || mode > 3) return fail(VC2_ERR_ARG, "mode must be 0 (exact) or 1 (torch order)");   // 2, 3: debug
+  if (mode < 0 || mode > 3) return fail(VC2_ERR_ARG, "mode must be 0 (exact), 1 (torch order) or 3 (torch order, proven centre margins)");   // 2: debug
   g_mode_default.store(mode, std::memory_order_relaxed);
   g_mode_thread = -1;                               // (the caller sees what it just set)
   return VC2_OK;
@@ -2893,8 +2998,9 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
     rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1, nullptr, nullptr};
   rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider);
   if (rc) return rc;
-  if (csum_parts) {       // the fp64 sums of x^ per group of kCentreFL frames, in frame order: [ceil(F/16)][C]
-    hipError_t e = hipMemcpyAsync(csum_parts, wsp<double>(ws, p.o_csum_part), size_t(cdiv(F, kCentreFL)) * size_t(C) * 8,
+  if (csum_parts) {       // per group of kCentreFL frames, in frame order: the fp64 sums of x^ [ceil(F/16)][C], then the
+    //                        groups' bounds of sum |x^| [ceil(F/16)][C] (the replay margin of the video centre)
+    hipError_t e = hipMemcpyAsync(csum_parts, wsp<double>(ws, p.o_csum_part), size_t(2) * size_t(cdiv(F, kCentreFL)) * size_t(C) * 8,
                                   hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "csum copy: %s", hipGetErrorString(e));
   }
@@ -2908,8 +3014,10 @@ static bool vc_blocks_ok(const Plan& p, int64_t R_total, int strict) {
 
 int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
                             const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
-                            int64_t R_total, void* ws, size_t ws_bytes, float* blocks_out, int cap, void* stream) {
-  if (!x || !csum_all || !blocks_out || P <= 0 || csum_stride < C || cap <= 0)
+                            int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes, float* blocks_out, int cap,
+                            void* stream) {
+  if (!x || !csum_all || !blocks_out || P <= 0 || csum_stride < C || cap <= 0 || rows_per_rank < 0 ||
+      (rows_per_rank > 0 && (rows_per_rank % 2 || P % rows_per_rank)))
     return fail(VC2_ERR_ARG, "bad video_centre_blocks arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
@@ -2923,7 +3031,8 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
                                             csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                             int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
-                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr, vflag));
+                                            wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr, vflag,
+                                            int(rows_per_rank)));
   const int64_t nb = p.R / 16;
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64)), unsigned(cap)), dim3(64), 0, st,
                                             vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), nb,
@@ -2932,18 +3041,20 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
 }
 
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
-                      const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
+                      const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride, int64_t rows_per_rank,
                       int64_t R_total, void* ws,
                       size_t ws_bytes, void* v_T, void* f_T, float* total_f32, float* s_f32, void* stream) {
-  return vc2_scores_phase2_blocks(x, F, N, D, dtype, cols, C, spos, csum_all, P, csum_stride, R_total, ws, ws_bytes, v_T,
-                                  f_T, total_f32, s_f32, nullptr, 0, 0, stream);
+  return vc2_scores_phase2_blocks(x, F, N, D, dtype, cols, C, spos, csum_all, P, csum_stride, rows_per_rank, R_total, ws,
+                                  ws_bytes, v_T, f_T, total_f32, s_f32, nullptr, 0, 0, stream);
 }
 
 int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
                              const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
-                             int64_t R_total, void* ws, size_t ws_bytes, void* v_T, void* f_T, float* total_f32,
-                             float* s_f32, const float* blocks_all, int world, int cap, void* stream) {
-  if (!x || !csum_all || P <= 0 || csum_stride < C) return fail(VC2_ERR_ARG, "bad phase-2 arguments");
+                             int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes, void* v_T, void* f_T,
+                             float* total_f32, float* s_f32, const float* blocks_all, int world, int cap, void* stream) {
+  if (!x || !csum_all || P <= 0 || csum_stride < C || rows_per_rank < 0 ||
+      (rows_per_rank > 0 && (rows_per_rank % 2 || P % rows_per_rank)))
+    return fail(VC2_ERR_ARG, "bad phase-2 arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
   Plan p;
   int rc = make_plan(F, N, D, dtype, &p, R_total / N);
@@ -2958,7 +3069,7 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
                                               csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                               int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
                                               wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr,
-                                              wsp<uint8_t>(ws, p.o_mask)));
+                                              wsp<uint8_t>(ws, p.o_mask), int(rows_per_rank)));
   // ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary.  With the
   // all-gathered level-0 block sums (vc2_video_centre_blocks) torch's cascade is finished here for the first `cap`
   // of them; the others keep the exactly rounded mean and stay counted (vc2_select_sharded reports K_out[2]).
@@ -2983,6 +3094,7 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
+  if (cs.strict == 3 && (rc = launch_stats_sweep(p, x, ws, PoolSrc{}, st))) return rc;   // (bounds sum |x^|: mean_delta)
   if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);

@@ -54,7 +54,8 @@ class HipStages:
         self.bf = next(b for b in (8, 4, 2, 1) if F % b == 0)
         self.stats = torch.empty((F // self.bf, 2, D), dtype=torch.float64, device=self.device)
         self.C = int(D * 0.5)                                   # int(x.shape[-1] * ratio), vidcom2.py:41
-        self.csum = torch.zeros(((F + 15) // 16, self.C), dtype=torch.float64, device=self.device)
+        # exchange 2: per group of 16 frames the sums of x^ and, behind them, the groups' bounds of sum |x^|
+        self.csum = torch.zeros((2 * ((F + 15) // 16), self.C), dtype=torch.float64, device=self.device)
         self.F_total = F                                        # set by ShardedCompressor (world * F)
         self.var_f32 = torch.empty(D, dtype=torch.float32, device=self.device)
         self.mask = torch.empty(D, dtype=torch.uint8, device=self.device)
@@ -69,7 +70,7 @@ class HipStages:
         self.ks = torch.empty(F, dtype=torch.int64, device=self.device)
         self.kout = torch.zeros(4, dtype=torch.int64, device=self.device)     # K, capacity overflow, fragile centre columns
         # exchange 2b (video-centre replay): level-0 block sums of this rank's rows for up to VC_CAP flagged columns
-        self.vc_cap = 16
+        self.vc_cap = 64                                      # flagged columns whose blocks one exchange carries
         self.vc_replay = dtype != torch.float32 and (F * N) % 16 == 0
         self.blocks = torch.zeros((self.vc_cap, max(1, F * N // 16)), dtype=torch.float32, device=self.device)
         self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
@@ -117,8 +118,9 @@ class HipStages:
         p = self._p
         parts = csum_all.reshape(-1, csum_all.shape[-1])
         check(self._L.vc2_video_centre_blocks(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
-                                              ptr(parts), parts.shape[0], parts.shape[1], R_total, p["ws"], self._ws_n,
-                                              p["blocks"], self.vc_cap, self._st()), "vc2_video_centre_blocks")
+                                              ptr(parts), parts.shape[0], parts.shape[1], self.csum.shape[0], R_total,
+                                              p["ws"], self._ws_n, p["blocks"], self.vc_cap, self._st()),
+              "vc2_video_centre_blocks")
         return self.blocks
 
     def phase2(self, x, csum_all, R_total, blocks_all=None):
@@ -126,8 +128,8 @@ class HipStages:
         parts = csum_all.reshape(-1, csum_all.shape[-1])       # [world * groups, C], rank order = frame order
         world = 0 if blocks_all is None else int(blocks_all.shape[0])
         check(self._L.vc2_scores_phase2_blocks(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
-                                               ptr(parts), parts.shape[0], parts.shape[1], R_total, p["ws"],
-                                               self._ws_n, None, None, p["total"], p["s"],
+                                               ptr(parts), parts.shape[0], parts.shape[1], self.csum.shape[0], R_total,
+                                               p["ws"], self._ws_n, None, None, p["total"], p["s"],
                                                ptr(blocks_all) if blocks_all is not None else None, world, self.vc_cap,
                                                self._st()), "vc2_scores_phase2")
         return self.s
@@ -147,10 +149,10 @@ class HipStages:
         self.vc_fragile = int(vc_fragile)
         if vc_fragile and _ffi.get_mode() == "torch":
             import warnings
-            warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within 16 fp32-ulps of a "
-                          "rounding boundary and could not be replayed across ranks (rows per rank not a multiple of 16, more "
-                          "than 16 such columns, or a channel count that is not a multiple of 32); they keep the exactly "
-                          "rounded mean, the reference's fp32 summation order could round the other way.",
+            warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within the replay margin "
+                          "of a rounding boundary and could not be replayed across ranks (rows per rank not a multiple of 16, "
+                          f"more than {self.vc_cap} such columns, or a channel count that is not a multiple of 32); they keep "
+                          "the exactly rounded mean, the reference's fp32 summation order could round the other way.",
                           RuntimeWarning, stacklevel=2)
         li = self.idx[:K]
         return ShardResult(self.rows[:K] if self.rows is not None else None, li, li + f0 * self.N, self.ks, int(K))
