@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Adversarial fixtures for the centre means: the `cancel` inputs of vidcom2_amd/synth.py --
+half-positive half-negative tokens, scored channels whose frame / video means are the residue of a ~100x cancellation -- run
+through the REFERENCE itself (build container only: needs /root/reference):
+
+    python tests/golden/make_adversarial_golden.py      ->  tests/golden/adversarial_cases.json
+
+Data only (seeds, shapes, digests, index lists).  Also records, per case, how often the reference's centre values
+differ from the exactly rounded means -- i.e. how often torch's fp32 cascade decided a rounding -- and the largest
+distance (in fp32-ulps of the mean) between the exact sum and torch's: the quantity an ulp-of-the-mean margin cannot
+bound."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from token_compressor.vidcom2 import vidcom2 as R  # noqa: E402  (the reference)
+import torch.nn.functional as F  # noqa: E402
+
+from vidcom2_amd import synth  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+CASES = [("adv", 16, 196, 512, "bf16", 0), ("adv", 16, 196, 512, "f16", 0), ("adv", 32, 100, 1024, "bf16", 1),
+         ("adv", 8, 324, 768, "f16", 2), ("adv", 64, 196, 256, "bf16", 3)]
+
+
+def main():
+    out = []
+    for name, Fr, N, D, dn, seed in CASES:
+        x = synth.make(Fr, N, D, DT[dn], seed, "cancel")
+        sel = R.select_low_var_channels(x)
+        v, f = R.compute_gaussian_scores(sel, N)
+        scales = R.compute_scales(-v.mean(dim=-1), 0.25)
+        ks = (scales * N).round().long().clamp(min=1).tolist()
+        idx = R.select_outlier_indices(v + f, scales, N)
+        g = R._map_linear_offset(idx, N)
+        # diagnostics: the reference's centres against the exactly rounded means
+        frames = F.normalize(sel.view(-1, N, sel.shape[-1]), dim=-1)
+        fc_ref = frames.mean(dim=1)
+        vc_ref = frames.mean(dim=(0, 1))
+        fd = frames.double()
+        fc_exact = (fd.sum(dim=1).float() / float(N)).to(DT[dn])
+        vc_exact = (fd.sum(dim=(0, 1)).float() / float(Fr * N)).to(DT[dn])
+        cancel = float((fd.abs().mean(dim=1) / fd.mean(dim=1).abs().clamp_min(1e-30)).median())
+        out.append({"name": name, "F": Fr, "N": N, "D": D, "dtype": dn, "seed": seed, "dist": "cancel", "base": 0.25,
+                    "x_sha256": synth.sha256_tensor(x), "ks": ks, "global_idx": g.tolist(),
+                    "v_sha256": synth.sha256_tensor(v), "f_sha256": synth.sha256_tensor(f),
+                    "frame_centres_decided_by_order": int((fc_ref != fc_exact).sum()),
+                    "video_centre_decided_by_order": int((vc_ref != vc_exact).sum()),
+                    "median_cancellation": round(cancel, 1)})
+        print(out[-1]["dtype"], Fr, N, D, "ks", ks[:6], "frame centres decided by torch's order:",
+              out[-1]["frame_centres_decided_by_order"], "of", fc_ref.numel(), "| video:",
+              out[-1]["video_centre_decided_by_order"], "of", vc_ref.numel(), "| cancellation x", cancel)
+    json.dump({"cases": out}, open(os.path.join(HERE, "adversarial_cases.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -519,3 +519,33 @@ def test_mode_is_process_wide_with_a_per_thread_override():
     finally:
         _ffi.set_mode("torch")
         _ffi.set_thread_mode(None)
+
+
+ADV = load_json("adversarial_cases.json")["cases"]
+ADV_BEYOND_THE_EMPIRICAL_MARGIN = {("f16", 16, 196, 512)}
+
+
+@pytest.mark.parametrize("mode", ["torch", "torch_proven"])
+@pytest.mark.parametrize("c", ADV, ids=lambda c: f"adv-{c['F']}x{c['N']}x{c['D']}-{c['dtype']}")
+def test_adversarial_centre_means(c, mode):
+    """tests/golden/make_adversarial_golden.py: inputs BUILT so that torch's fp32 cascade decides centre-mean roundings
+    (tiny addends meet a large running sum that later cancels: `frame_centres_decided_by_order` > 0 in the fixture)
+    and the cascade's error is hundreds of ulps of the mean.  Scores, budgets and kept indices must equal the
+    reference's in the default mode and in the proven-margin mode."""
+    x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
+    assert synth.sha256_tensor(x) == c["x_sha256"]
+    try:
+        _ffi.set_mode(mode)
+        got = vc.compress(x.to(dev()), c["N"], c["base"], want_scores=True)
+    finally:
+        _ffi.set_mode("torch")
+    assert got.ks.cpu().tolist() == c["ks"]
+    assert got.global_idx.cpu().tolist() == c["global_idx"]
+    same_scores = synth.sha256_tensor(got.v_score) == c["v_sha256"] and synth.sha256_tensor(got.f_score) == c["f_sha256"]
+    if mode == "torch" and (c["dtype"], c["F"], c["N"], c["D"]) in ADV_BEYOND_THE_EMPIRICAL_MARGIN:
+        # The documented limit of the DEFAULT mode (DESIGN.md "Numerics contract"): here a frame mean sits farther than
+        # 16 ulps from a rounding boundary and torch's cascade still crosses it; some f scores differ in their last
+        # bit (kept indices and budgets -- asserted above -- do not).  The proven-margin mode gets it right.
+        assert not same_scores, "the empirical margin now covers this case: drop it from the list"
+        return
+    assert same_scores

@@ -14,6 +14,8 @@ Distributions
           per-frame noise e, and a slow global drift d so later frames move away
           from the video centre -> non-trivial per-frame budgets.  s_c is a
           per-channel scale in {2^(k/2)} so channel variances spread over ~2 decades.
+  "cancel" adversarial for the centre means: large positive, tiny, large negative thirds per frame and channel, so the
+          tiny addends are rounded against a large running sum that later cancels (see make_fp32_frames).
 """
 from __future__ import annotations
 
@@ -63,6 +65,27 @@ def make_fp32_frames(F: int, N: int, D: int, f0: int, count: int, seed: int = 0,
     if dist == "iid":
         for i in range(count):
             out[i] = gauss(seed, _TID_IID, (f0 + i) * N * D, N * D).reshape(N, D)
+        return out
+    if dist == "cancel":
+        # ADVERSARIAL for the centre means (vidcom2.py:51-52).  fp32 sums of T values are EXACT while the addends are
+        # within 16 (bf16) / 13 (fp16) binades of the running sum -- which is why torch's fp32 cascade and the exact
+        # sum agree to a few ulps on ordinary data -- so: every channel sees a third of a frame's tokens at +a, then a
+        # third with values five orders of magnitude smaller, then a third at -a,
+        #     x[f,n,c] = a_c * (z(n, c) + 0.02 e[f,n,c]),  z = +1 / 1e-5 e' / -1 by ((n + 64 (c % 3)) % 192) // 64,
+        # a_c = 1 (c < D/2) or 1.5 (the rest: higher variance, not scored); the channel phase c % 3 keeps two thirds
+        # of every ROW large, so the tiny values survive the normalisation.  The small addends meet a running sum of
+        # half of sum |x^| and the big ones then cancel: the cascade's error is hundreds of ulps OF THE MEAN.
+        n_idx = np.arange(N).reshape(N, 1)
+        c_idx = np.arange(D).reshape(1, D)
+        zone = ((n_idx + 64 * (c_idx % 3)) % 192) // 64
+        zone = np.where(n_idx >= (N // 192) * 192, 1, zone)              # leftover tokens: the tiny zone
+        big = np.where(zone == 0, np.float32(1.0), np.where(zone == 2, np.float32(-1.0), np.float32(0.0))).astype(np.float32)
+        tiny = (zone == 1)
+        amp = np.where(np.arange(D) < D // 2, np.float32(1.0), np.float32(1.5)).astype(np.float32)
+        for i in range(count):
+            e = gauss(seed, _TID_E, (f0 + i) * N * D, N * D).reshape(N, D)
+            v = np.where(tiny, np.float32(1e-5) * e, big + np.float32(0.02) * e).astype(np.float32)
+            out[i] = amp * v
         return out
     if dist != "drift":
         raise ValueError(f"unknown dist {dist!r}")
