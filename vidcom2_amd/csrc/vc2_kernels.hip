@@ -1240,6 +1240,50 @@ __device__ float wave_column_solo(float* l1s, bool simple, const void* __restric
   return s;
 }
 
+// Short chains (n <= kCFixSolo elements, e.g. the N rows of one frame): the whole chain is fetched in ONE round of
+// loads into LDS (xs, by the caller) and the cascade runs from there -- blocks of 16 by one lane each, the (at most
+// two) level-1 groups through lane reads -- instead of one memory round trip per level-1 group.
+// Element e of the chain = xs[off + rs * e].  Same value on every lane.
+__device__ __forceinline__ float lds_cascade_short(const float* xs, int off, int rs, int n, int lane) {
+  const int nb = n >> 4;                                           // <= 32 blocks
+  float a = 0.f;
+  if (lane < nb) {
+    const float* p = xs + off + rs * 16 * lane;
+    a = p[0];
+#pragma unroll
+    for (int u = 1; u < 16; ++u) a += p[rs * u];
+  }
+  const int n1c = nb >> 4;                                         // complete level-1 groups (0 .. 2)
+  float l1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int cnt = min(16, nb - 16 * g);
+    if (cnt > 0) {
+      float t = __shfl(a, 16 * g, 64);
+      for (int u = 1; u < cnt; ++u) t += __shfl(a, 16 * g + u, 64);
+      l1[g] = t;
+    }
+  }
+  float acc2 = 0.f;
+  for (int g = 0; g < n1c; ++g) acc2 += l1[g];
+  const float acc1 = (nb & 15) ? l1[n1c] : 0.f;
+  float r = 0.f;
+  for (int e = nb << 4; e < n; ++e) r += xs[off + rs * e];         // the < 16 leftover elements, in order
+  r += acc1; r += acc2; r += 0.f;                                  // (acc3: no complete level-2 group below 4096)
+  return r;
+}
+// a frame's column sum in torch's order from its N <= kCFixSolo values in LDS (see wave_column_solo)
+__device__ __forceinline__ float lds_column_short(const float* xs, bool simple, int n, int lane) {
+  if (simple) return lds_cascade_short(xs, 0, 1, n, lane);
+  const int q4 = n >> 2;
+  float part[4];
+  for (int k = 0; k < 4; ++k) part[k] = lds_cascade_short(xs, k, 4, q4, lane);
+  float s = part[0];
+  for (int i = q4 << 2; i < n; ++i) s += xs[i];
+  s += part[1]; s += part[2]; s += part[3];
+  return s;
+}
+
 // ---- centres (vidcom2.py:51-52): two kernels between sweep 2 and sweep 3 ---------------------------------------
 // k_frame_centres   workgroup = 64 columns (compact channel space) x 16 frames: frame sums (the S partials of
 //                   sweep 2 in order, norm corrections applied) -> frame_center[f][c] = mean_T; the 16 frame sums
@@ -1352,7 +1396,23 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   for (int e = wave; e < nf; e += kCentreFL) {
     const int ff = g * kCentreFL + int(flist[e] >> 6), cc = blockIdx.x * 64 + int(flist[e] & 63u);
     const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
-    const float s = wave_column_solo<DT>(l1s_all[wave], sp < simple_end, x, D, col, den, int64_t(ff) * N, N, lane);
+    float s;
+    if (N <= kCFixSolo) {                                         // the frame's values in one round of loads, then LDS
+      float* xs = l1s_all[wave];
+      float v[kCFixSolo / 64];
+#pragma unroll
+      for (int i = 0; i < kCFixSolo / 64; ++i) {
+        const int r = min(lane + 64 * i, N - 1);
+        v[i] = xhat_at<DT>(x, int64_t(ff) * N + r, D, col, den);
+      }
+#pragma unroll
+      for (int i = 0; i < kCFixSolo / 64; ++i) if (lane + 64 * i < N) xs[lane + 64 * i] = v[i];
+      wave_lds_fence();
+      s = lds_column_short(xs, sp < simple_end, N, lane);
+      wave_lds_fence();
+    } else {
+      s = wave_column_solo<DT>(l1s_all[wave], sp < simple_end, x, D, col, den, int64_t(ff) * N, N, lane);
+    }
     if (lane == 0) fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
   }
 }
