@@ -170,3 +170,33 @@ def test_oracle_matches_the_reference_on_adversarial_centre_means():
             assert synth.sha256_tensor(r["v"]) == c["v_sha256"] and synth.sha256_tensor(r["f"]) == c["f_sha256"]
     finally:
         O.set_mode("exact")
+
+
+def test_oracle_matches_the_reference_on_long_clips():
+    """tests/golden/make_long_golden.py: more than 2^19 tokens per video, where torch's outer-sum cascade switches to
+    level_power 5 (blocks of 32 rows).  Four of the fixtures are built (`cancel`) so that the reference's video centre
+    IS the level-power-5 cascade's and differs from the level-power-4 one; the oracle's 'torch' mode reproduces the
+    reference on all of them (indices, budgets, both score tensors)."""
+    import json
+    import os
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "long_cases.json")))["cases"]
+    assert sum(c["video_centre"]["ne_level_power_4"] > 0 for c in cases) >= 4
+    assert all(c["video_centre"]["ne_level_power_5"] == 0 and c["F"] * c["N"] > 1 << 19 for c in cases)
+    O.set_mode("torch")
+    try:
+        for c in cases:
+            x = synth.make(c["F"], c["N"], c["D"], DT[c["dtype"]], c["seed"], c["dist"])
+            assert synth.sha256_tensor(x) == c["x_sha256"]
+            r = O.compress_indices(x, c["N"], c["base"])
+            assert synth.sha256_tensor(r["ks"].to(torch.int64)) == c["ks_sha256"]
+            assert r["global_idx"].numel() == c["K"] and synth.sha256_tensor(r["global_idx"]) == c["idx_sha256"]
+            assert synth.sha256_tensor(r["v"]) == c["v_sha256"] and synth.sha256_tensor(r["f"]) == c["f_sha256"]
+    finally:
+        O.set_mode("exact")
+
+
+def test_cascade_level_power_host_rule():
+    from vidcom2_amd.vidcom2 import cascade_level_power, cascade_modelled
+    assert [cascade_level_power(n) for n in (1, 196, 1 << 19, (1 << 19) + 1, 1 << 23, (1 << 23) + 1, 1 << 27)] == \
+        [4, 4, 4, 5, 5, 6, 6]
+    assert cascade_modelled(3000 * 196) and cascade_modelled(1 << 25) and not cascade_modelled((1 << 25) + 4096)

@@ -725,10 +725,14 @@ template <int DT> __device__ __forceinline__ bool mean_near_T_boundary(float q) 
     return near_T_boundary<DT>(q, kFragileUlpsMean);
   }
 }
-__host__ __device__ inline int cascade_depth(int64_t n) {
+// SumKernel.cpp's level_power for a chain of n elements: 4 up to 2^19, 5 up to 2^23, 6 up to 2^27
+__host__ __device__ inline int cascade_lp(int64_t n) {
   int lg = 0;
   while ((int64_t(1) << lg) < n) ++lg;
-  const int lp = lg / 4 > 4 ? lg / 4 : 4;
+  return lg / 4 > 4 ? lg / 4 : 4;
+}
+__host__ __device__ inline int cascade_depth(int64_t n) {
+  const int lp = cascade_lp(n);
   return 3 * ((1 << lp) - 1) + int((n >> (3 * lp)) + 1) + 4 + 4;      // (+4: row_sum's interleaved chains, C % 32 tail)
 }
 // is a T rounding boundary within `delta` (absolute, >= 0) of q?
@@ -1149,11 +1153,17 @@ constexpr int kCentreFL = 16;           // frames per centre group (csum_part ro
 // ---- "torch order" mode, half precision: torch's fp32 outer-sum cascade for boundary-near centre means -----------
 // SumKernel.cpp multi_row_sum over n elements: blocks of 16 added sequentially (acc0), block sums added into
 // acc1, acc1 dumped into acc2 every 256 elements, acc2 into acc3 every 4096; finally
-// ((tail + acc1) + acc2) + acc3.  (level_power = max(4, ceil_log2(n) / 4) is 4 for n <= 2^19.)
-// Every block / group sum is an independent sequential chain.  Work item = one level-1 group (16 blocks = 256
-// rows) of one column, done by 16 lanes: each adds one block's 16 values in order, then the 16 block sums are
-// added in order.
-constexpr int kCFixSolo = 512;       // level-1 groups a single wave may hold (rows <= 131072)
+// ((tail + acc1) + acc2) + acc3.  That is level_power lp = 4; in general lp = max(4, ceil_log2(n) / 4) (cascade_lp:
+// 5 beyond 2^19 elements, 6 beyond 2^23) and blocks, level-1 and level-2 groups all hold B = 2^lp members.
+// Every block / group sum is an independent sequential chain.  Work item = one level-1 group (B blocks = B^2
+// rows) of one column, done by B lanes: each adds one block's B values in order, then the B block sums are
+// added in order.  Modelled: lp <= 6 (B <= 64 = one wave) and at most kL1Cap level-1 groups per chain.
+constexpr int kCFixSolo = 512;       // level-1 groups one wave of k_frame_centres may hold (its LDS share)
+constexpr int kL1Cap = 8192;         // level-1 groups of a video-centre chain: 2^23 rows at lp = 5, 2^25 at lp = 6
+__host__ __device__ inline bool cascade_modelled(int64_t n) {
+  const int lp = cascade_lp(n);
+  return lp <= 6 && (((n >> lp) + (int64_t(1) << lp) - 1) >> lp) <= kL1Cap;
+}
 
 template <int DT>
 __device__ __forceinline__ float xhat_at(const void* __restrict__ x, int64_t row, int D, int col,
@@ -1162,20 +1172,28 @@ __device__ __forceinline__ float xhat_at(const void* __restrict__ x, int64_t row
   return rnT<DT>(ldT<DT>(x, row * D + col) / den[row]);
 }
 
-// sum of the level-0 sums of blocks [first_block, first_block + nbl), nbl <= 16, elements at rows r0 + e*rs
+// one level-0 block: the 2^lp elements e0 .. at rows r0 + e*rs added in order (sixteen loads in flight at a time)
 template <int DT>
-__device__ float wave_l1_group(const void* __restrict__ x, int D, int col, const float* __restrict__ den,
-                               int64_t r0, int rs, int64_t first_block, int nbl, int lane) {
+__device__ __forceinline__ float block_sum_rows(const void* __restrict__ x, int D, int col,
+                                                const float* __restrict__ den, int64_t r0, int rs, int64_t e0, int lp) {
   float a = 0.f;
-  if (lane < nbl) {
-    const int64_t e0 = (first_block + lane) << 4;
+  for (int c0 = 0; c0 < (1 << lp); c0 += 16) {
     float v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, r0 + (e0 + u) * rs, D, col, den);
-    a = v[0];
+    for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, r0 + (e0 + c0 + u) * rs, D, col, den);
+    a = c0 == 0 ? v[0] : a + v[0];
 #pragma unroll
     for (int u = 1; u < 16; ++u) a += v[u];
   }
+  return a;
+}
+
+// sum of the level-0 sums of blocks [first_block, first_block + nbl), nbl <= 2^lp, elements at rows r0 + e*rs
+template <int DT>
+__device__ float wave_l1_group(const void* __restrict__ x, int D, int col, const float* __restrict__ den,
+                               int64_t r0, int rs, int64_t first_block, int nbl, int lane, int lp) {
+  float a = 0.f;
+  if (lane < nbl) a = block_sum_rows<DT>(x, D, col, den, r0, rs, (first_block + lane) << lp, lp);
   float s = __shfl(a, 0, 64);
   for (int u = 1; u < nbl; ++u) s += __shfl(a, u, 64);
   return s;
@@ -1184,44 +1202,48 @@ __device__ float wave_l1_group(const void* __restrict__ x, int D, int col, const
 // ((tail + acc1) + acc2) + acc3 from the level-1 values l1[0 .. ceil(nb/16)) (same result on every lane)
 template <int DT>
 __device__ float wave_cascade_final(const float* l1, int64_t nb, const void* __restrict__ x, int D, int col,
-                                    const float* __restrict__ den, int64_t r0, int rs, int64_t n, int lane) {
-  const int n1c = int(nb >> 4);                               // complete level-1 groups
-  const int n2 = n1c >> 4;                                    // complete level-2 groups
+                                    const float* __restrict__ den, int64_t r0, int rs, int64_t n, int lane,
+                                    int lp = 4) {
+  const int B = 1 << lp;
+  const int n1c = int(nb >> lp);                              // complete level-1 groups
+  const int n2 = n1c >> lp;                                   // complete level-2 groups
   float acc3 = 0.f;
   for (int h0 = 0; h0 < n2; h0 += 64) {
     const int h = h0 + lane;
     float a = 0.f;
     if (h < n2) {
-      a = l1[16 * h];
-      for (int u = 1; u < 16; ++u) a += l1[16 * h + u];
+      a = l1[B * h];
+      for (int u = 1; u < B; ++u) a += l1[B * h + u];
     }
     const int cnt = min(64, n2 - h0);
     for (int u = 0; u < cnt; ++u) acc3 += __shfl(a, u, 64);
   }
   float acc2 = 0.f;
-  for (int g = 16 * n2; g < n1c; ++g) acc2 += l1[g];
-  const float acc1 = (nb & 15) ? l1[n1c] : 0.f;
-  // the < 16 leftover rows: fetched by as many lanes at once, added in row order
-  const int ntail = int(n - (nb << 4));
-  const float tv = lane < ntail ? xhat_at<DT>(x, r0 + ((nb << 4) + lane) * rs, D, col, den) : 0.f;
+  for (int g = B * n2; g < n1c; ++g) acc2 += l1[g];
+  const float acc1 = (nb & (B - 1)) ? l1[n1c] : 0.f;
+  // the < B leftover rows: fetched by as many lanes at once, added in row order
+  const int ntail = int(n - (nb << lp));
+  const float tv = lane < ntail ? xhat_at<DT>(x, r0 + ((nb << lp) + lane) * rs, D, col, den) : 0.f;
   float r = 0.f;
   for (int u = 0; u < ntail; ++u) r += __shfl(tv, u, 64);
   r += acc1; r += acc2; r += acc3;
   return r;
 }
 
-// one chain (n elements at rows r0 + e*rs) by ONE wave; needs ceil((n/16)/16) <= kCFixSolo
+// one chain (n elements at rows r0 + e*rs) by ONE wave; needs cascade_modelled(n) and as many level-1 groups as l1s holds
 template <int DT>
 __device__ float wave_cascade_solo(float* l1s, const void* __restrict__ x, int D, int col,
                                    const float* __restrict__ den, int64_t r0, int rs, int64_t n, int lane) {
-  const int64_t nb = n >> 4;
-  const int G = int((nb + 15) >> 4);
+  const int lp = cascade_lp(n), B = 1 << lp;
+  const int64_t nb = n >> lp;
+  const int G = int((nb + B - 1) >> lp);
   for (int g = 0; g < G; ++g) {
-    const float v = wave_l1_group<DT>(x, D, col, den, r0, rs, int64_t(g) << 4, int(min<int64_t>(16, nb - (int64_t(g) << 4))), lane);
+    const float v = wave_l1_group<DT>(x, D, col, den, r0, rs, int64_t(g) << lp,
+                                      int(min<int64_t>(B, nb - (int64_t(g) << lp))), lane, lp);
     if (lane == 0) l1s[g] = v;
   }
   wave_lds_fence();
-  const float r = wave_cascade_final<DT>(l1s, nb, x, D, col, den, r0, rs, n, lane);
+  const float r = wave_cascade_final<DT>(l1s, nb, x, D, col, den, r0, rs, n, lane, lp);
   wave_lds_fence();
   return r;
 }
@@ -1434,7 +1456,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       int strict, int replay_rows, int* __restrict__ fragile_count,
                                                       float* __restrict__ l1g, int vstride, int* __restrict__ vtick,
                                                       uint8_t* __restrict__ vflag, int rpr) {
-  __shared__ float l1s[2052];                        // level-1 groups of one column (R <= 2^19 rows)
+  __shared__ float l1s[kL1Cap + 4];                  // level-1 groups of one column
   const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = gridDim.y;
   const bool replay = strict != 0 && DT != VC2_F32;
   const bool all = strict == 2;
@@ -1462,7 +1484,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
     if (rpr <= 0) ab = double(R);
     if (y == 0) vc[c] = mean_T<DT>(t, R);
     const float q = float(t) / float(R);
-    flag = replay && R <= (int64_t(1) << 19) &&
+    flag = replay && cascade_modelled(R) &&
            (all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, ab, R)) : mean_near_T_boundary<DT>(q)));
   }
   if (vflag && y == 0 && c < C) vflag[c] = flag ? 1 : 0;         // (frame-sharded pass: which columns to replay)
@@ -1473,34 +1495,28 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
   if (!replay_rows) return;
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
-  const int64_t nbv = R >> 4;
-  const int G1v = int((nbv + 15) >> 4);
-  const int sub = lane >> 4, li = lane & 15;
+  const int lp = cascade_lp(R), B = 1 << lp, gpw = 64 >> lp;       // gpw level-1 groups per wave, B lanes each
+  const int64_t nbv = R >> lp;
+  const int G1v = int((nbv + B - 1) >> lp);
+  const int sub = lane >> lp, li = lane & (B - 1);
   for (uint64_t m = flagged; m; m &= m - 1) {
     const int vl = __builtin_ctzll(m), cc = bx * 64 + vl;
     const int col = __shfl(my_col, vl, 64), sp = __shfl(my_sp, vl, 64);
     if (sp >= simple_end) {                       // row_sum's four interleaved chains (C % 32 tail): y = 0 alone
-      if (y == 0 && int((((R >> 2) >> 4) + 15) >> 4) <= kCFixSolo) {
+      if (y == 0) {                                 // (cascade_modelled(R) covers the chains of R / 4 too)
         const float s = wave_column_solo<DT>(l1s, false, x, D, col, den, 0, R, lane);
         if (lane == 0) vc[cc] = rnT<DT>(s / float(R));
       }
       continue;
     }
-    for (int g4 = y * 4; g4 < G1v; g4 += Y * 4) {   // four level-1 groups at once, 16 lanes each
+    for (int g4 = y * gpw; g4 < G1v; g4 += Y * gpw) {   // gpw level-1 groups at once (four at lp = 4)
       const int g1 = g4 + sub;
-      const int nbl = g1 < G1v ? int(min<int64_t>(16, nbv - (int64_t(g1) << 4))) : 0;
+      const int nbl = g1 < G1v ? int(min<int64_t>(B, nbv - (int64_t(g1) << lp))) : 0;
       float a = 0.f;
-      if (li < nbl) {
-        const int64_t e0 = ((int64_t(g1) << 4) + li) << 4;
-        float vv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) vv[u] = xhat_at<DT>(x, e0 + u, D, col, den);
-        a = vv[0];
-#pragma unroll
-        for (int u = 1; u < 16; ++u) a += vv[u];
-      }
-      float sgrp = __shfl(a, lane & 48, 64);         // the block sums of my group, added in block order
-      for (int u = 1; u < 16; ++u) { const float t = __shfl(a, (lane & 48) + u, 64); if (u < nbl) sgrp += t; }
+      if (li < nbl) a = block_sum_rows<DT>(x, D, col, den, 0, 1, ((int64_t(g1) << lp) + li) << lp, lp);
+      const int l0 = lane & ~(B - 1);
+      float sgrp = __shfl(a, l0, 64);                // the block sums of my group, added in block order
+      for (int u = 1; u < B; ++u) { const float t = __shfl(a, l0 + u, 64); if (u < nbl) sgrp += t; }
       if (li == 0 && g1 < G1v) l1g[int64_t(cc) * vstride + g1] = sgrp;
     }
   }
@@ -1515,7 +1531,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
     if (sp >= simple_end) continue;
     for (int g1 = lane; g1 < G1v; g1 += 64) l1s[g1] = l1g[int64_t(cc) * vstride + g1];
     wave_lds_fence();
-    const float s = wave_cascade_final<DT>(l1s, nbv, x, D, col, den, 0, 1, R, lane);
+    const float s = wave_cascade_final<DT>(l1s, nbv, x, D, col, den, 0, 1, R, lane, lp);
     wave_lds_fence();
     if (lane == 0) vc[cc] = rnT<DT>(s / float(R));
   }
@@ -1523,10 +1539,11 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
 
 // ---- frame-sharded pass: the video-centre replay across ranks ------------------------------------------------
 // Every rank flags the same columns (the flags come from the all-gathered group sums).  Slot j = the j-th flagged
-// column in ascending order.  k_vc_blocks: level-0 sums of MY rows -- blocks of 16 consecutive rows, added in row
-// order -- for the first `cap` flagged columns; these are all-gathered (rank order = row order) and k_vc_finish
-// runs the rest of torch's cascade over the whole video's blocks.  Needs rows-per-rank % 16 == 0 (blocks do not
-// straddle ranks) and the cascade's plain form (column in a full group of 32, R_total <= 2^19).
+// column in ascending order.  k_vc_blocks: level-0 sums of MY rows -- blocks of B = 2^lp consecutive rows (lp =
+// cascade_lp(R_total): 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 beyond), added in row order -- for the
+// first `cap` flagged columns, in rows of `bstride` = R_local / 16 floats whatever B is; these are all-gathered (rank
+// order = row order) and k_vc_finish runs the rest of torch's cascade over the whole video's blocks.  Needs
+// rows-per-rank % B == 0 (blocks do not straddle ranks) and the cascade's plain form (column in a full group of 32).
 __device__ __forceinline__ int nth_flagged_column(const uint8_t* __restrict__ vflag, int C, int j, int lane) {
   // lane-contiguous chunks, wave scan; returns the column of the j-th set flag or -1 (same value in every lane)
   const int E = (C + 63) / 64;
@@ -1547,52 +1564,48 @@ __device__ __forceinline__ int nth_flagged_column(const uint8_t* __restrict__ vf
 template <int DT>
 __global__ __launch_bounds__(64) void k_vc_blocks(const uint8_t* __restrict__ vflag, int C, const void* __restrict__ x,
                                                   int D, const int* __restrict__ cols, const int* __restrict__ spos,
-                                                  const float* __restrict__ den, int64_t nb_local,
-                                                  float* __restrict__ blocks_out) {
+                                                  const float* __restrict__ den, int64_t nb_local, int lp,
+                                                  int64_t bstride, float* __restrict__ blocks_out) {
   const int lane = threadIdx.x, j = blockIdx.y;
   const int cc = nth_flagged_column(vflag, C, j, lane);
   if (cc < 0) return;
   const int col = cols ? cols[cc] : cc;
   const int64_t b = int64_t(blockIdx.x) * 64 + lane;
   if (b >= nb_local) return;
-  float v[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) v[u] = xhat_at<DT>(x, (b << 4) + u, D, col, den);
-  float a = v[0];
-#pragma unroll
-  for (int u = 1; u < 16; ++u) a += v[u];
-  blocks_out[int64_t(j) * nb_local + b] = a;
+  blocks_out[int64_t(j) * bstride + b] = block_sum_rows<DT>(x, D, col, den, 0, 1, b << lp, lp);
 }
 
 template <int DT>
 __global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ vflag, int C,
                                                    const int* __restrict__ spos, const float* __restrict__ blocks_all,
-                                                   int world, int cap, int64_t nb_local, int64_t R_total,
-                                                   float* __restrict__ vc, int* __restrict__ fragile_count) {
-  __shared__ float l1[2052];
+                                                   int world, int cap, int64_t nb_local, int64_t bstride,
+                                                   int64_t R_total, float* __restrict__ vc,
+                                                   int* __restrict__ fragile_count) {
+  __shared__ float l1[kL1Cap + 4];
   const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x;
   const int cc = nth_flagged_column(vflag, C, j, lane);
   if (cc < 0) return;
   const int group = C >= 8 ? 32 : 4;
   const int sp = spos ? spos[cc] : cc;
   if (sp >= (C / group) * group) return;                        // row_sum's interleaved chains: not replayed here
-  const int64_t nbv = R_total >> 4;                             // (R_total % 16 == 0: checked by the caller)
-  const int G1 = int((nbv + 15) >> 4);
-  for (int g = tid; g < G1; g += 256) {                         // level 1: 16 block sums in block order
-    const int64_t b0 = int64_t(g) << 4;
-    const int nbl = int(min<int64_t>(16, nbv - b0));
+  const int lp = cascade_lp(R_total), B = 1 << lp;
+  const int64_t nbv = R_total >> lp;                            // (R_total % B == 0: checked by the caller)
+  const int G1 = int((nbv + B - 1) >> lp);
+  for (int g = tid; g < G1; g += 256) {                         // level 1: B block sums in block order
+    const int64_t b0 = int64_t(g) << lp;
+    const int nbl = int(min<int64_t>(B, nbv - b0));
     float a = 0.f;
     for (int u = 0; u < nbl; ++u) {
       const int64_t b = b0 + u;
       const int64_t w = b / nb_local, bl = b - w * nb_local;
-      const float t = blocks_all[(w * cap + j) * nb_local + bl];
+      const float t = blocks_all[(w * cap + j) * bstride + bl];
       a = u == 0 ? t : a + t;
     }
     l1[g] = a;
   }
   __syncthreads();
   if (tid < 64) {
-    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, nbv << 4, lane);   // (no tail rows)
+    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, nbv << lp, lane, lp);   // (no tail rows)
     if (lane == 0) {
       vc[cc] = rnT<DT>(s / float(R_total));
       if (fragile_count) atomicSub(fragile_count, 1);            // one flagged column less that kept its exact mean
@@ -2569,7 +2582,10 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_ticket = take(256);                                    // 64 ints (kTk*)
   p->o_nfixlist = take(size_t(p->R) * 8);                     // 8-byte queue granules (fixq_pack)
   p->o_corr = take(size_t(p->R) * sizeof(NormCorr));
-  p->vstride = int(cdiv(cdiv(std::min<int64_t>(p->R, int64_t(1) << 19), 16), 16) + 1);
+  {
+    const int lpv = cascade_lp(p->R);           // level-1 groups of a video-centre column (k_video_centre's scratch)
+    p->vstride = cascade_modelled(p->R) ? int(cdiv(p->R >> lpv, int64_t(1) << lpv) + 1) : 1;
+  }
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
   p->o_vticket = take(size_t(D) * 4);
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
@@ -2839,8 +2855,9 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
                                            wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs));
   if (single_rank) {
-    const int G1v = int(cdiv(p.R >> 4, 16));
-    const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 4))));
+    const int lpv = cascade_lp(p.R);
+    const int G1v = int(cdiv(p.R >> lpv, int64_t(1) << lpv));
+    const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 64 >> std::min(lpv, 6)))));
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y)), dim3(64), 0,
                                              st, cpart, 2 * FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
                                              cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1,
@@ -3069,7 +3086,8 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
 
 // can the frame-sharded pass replay its video-centre means (see k_vc_blocks)?
 static bool vc_blocks_ok(const Plan& p, int64_t R_total, int strict) {
-  return strict != 0 && p.dt != VC2_F32 && p.R % 16 == 0 && R_total % 16 == 0 && R_total <= (int64_t(1) << 19);
+  const int64_t B = int64_t(1) << cascade_lp(R_total);
+  return strict != 0 && p.dt != VC2_F32 && p.R % B == 0 && R_total % B == 0 && cascade_modelled(R_total);
 }
 
 int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
@@ -3093,10 +3111,11 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
                                             int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
                                             wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr, vflag,
                                             int(rows_per_rank)));
-  const int64_t nb = p.R / 16;
+  const int lpv = cascade_lp(R_total);
+  const int64_t nb = p.R >> lpv;
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64)), unsigned(cap)), dim3(64), 0, st,
-                                            vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), nb,
-                                            blocks_out));
+                                            vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), nb, lpv,
+                                            p.R / 16, blocks_out));
   return check_launch("video_centre_blocks");
 }
 
@@ -3136,7 +3155,8 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   if (have_blocks)
     VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_finish<DT>), dim3(unsigned(cap)), dim3(256), 0, st,
                                               wsp<uint8_t>(ws, p.o_mask), int(C), spos, blocks_all, world, cap,
-                                              p.R / 16, R_total, wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket) + 5));
+                                              p.R >> cascade_lp(R_total), p.R / 16, R_total, wsp<float>(ws, p.o_vc),
+                                              wsp<int>(ws, p.o_ticket) + 5));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, make_chanset(p, cols, spos, C), ws, v_T, f_T, total, s, st);

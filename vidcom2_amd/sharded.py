@@ -111,9 +111,13 @@ class HipStages:
 
     def vc_blocks(self, x, csum_all, R_total):
         """Exchange 2b: this rank's level-0 block sums of the boundary-near video-centre columns, or None when the
-        replay does not apply (fp32, exact mode, rows per rank not a multiple of 16, more than 2^19 tokens) -- a
-        decision every rank takes identically."""
-        if not self.vc_replay or _ffi.get_mode() != "torch" or R_total > (1 << 19) or R_total % 16 != 0:
+        replay does not apply (fp32, exact mode, rows per rank not a multiple of the cascade's block -- 16 rows up to
+        2^19 tokens per video, 32 up to 2^23, 64 beyond --, more tokens than the replay models) -- a decision every
+        rank takes identically."""
+        from .vidcom2 import cascade_level_power, cascade_modelled
+        B = 1 << cascade_level_power(R_total)
+        if (not self.vc_replay or _ffi.get_mode() != "torch" or not cascade_modelled(R_total) or R_total % B != 0
+                or (self.F * self.N) % B != 0):
             return None
         p = self._p
         parts = csum_all.reshape(-1, csum_all.shape[-1])
@@ -150,7 +154,7 @@ class HipStages:
         if vc_fragile and _ffi.get_mode() == "torch":
             import warnings
             warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within the replay margin "
-                          "of a rounding boundary and could not be replayed across ranks (rows per rank not a multiple of 16, "
+                          "of a rounding boundary and could not be replayed across ranks (rows per rank not a multiple of 16 -- 32 beyond 2^19 tokens per video --, "
                           f"more than {self.vc_cap} such columns, or a channel count that is not a multiple of 32); they keep "
                           "the exactly rounded mean, the reference's fp32 summation order could round the other way.",
                           RuntimeWarning, stacklevel=2)

@@ -130,9 +130,41 @@ def to_torch(x32: np.ndarray, dtype):
     raise ValueError(f"unsupported dtype {dtype}")
 
 
+def _cast_into(dst: np.ndarray, v32: np.ndarray, kind: str) -> None:
+    """RNE-cast fp32 v32 into dst (uint16 bf16 bit patterns / float16 / float32), cache-sized slices at a time."""
+    a, d = v32.reshape(-1), dst.reshape(-1)
+    for i in range(0, a.size, 1 << 18):
+        j = min(a.size, i + (1 << 18))
+        d[i:j] = f32_to_bf16_bits(a[i:j]) if kind == "bf16" else a[i:j]       # (float16 / float32: numpy casts RNE)
+
+
 def make(F: int, N: int, D: int, dtype, seed: int = 0, dist: str = "drift"):
-    """[F*N, D] torch tensor in `dtype` -- the `flattened_feat` the hooks hand to the path."""
-    return to_torch(make_fp32(F, N, D, seed, dist), dtype).reshape(F * N, D)
+    """[F*N, D] torch tensor in `dtype` -- the `flattened_feat` the hooks hand to the path.  Large tensors are
+    produced a few frames at a time by a handful of threads (frames are independent element-wise functions of the
+    seed and the index: same bits as make_fp32 + to_torch, at a fraction of the time and memory)."""
+    import torch
+    if F * N * D < (1 << 23) or F < 8:
+        return to_torch(make_fp32(F, N, D, seed, dist), dtype).reshape(F * N, D)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if dtype == torch.bfloat16:
+        kind, out = "bf16", np.empty((F, N, D), dtype=np.uint16)
+    elif dtype == torch.float16:
+        kind, out = "f16", np.empty((F, N, D), dtype=np.float16)
+    elif dtype == torch.float32:
+        kind, out = "f32", np.empty((F, N, D), dtype=np.float32)
+    else:
+        raise ValueError(f"unsupported dtype {dtype}")
+    step = max(4, min(64, (1 << 22) // (N * D)))              # frames per piece (>= 4: the per-call setup of `drift`)
+
+    def fill(f0):
+        cnt = min(step, F - f0)
+        _cast_into(out[f0:f0 + cnt], make_fp32_frames(F, N, D, f0, cnt, seed, dist), kind)
+
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+        list(ex.map(fill, range(0, F, step)))
+    t = torch.from_numpy(out.view(np.int16)).view(torch.bfloat16) if kind == "bf16" else torch.from_numpy(out)
+    return t.reshape(F * N, D)
 
 
 def sha256_tensor(t) -> str:

@@ -83,6 +83,18 @@ class CompressionResult:
     f_score: Optional[torch.Tensor] = None   # T [F, N]
 
 
+def cascade_level_power(n: int) -> int:
+    """torch's SumKernel.cpp level_power for a reduction over n elements: max(4, ceil_log2(n) // 4) -- 4 up to 2^19
+    elements, 5 up to 2^23, 6 up to 2^27 (the block size 2^lp of the centre-mean replays, csrc cascade_lp)."""
+    return max(4, (max(int(n), 1) - 1).bit_length() // 4)
+
+
+def cascade_modelled(n: int) -> bool:
+    """Is torch's summation order for a centre mean over n tokens replayed by the kernels (csrc cascade_modelled)?"""
+    lp = cascade_level_power(n)
+    return lp <= 6 and (((int(n) >> lp) + (1 << lp) - 1) >> lp) <= 8192
+
+
 class CompressPlan:
     """Pre-allocated buffers for repeated passes over one (F, N, D, dtype) shape.
 
@@ -105,11 +117,12 @@ class CompressPlan:
         if self.map_mode == MAP_GRID_VID:
             cap += self.F * self.grid_h
         self.cap = cap
-        if dtype != torch.float32 and _ffi.get_mode() == "torch" and (self.F * self.N > (1 << 19) or self.N > (1 << 17)):
-            # beyond these sizes torch's outer-sum cascade changes shape (SumKernel.cpp level_power) and the centre-mean
-            # replays are not modelled: say so instead of silently keeping the exactly rounded means
+        if dtype != torch.float32 and _ffi.get_mode() == "torch" and not cascade_modelled(self.F * self.N):
+            # beyond this size the centre-mean replays do not model torch's outer-sum cascade (SumKernel.cpp level_power
+            # 4 / 5 / 6 are modelled, i.e. up to 2^25 tokens per video): say so instead of silently keeping the exactly
+            # rounded means
             warnings.warn(f"vidcom2_amd: {self.F} x {self.N} tokens exceed the modelled range of torch's centre-mean "
-                          "accumulation order (2^19 tokens per video, 2^17 per frame); boundary-near centre values "
+                          "accumulation order (2^25 tokens per video); boundary-near centre values "
                           "keep their exactly rounded mean and may differ from the CPU reference by one ulp",
                           RuntimeWarning, stacklevel=3)
         self.ws = ws if ws is not None else _ffi.workspace(self.F, self.N, self.D, dtype, self.device)
