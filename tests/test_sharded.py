@@ -71,12 +71,12 @@ def test_gloo_world2_matches_unsharded(dtype_name):
         assert synth.sha256_tensor(x[torch.tensor(gi, dtype=torch.int64)]) == sha
 
 
-def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev):
+def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev, vc_cap=64):
     """P logical ranks, one HipStages each, exchanges done by stacking (what all_gather returns)."""
     from vidcom2_amd.sharded import HipStages
     Fl = F // P
     shards = [x[p * Fl * N: (p + 1) * Fl * N].contiguous() for p in range(P)]
-    st = [HipStages(Fl, N, D, dtype, dev, base) for _ in range(P)]
+    st = [HipStages(Fl, N, D, dtype, dev, base, vc_cap=vc_cap) for _ in range(P)]
     for s_ in st:
         s_.F_total = F
     stats_all = torch.stack([s.chan_stats(xs).clone() for s, xs in zip(st, shards)])

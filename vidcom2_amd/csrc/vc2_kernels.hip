@@ -710,6 +710,12 @@ template <int DT> __device__ __forceinline__ bool near_T_boundary(float y, int m
 // target pass +70 us.  Mode 3 uses the bound; the parity suite runs every fixture in both and asserts that they agree
 // -- which is the evidence for the empirical margin (the measured spread of torch's cascade around the exact sum is
 // < 2 ulp at 25088 rows; the bound assumes every rounding errs the same way).
+// Tried in round 3 and NOT adopted as the default: the bound's delta with k replaced by ceil(2 sqrt(k)) (independent
+// rounding errors: 3-11 standard deviations).  Being relative to A it widens under cancellation and passes every
+// `cancel` fixture, but it replays 11x as many frame means and 8x as many video-centre columns on `drift` data
+// (+45 us per pass) and 18 % of the video-centre columns on `iid` data (2.5x the pass): a data-dependent cliff.
+// Mode 3 evaluates its margin lazily: |x^| <= 1 gives A <= n, and only a mean with a boundary inside THAT delta goes
+// on to fetch sweep 1's partials for its real A.
 constexpr int kFragileUlpsMean = 16;
 template <int DT> __device__ __forceinline__ bool mean_near_T_boundary(float q) {
   if constexpr (DT == VC2_F32) {
@@ -735,6 +741,8 @@ __host__ __device__ inline int cascade_depth(int64_t n) {
   const int lp = cascade_lp(n);
   return 3 * ((1 << lp) - 1) + int((n >> (3 * lp)) + 1) + 4 + 4;      // (+4: row_sum's interleaved chains, C % 32 tail)
 }
+// the k of mean_delta (mode 3)
+inline double margin_depth(int64_t n, int) { return double(cascade_depth(n)); }
 // is a T rounding boundary within `delta` (absolute, >= 0) of q?
 template <int DT> __device__ __forceinline__ bool T_boundary_within(float q, float delta) {
   if constexpr (DT == VC2_F32) {
@@ -758,8 +766,8 @@ template <int DT> __device__ __forceinline__ bool T_boundary_within(float q, flo
     return dist <= delta || delta >= float(1 << (DROP - 2)) * ulp;
   }
 }
-template <int DT> __device__ __forceinline__ float mean_delta(float q, double A, int64_t n) {
-  return float((double(cascade_depth(n)) * A / double(n) + 4.0 * double(fabsf(q))) * 5.9604644775390625e-08 * 1.01);
+template <int DT> __device__ __forceinline__ float mean_delta(float q, double A, int64_t n, double kk) {
+  return float((kk * A / double(n) + 4.0 * double(fabsf(q))) * 5.9604644775390625e-08 * 1.01);
 }
 // per-frame bound of A = sum_r |x^[r, c]| from sweep 1's partials of the frame's groups: s = sum (x - K), q = sum (x - K)^2
 // with K the first row of the frame's stat block -> sum x^2 = q + 2 K s + n K^2
@@ -1342,10 +1350,11 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
                                                                    const float* __restrict__ den,
                                                                    const int* __restrict__ corr_count,
                                                                    const NormCorr* __restrict__ corr, int strict,
-                                                                   int* __restrict__ vtick, FrameStatSrc fs) {
+                                                                   int* __restrict__ vtick, FrameStatSrc fs,
+                                                                   double kk, int want_bounds,
+                                                                   float* __restrict__ dmin_out) {
   __shared__ double sm[kCentreFL][64];
   __shared__ double sb[kCentreFL][64];
-  __shared__ float dmin_s[kCentreFL];
   __shared__ float l1s_all[kCentreFL][kCFixSolo];
   __shared__ uint32_t flist[kCen2List];            // local frame * 64 + local column
   __shared__ int count;
@@ -1359,16 +1368,15 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     count = 0;
     if (g == 0) vtick[blockIdx.x] = 0;             // k_video_centre's arrival ticket of this column block
   }
-  if (strict == 3 && DT != VC2_F32) {              // the frame's smallest denominator (wave fl = frame f): |x^| <= |x| / it
-    float m = INFINITY;
-    if (f < F) for (int r = cl; r < N; r += 64) m = fminf(m, den[int64_t(f) * N + r]);   // (NaN rows do not enter)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-    if (cl == 0) dmin_s[fl] = m;
-  }
+  // the frame's smallest denominator (wave fl = frame f): |x^| <= |x| / it.  (The loads are in flight with the ones below.)
+  float dmin = INFINITY;
+  const bool bounded = replay && (strict == 3 || want_bounds);      // margins relative to sum |x^| (mode 3; exchange 2)
+  if (bounded && f < F) for (int r = cl; r < N; r += 64) dmin = fminf(dmin, den[int64_t(f) * N + r]);   // (NaN rows do not enter)
   __syncthreads();
   double sf = 0.0, ab = 0.0;
-  if (c < C && f < F) {
+  float q = 0.f;
+  const bool active = c < C && f < F;
+  if (active) {
     const int Sf = f < S_nhi ? S : S - 1;                       // this frame's pieces (see make_plan)
     for (int s0 = 0; s0 < Sf; s0 += 8) {                        // (S <= 8: one batch of loads, added in split order)
       double v[8];
@@ -1387,12 +1395,31 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       }
     }
     fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
-    if (replay) {
-      // A >= sum_r |x^[r, c]| over the frame (see mean_delta): from sweep 1's partials, or -- none at hand -- |x^| <= 1
-      ab = (fs.part && strict == 3) ? abs_sum_bound(fs.sumsq<DT>(f, cols ? cols[c] : c, x, D), N, dmin_s[fl]) : double(N);
-      const float q = float(sf) / float(N);
-      // mode 3 ("proven centre margins"): the bound; default: the empirical kFragileUlpsMean (see there)
-      if (all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N)) : mean_near_T_boundary<DT>(q))) {
+    q = float(sf) / float(N);
+  }
+  if (replay && !bounded) {                        // default: the empirical margin (see kFragileUlpsMean)
+    if (active && (all || mean_near_T_boundary<DT>(q))) {
+      const int j = atomicAdd(&count, 1);
+      if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
+    }
+  } else if (replay) {                             // (wave-uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+    if (dmin_out && blockIdx.x == 0 && cl == 0 && f < F) dmin_out[f] = dmin;     // (k_video_centre's lazy bounds)
+    if (active) {
+      // A >= sum_r |x^[r, c]| over the frame (see mean_delta).  |x^| <= 1 gives A <= N: only a mean with a boundary
+      // inside that margin fetches sweep 1's partials for the real one (want_bounds: the frame-sharded pass ships
+      // every group's bound with exchange 2, so all of them)
+      bool near = all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk))
+                                      : mean_near_T_boundary<DT>(q));
+      if ((want_bounds || (near && strict == 3)) && fs.part) {
+        const double b = abs_sum_bound(fs.sumsq<DT>(f, cols ? cols[c] : c, x, D), N, dmin);
+        ab = b < double(N) ? b : double(N);        // (NaN: N)
+        if (near && !all && strict == 3) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk));
+      } else {
+        ab = double(N);
+      }
+      if (near) {
         const int j = atomicAdd(&count, 1);
         if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
       }
@@ -1406,7 +1433,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 #pragma unroll
     for (int i = 0; i < kCentreFL; ++i) { t += sm[i][cl]; tb += sb[i][cl]; }
     csum_part[int64_t(g) * C + c] = t;
-    csum_part[(int64_t(gridDim.y) + g) * C + c] = tb;            // second half of the buffer: the groups' bounds
+    if (want_bounds) csum_part[(int64_t(gridDim.y) + g) * C + c] = tb;   // second half of the buffer: the groups' bounds
   }
   if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
   // ---- the boundary-near frame means in torch's cascade order: one wave per entry (the list holds every pair of the
@@ -1455,17 +1482,20 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       const int* __restrict__ spos, const float* __restrict__ den,
                                                       int strict, int replay_rows, int* __restrict__ fragile_count,
                                                       float* __restrict__ l1g, int vstride, int* __restrict__ vtick,
-                                                      uint8_t* __restrict__ vflag, int rpr) {
+                                                      uint8_t* __restrict__ vflag, int rpr, double kk,
+                                                      FrameStatSrc fs, const float* __restrict__ dmin, int F) {
   __shared__ float l1s[kL1Cap + 4];                  // level-1 groups of one column
   const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = gridDim.y;
   const bool replay = strict != 0 && DT != VC2_F32;
   const bool all = strict == 2;
   const int c = bx * 64 + lane;
-  bool flag = false;
+  bool flag = false, pre = false;
   const int cl = c < C ? c : C - 1;
   const int my_col = cols ? cols[cl] : cl, my_sp = spos ? spos[cl] : cl;   // (in flight with the partial sums)
+  double ab = 0.0;
+  float q = 0.f;
   if (c < C) {
-    double t = 0.0, ab = 0.0;
+    double t = 0.0;
     const int half = rpr > 0 ? rpr / 2 : NP;        // rows of sums in a rank's block
     const int nblocks = rpr > 0 ? NP / rpr : 1;
     for (int b = 0; b < nblocks; ++b) {
@@ -1481,11 +1511,37 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
         for (int u = 0; u < 8; ++u) if (p0 + u < half) { t += v[u]; ab += w[u]; }
       }
     }
-    if (rpr <= 0) ab = double(R);
     if (y == 0) vc[c] = mean_T<DT>(t, R);
-    const float q = float(t) / float(R);
-    flag = replay && cascade_modelled(R) &&
-           (all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, ab, R)) : mean_near_T_boundary<DT>(q)));
+    q = float(t) / float(R);
+    if (replay && cascade_modelled(R)) {
+      if (all) flag = true;
+      else if (strict != 3) flag = mean_near_T_boundary<DT>(q);                    // default: the empirical margin
+      else if (rpr > 0) flag = T_boundary_within<DT>(q, mean_delta<DT>(q, ab < double(R) ? ab : double(R), R, kk));
+      else pre = T_boundary_within<DT>(q, mean_delta<DT>(q, double(R), R, kk));      // |x^| <= 1: A <= R
+    }
+  }
+  // single rank: the real A of the (few) columns that pass with A = R -- the sum over the frames of the frame bounds
+  // (k_frame_centres), from sweep 1's partials and the frames' smallest denominators; the lanes share the frames.
+  // (Every y evaluates the same expression in the same order: the same flags in all workgroups of a column block.)
+  if (replay) {
+    const uint64_t pm = __ballot(pre);
+    if (pm && fs.part && dmin) {
+      for (uint64_t m = pm; m; m &= m - 1) {
+        const int vl = __builtin_ctzll(m);
+        const int col = __shfl(my_col, vl, 64);
+        double a = 0.0;
+        for (int f = lane; f < F; f += 64) {
+          const double b = abs_sum_bound(fs.sumsq<DT>(f, col, x, D), fs.N, dmin[f]);
+          a += b < double(fs.N) ? b : double(fs.N);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == vl) ab = a;
+      }
+      if (pre) flag = T_boundary_within<DT>(q, mean_delta<DT>(q, ab < double(R) ? ab : double(R), R, kk));
+    } else {
+      flag = flag || pre;
+    }
   }
   if (vflag && y == 0 && c < C) vflag[c] = flag ? 1 : 0;         // (frame-sharded pass: which columns to replay)
   if (!replay) return;
@@ -2487,7 +2543,7 @@ struct Plan {
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_tmp_f32, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_tmp_f32, total_bytes;
   int vstride;
 };
 
@@ -2588,6 +2644,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   }
   p->o_vscratch = take(size_t(D) * p->vstride * 4);
   p->o_vticket = take(size_t(D) * 4);
+  p->o_dmin = take(size_t(F) * 4);                 // per frame: the smallest denominator (centre-mean margins)
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
   p->total_bytes = o;
   return VC2_OK;
@@ -2853,17 +2910,20 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
                                            wsp<float>(ws, p.o_den),
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
-                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs));
+                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs,
+                                           margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0,
+                                           wsp<float>(ws, p.o_dmin)));
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
     const int G1v = int(cdiv(p.R >> lpv, int64_t(1) << lpv));
     const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 64 >> std::min(lpv, 6)))));
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y)), dim3(64), 0,
-                                             st, cpart, 2 * FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
+                                             st, cpart, FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
                                              cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1,
                                              wsp<int>(ws, p.o_ticket) + kTkVcFragile,
                                              wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
-                                             (uint8_t*)nullptr, 2 * FG));
+                                             (uint8_t*)nullptr, 0, margin_depth(p.R, cs.strict), fs,
+                                             wsp<float>(ws, p.o_dmin), int(p.F)));
   }
   }
   return check_launch("scores phase 1");
@@ -3110,7 +3170,8 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
                                             csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                             int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
                                             wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr, vflag,
-                                            int(rows_per_rank)));
+                                            int(rows_per_rank), margin_depth(R_total, cs0.strict), FrameStatSrc{},
+                                            (const float*)nullptr, 0));
   const int lpv = cascade_lp(R_total);
   const int64_t nb = p.R >> lpv;
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64)), unsigned(cap)), dim3(64), 0, st,
@@ -3148,7 +3209,8 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
                                               csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                               int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
                                               wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr,
-                                              wsp<uint8_t>(ws, p.o_mask), int(rows_per_rank)));
+                                              wsp<uint8_t>(ws, p.o_mask), int(rows_per_rank),
+                                              margin_depth(R_total, cs0.strict), FrameStatSrc{}, (const float*)nullptr, 0));
   // ticket[5] = video-centre columns whose mean lies within the replay margin of a T rounding boundary.  With the
   // all-gathered level-0 block sums (vc2_video_centre_blocks) torch's cascade is finished here for the first `cap`
   // of them; the others keep the exactly rounded mean and stay counted (vc2_select_sharded reports K_out[2]).

@@ -43,7 +43,8 @@ class ShardResult:
 class HipStages:
     """The five shard-local stages on the HIP kernels (include/vc2.h 'frame-sharded building blocks')."""
 
-    def __init__(self, F: int, N: int, D: int, dtype, device, base_scale: float, gather: bool = True):
+    def __init__(self, F: int, N: int, D: int, dtype, device, base_scale: float, gather: bool = True,
+                 vc_cap: int = 64):
         self.F, self.N, self.D, self.dtype, self.device, self.base = F, N, D, dtype, torch.device(device), base_scale
         self.code = DTYPE_CODE[dtype]
         L = lib()
@@ -70,7 +71,7 @@ class HipStages:
         self.ks = torch.empty(F, dtype=torch.int64, device=self.device)
         self.kout = torch.zeros(4, dtype=torch.int64, device=self.device)     # K, capacity overflow, fragile centre columns
         # exchange 2b (video-centre replay): level-0 block sums of this rank's rows for up to VC_CAP flagged columns
-        self.vc_cap = 64                                      # flagged columns whose blocks one exchange carries
+        self.vc_cap = int(vc_cap)                             # flagged columns whose blocks one exchange carries
         self.vc_replay = dtype != torch.float32 and (F * N) % 16 == 0
         self.blocks = torch.zeros((self.vc_cap, max(1, F * N // 16)), dtype=torch.float32, device=self.device)
         self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
