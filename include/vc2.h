@@ -234,11 +234,12 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
                       int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
                       void* f_T, float* total_f32, float* s_f32, void* stream);
-/* Video-centre replay of the frame-sharded pass ("torch order" mode, 16-bit inputs, rows per rank % 16 == 0,
- * R_total <= 2^19).  Between exchange 2 and phase 2:
+/* Video-centre replay of the frame-sharded pass ("torch order" mode, 16-bit inputs, rows per rank % B == 0 with
+ * B = 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 up to 2^25 -- torch's level_power 4 / 5 / 6 --,
+ * R_total <= 2^25).  Between exchange 2 and phase 2:
  *   vc2_video_centre_blocks  flags the boundary-near video-centre columns (identically on every rank) and writes, for
- *                            the first `cap` of them, the level-0 sums of THIS rank's rows (blocks of 16 rows, torch's
- *                            SumKernel cascade) to blocks_out[cap][F*N/16]
+ *                            the first `cap` of them, the level-0 sums of THIS rank's rows (blocks of B rows, torch's
+ *                            SumKernel cascade) to the first F*N/B entries of the rows of blocks_out[cap][F*N/16]
  *   (all-gather -> blocks_all[world][cap][F*N/16], rank order)
  *   vc2_scores_phase2_blocks = vc2_scores_phase2, which then finishes the cascade over the whole video for those
  *                            columns, so their means round like the unsharded pass / the reference.
