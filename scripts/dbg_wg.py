@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Per-workgroup begin / end times of sweeps 2 and 3 (library built with -DVC2_DEBUG_TIMING):
+python scripts/dbg_wg.py lib.so"""
+import ctypes, os, sys
+os.environ["VC2_LIB_PATH"] = os.path.abspath(sys.argv[1])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import vidcom2_amd as vc
+from vidcom2_amd import _ffi, synth
+F, N, D = 128, 196, 3584
+x = synth.make(F, N, D, torch.bfloat16, 0, sys.argv[2] if len(sys.argv) > 2 else "drift").cuda()
+plan = vc.vidcom2.CompressPlan(F, N, D, torch.bfloat16, x.device, 0.25)
+L = ctypes.CDLL(_ffi.LIB_PATH)
+buf = (ctypes.c_ulonglong * (3 * 2 * 4096))()
+for it in range(5):
+    plan.enqueue(x); plan.finish()
+L.vc2_debug_wg(buf)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(3, 2, 4096).astype(np.float64) / 100.0
+for slot, name in ((1, "k_norm_colsum"), (2, "k_dist")):
+    b, e = a[slot, 0], a[slot, 1]
+    m = e > 0
+    t0 = b[m].min()
+    b, e = b[m] - t0, e[m] - t0
+    pct = lambda v: " ".join(f"{np.percentile(v, q):6.1f}" for q in (0, 10, 50, 90, 99, 100))
+    print(f"{name}: {m.sum()} workgroups; begin p0/10/50/90/99/100: {pct(b)} | end: {pct(e)} | duration: {pct(e - b)}")
+    late = np.argsort(e)[-8:]
+    print("   last to end (wg: begin -> end):", ", ".join(f"{i}: {b[i]:.1f}->{e[i]:.1f}" for i in late))

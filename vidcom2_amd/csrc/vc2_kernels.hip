@@ -61,8 +61,12 @@ __device__ __forceinline__ void dbg_stamp(int tag) {      // (one lane) wall clo
 }
 }
 #define VC2_STAMP(tag) dbg_stamp(tag)
+// per-workgroup begin / end times of the three sweeps (slot 0: k_chan_stats, 1: k_norm_colsum, 2: k_dist)
+namespace vc2 { __device__ unsigned long long g_dbg_wg[3][2][4096]; }
+#define VC2_WGTIME(slot, which) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_wg[slot][which][blockIdx.x] = wall_clock64(); } while (0)
 #else
 #define VC2_STAMP(tag) ((void)0)
+#define VC2_WGTIME(slot, which) ((void)0)
 #endif
 
 namespace {
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
   // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
   // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
   __shared__ double sm[3][kRedGL][64];
+  if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(100);
   if (counters && blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;  // strict-mode queues of this pass
   if (fixq) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfixq; i += gridDim.x * blockDim.x) fixq[i] = 0ull;
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
@@ -339,6 +344,7 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
   const float v = rnT<DT>(float(t.m2 / t.n));
   if (var_f32) var_f32[c] = v;
   if (var_T) stT<DT>(var_T, c, v);
+  if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(109);
 }
 
 // ======================================================================================
@@ -393,6 +399,7 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
   else topk_smallest2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, k, tid);
   __syncthreads();
+  if (tid == 0) VC2_STAMP(205);
   if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
   // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction)
   for (int i = tid; i < D; i += kSelNT) S.la[i] = (k >= D) ? 1 : 0;
@@ -426,11 +433,13 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
                                                         uint32_t* __restrict__ wcpos) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int bad = 0;
+  if (threadIdx.x == 0) VC2_STAMP(200);
   for (int i = threadIdx.x; i < D; i += kSelNT) bad |= key_fits_u32(var_f32[i]) ? 0 : 1;
   // widened 16-bit variances pack into 32-bit words (the common case); arbitrary fp32 ones take 64-bit words
   // (wperm / wcpos are only requested for 16-bit inputs)
   if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, var_f32, D, k, mask, cols, perm, nullptr, nullptr);
   else chan_select_body<uint32_t>(smem, var_f32, D, k, mask, cols, perm, wperm, wcpos);
+  if (threadIdx.x == 0) VC2_STAMP(209);
 }
 __host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
 
@@ -974,6 +983,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
   // (RIDER = 0 instantiations carry no ORDER code: it is only ever attached in "torch order" mode.)
   const int nrider = (RIDER && rider.perm) ? (rider.parts & 0xFF) : 0;
+  VC2_WGTIME(1, 0);
 #ifdef VC2_RIDER_PROBE
   if (int(blockIdx.x) >= nrider && (rider.parts >> 8) == 1) return;     // probe: riders alone
   if (int(blockIdx.x) < nrider && (rider.parts >> 8) == 2) return;      // probe: sweep alone
@@ -983,6 +993,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
       chan_order_body<uint32_t, kRowWaves, 4, 4>(smem, rider.var_f32, rider.D, rider.k, rider.perm, rider.cols,
                                                  rider.order, rider.opos, rider.spos,    // (16-bit variances: 32-bit words)
                                                  int(blockIdx.x), nrider, rider.wperm, rider.wcpos);
+      VC2_WGTIME(1, 1);
       return;
     }
   }
@@ -1127,6 +1138,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
     part[(int64_t(f) * S + sp) * C + p] = t;
   }
+  VC2_WGTIME(1, 1);
 }
 
 // Fix-up of sweep 2: one wave per queued row.
@@ -1142,7 +1154,9 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   const size_t rowb = row_lds_bytes(D, ES);
   const int lane = threadIdx.x;
   unsigned char* buf0 = smem;
+  if (blockIdx.x == 0 && lane == 0) VC2_STAMP(400);
   const int count = min(*nfix_count, max_entries);
+  if (blockIdx.x == 0 && lane == 0) VC2_STAMP(401);
   if (int(blockIdx.x) >= count) return;
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   unsigned long long g = fixq[blockIdx.x];
@@ -1154,6 +1168,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
     fx.row(buf0, rowb, int64_t(uint32_t(g)) - 1, __uint_as_float(uint32_t(g >> 32)), C, N, den, corr_count, corr,
            max_entries, lane);
   }
+  if (blockIdx.x == 0 && lane == 0) VC2_STAMP(409);
 }
 
 constexpr int kCentreFL = 16;           // frames per centre group (csum_part rows; exchange 2 of the sharded pass)
@@ -1367,6 +1382,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   if (tid == 0) {
     count = 0;
     if (g == 0) vtick[blockIdx.x] = 0;             // k_video_centre's arrival ticket of this column block
+    if (g == 0 && blockIdx.x == 0) VC2_STAMP(500);
   }
   // the frame's smallest denominator (wave fl = frame f): |x^| <= |x| / it.  (The loads are in flight with the ones below.)
   float dmin = INFINITY;
@@ -1435,6 +1451,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     csum_part[int64_t(g) * C + c] = t;
     if (want_bounds) csum_part[(int64_t(gridDim.y) + g) * C + c] = tb;   // second half of the buffer: the groups' bounds
   }
+  if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(505);
   if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
   // ---- the boundary-near frame means in torch's cascade order: one wave per entry (the list holds every pair of the
   //      workgroup: 16 x 64 = kCen2List)
@@ -1464,6 +1481,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     }
     if (lane == 0) fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
   }
+  if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(509);
 }
 
 // parts[NP][stride]: the 16-frame group sums of one rank, or the all-gathered ones of every rank (frame order).
@@ -1489,6 +1507,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
   const bool replay = strict != 0 && DT != VC2_F32;
   const bool all = strict == 2;
   const int c = bx * 64 + lane;
+  if (bx == 0 && y == 0 && lane == 0) VC2_STAMP(600);
   bool flag = false, pre = false;
   const int cl = c < C ? c : C - 1;
   const int my_col = cols ? cols[cl] : cl, my_sp = spos ? spos[cl] : cl;   // (in flight with the partial sums)
@@ -1543,6 +1562,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
       flag = flag || pre;
     }
   }
+  if (bx == 0 && y == 0 && lane == 0) VC2_STAMP(605);
   if (vflag && y == 0 && c < C) vflag[c] = flag ? 1 : 0;         // (frame-sharded pass: which columns to replay)
   if (!replay) return;
   const uint64_t flagged = __ballot(flag);
@@ -1811,6 +1831,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   uint16_t* elist = reinterpret_cast<uint16_t*>(lcount + 4);      // [10 * kDistMaxRows] exp terms for the fp64 path
   uint8_t* rfl = reinterpret_cast<uint8_t*>(elist + 10 * kDistMaxRows);   // [kDistMaxRows]
   int n = n0 + wave;
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) VC2_STAMP(700);
+  VC2_WGTIME(2, 0);
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   if (tid < 2) lcount[tid] = 0;
   for (int r = tid; r < nrows; r += kRowWaves * 64) {
@@ -2007,6 +2029,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     }
     vd = wave_sum(vd);                                            // fixed tree over T values: exact in fp64
     if (lane == 0) vpart[blockIdx.x] = vd;
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) VC2_STAMP(709);
+    VC2_WGTIME(2, 1);
   }
 }
 
@@ -2187,9 +2211,11 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
   Sel2<W> S = sel2_carve<W>(smem, N);
   for (int i = tid; i < N; i += kFrameNT) S.w[i] = T::pack(topk_key(total[int64_t(f) * N + i]), i);
   __syncthreads();
+  if (tid == 0 && f == 0) VC2_STAMP(802);
   if (N > sel2_capacity(1, 4)) topk_smallest2<W, 4, 4, 8>(S, N, k, tid);
   else if (tid < 64) topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
   __syncthreads();
+  if (tid == 0 && f == 0) VC2_STAMP(803);
   // kept flags (la is free now), then ordered compaction = idx.sort().values
   for (int i = tid; i < N; i += kFrameNT) S.la[i] = (k >= N) ? 1 : 0;
   __syncthreads();
@@ -2242,6 +2268,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   const int f = f0 + fl;                                        // its index among the F budget frames
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
+  if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(800 + (fl ? 50 : 0));
   // ---- budgets of all frames; thread t holds frames t, t + 256, ...
   constexpr int FPT = kFusedScalesMaxF / kFrameNT;
   long long before = 0, all = 0;
@@ -2351,6 +2378,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
     if (holder) { smi[0] = kmine; smf[0] = scmine; }
   }
   __syncthreads();
+  if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(801 + (fl ? 50 : 0));
   const int kraw = int(smi[0]);                                 // round(scale * tpf): may exceed N when tpf != N
   const int k = kraw < N ? kraw : N;
   if (tid == 0) {
@@ -2367,6 +2395,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   }
   if constexpr (DT == VC2_F32) select_frame_body<DT, uint64_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
   else select_frame_body<DT, uint32_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
+  if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(809 + (fl ? 50 : 0));
 }
 
 // standalone mappers on already-selected local indices
@@ -2422,6 +2451,7 @@ __device__ __forceinline__ void copy_row(const unsigned char* __restrict__ s, un
 }
 __global__ __launch_bounds__(256) void k_gather_rows(GSArgs a) {
   const int t = blockIdx.y;
+  if (blockIdx.x == 0 && t == 0 && threadIdx.x == 0) VC2_STAMP(900);
   const int64_t n = a.n_dev ? min(a.n_dev[0], a.n_max) : a.n_max;
   const int64_t total = n + (t == 0 ? a.tail_rows : 0);
   for (int64_t j = blockIdx.x; j < total; j += gridDim.x) {
@@ -2439,6 +2469,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(GSArgs a) {
       copy_row(a.tail + (j - n) * a.row_bytes, a.dst[0] + d * a.row_bytes, a.row_bytes);
     }
   }
+  if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && t == 0 && threadIdx.x == 0) VC2_STAMP(909);
 }
 
 // Sequence positions a pruned prefill keeps (hooks, reference models/qwen2_5_vl.py:153-160): every position that is
@@ -3553,6 +3584,11 @@ int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, i
 }
 
 #ifdef VC2_DEBUG_TIMING
+int vc2_debug_wg(unsigned long long* out /*[3][2][4096]*/) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 3 * 2 * 4096);
+  return 0;
+}
 int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(n, HIP_SYMBOL(vc2::g_dbg_n), sizeof(int));
