@@ -973,7 +973,7 @@ struct NormFixer {
 template <int DT, int VEC, int NPLB, int ACC, int RIDER>
 __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __restrict__ x, int N, int D, int CV,
                                                                 int C, const int* __restrict__ cols,
-                                                                int strict, int S, int nhi,
+                                                                int strict, int S, int q, int64_t R,
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ tk, unsigned long long* __restrict__ fixq,
                                                                 int nfix_cap, uint8_t* __restrict__ rflag,
@@ -1001,28 +1001,29 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // frames [0, nhi) are cut in S pieces, the others in S - 1 (make_plan: the launch fills the resident slots exactly)
-  int f, sp, Sf;
-  if (bid < nhi * S) { f = bid / S; sp = bid - f * S; Sf = S; }
-  else { const int b2 = bid - nhi * S; f = nhi + b2 / (S - 1); sp = b2 - (f - nhi) * (S - 1); Sf = S - 1; }
-  const int rows_per_split = (N + Sf - 1) / Sf;
-  const int n0 = sp * rows_per_split;
-  const int n1 = min(N, n0 + rows_per_split);
+  // chunk `bid` = rows [bid * q, (bid + 1) * q) of this rank (make_plan); the frames it meets are swept one after the
+  // other: segment = the chunk's rows inside one frame, slot = the chunk's number among those that meet the frame
+  const int64_t row_a = int64_t(bid) * q, row_b = min(R, row_a + q);
   unsigned char* buf0 = smem + size_t(2 * wave) * rowb;          // [kRowWaves][2][rowb]; later double sacc[C]
   unsigned char* buf1 = buf0 + rowb;
+  int coff[NPLB];
+  load_col_offsets<NPLB, 1>(cols, C, int((rowb - 16) / ES), lane, coff);
+  constexpr bool kFastBf16 = ACC == 1 && DT == VC2_BF16;
+  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+  for (int64_t seg_a = row_a; seg_a < row_b;) {
+  const int f = int(seg_a / N);
+  const int64_t seg_b = min(row_b, int64_t(f + 1) * N);
+  const int sp = bid - int((int64_t(f) * N) / q);
+  const int n0 = int(seg_a - int64_t(f) * N), n1 = int(seg_b - int64_t(f) * N);
   if (lane < 4) {                                                // zero pad element of both buffers
     reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
     reinterpret_cast<uint32_t*>(buf1 + rowb - 16)[lane] = 0u;
   }
-  int coff[NPLB];
-  load_col_offsets<NPLB, 1>(cols, C, int((rowb - 16) / ES), lane, coff);
   double acc[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
   int n = n0 + wave;
   if (n < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, int64_t(f) * N + n, D, CV, buf0, lane);
-  constexpr bool kFastBf16 = ACC == 1 && DT == VC2_BF16;
-  typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
   for (; n < n1; n += kRowWaves) {
     const int64_t row = int64_t(f) * N + n;
     row_wait();
@@ -1137,6 +1138,9 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
 #pragma unroll
     for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
     part[(int64_t(f) * S + sp) * C + p] = t;
+  }
+  seg_a = seg_b;
+  if (seg_a < row_b) __syncthreads();                            // (the next segment refills the row buffers)
   }
   VC2_WGTIME(1, 1);
 }
@@ -1356,7 +1360,7 @@ struct FrameStatSrc {
 };
 
 template <int DT>
-__global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_nhi, int N,
+__global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_q, int N,
                                                                    int C, float* __restrict__ fc,
                                                                    double* __restrict__ csum_part,
                                                                    const void* __restrict__ x, int D,
@@ -1393,7 +1397,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   float q = 0.f;
   const bool active = c < C && f < F;
   if (active) {
-    const int Sf = f < S_nhi ? S : S - 1;                       // this frame's pieces (see make_plan)
+    // this frame's segments: one per sweep-2 chunk that meets it (make_plan)
+    const int Sf = int((int64_t(f + 1) * N - 1) / S_q) - int((int64_t(f) * N) / S_q) + 1;
     for (int s0 = 0; s0 < Sf; s0 += 8) {                        // (S <= 8: one batch of loads, added in split order)
       double v[8];
 #pragma unroll
@@ -2202,6 +2207,15 @@ __device__ __forceinline__ float block_max_nanprop_256(float v, float* sm) {
   return r;
 }
 
+// the frame's (score, index) words into LDS: issued at the top of k_select, so the loads' latency runs under the
+// budget arithmetic (which only needs the static shared arrays)
+template <typename W>
+__device__ __forceinline__ void select_frame_load(unsigned char* smem, const float* __restrict__ total, int f, int N) {
+  using T = WordTr<W>;
+  Sel2<W> S = sel2_carve<W>(smem, N);
+  for (int i = threadIdx.x; i < N; i += kFrameNT) S.w[i] = T::pack(topk_key(total[int64_t(f) * N + i]), i);
+}
+
 template <int DT, typename W>
 __device__ __forceinline__ void select_frame_body(unsigned char* smem, const float* __restrict__ total, int f, int N, int k,
                                   int64_t o0, int map_mode, int grid_h, int64_t stride, int64_t cap,
@@ -2209,7 +2223,7 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
   using T = WordTr<W>;
   const int tid = threadIdx.x;
   Sel2<W> S = sel2_carve<W>(smem, N);
-  for (int i = tid; i < N; i += kFrameNT) S.w[i] = T::pack(topk_key(total[int64_t(f) * N + i]), i);
+  // (the frame's words were packed into S.w by select_frame_load before the budgets were derived)
   __syncthreads();
   if (tid == 0 && f == 0) VC2_STAMP(802);
   if (N > sel2_capacity(1, 4)) topk_smallest2<W, 4, 4, 8>(S, N, k, tid);
@@ -2269,6 +2283,8 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(800 + (fl ? 50 : 0));
+  if constexpr (DT == VC2_F32) select_frame_load<uint64_t>(smem, total, fl, N);
+  else select_frame_load<uint32_t>(smem, total, fl, N);
   // ---- budgets of all frames; thread t holds frames t, t + 256, ...
   constexpr int FPT = kFusedScalesMaxF / kFrameNT;
   long long before = 0, all = 0;
@@ -2570,7 +2586,8 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups (G = F * stat_splits), stat blocks
   int stat_splits, NB, BF;      // groups per frame; stat blocks of BF (<= kStatBlockFrames) frames
   int64_t F_total;              // frames of the WHOLE video (frame-sharded pass: canonical blockings depend on it)
-  int S, S_nhi;                 // sweep 2: frames [0, S_nhi) are cut in S pieces, the others in S - 1
+  int S, S_q, S_W;              // sweep 2: S_W chunks of S_q consecutive rows (frame boundaries inside a chunk cut it in
+                                //   segments); a frame's segments fill its first slots of S in `part`
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
@@ -2618,12 +2635,16 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   // T-rounded x^ in [-1, 1] -- exact (so independent of how the rows are cut) for fp16 by range (2^-24 .. 1, <= 8192
   // rows: 48 bits), and for bf16 unless a nonzero |x^| < 2^-39 meets a frame sum > 2^6
   {
+    // Equal CHUNKS of consecutive rows, not equal pieces of frames: with 448 slots and 128 frames of 196 rows the
+    // frame-aligned cut was 4 x 49 rows for half of the frames and 3 x 66 for the others -- the sweep took as long as
+    // the 66-row workgroups (36 us against 25 for the others: scripts/dbg_wg.py).  A chunk that contains a frame
+    // boundary is swept segment by segment (one flush of the column sums per segment).
     const int64_t budget = 512 - riders;
-    const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(8, N / std::min<int64_t>(N, 8 * kRowWaves)));   // >= 32 rows a piece
-    const int64_t s_lo = std::max<int64_t>(1, std::min<int64_t>(smax, budget / F));
-    const int64_t left = budget - F * s_lo;                    // slots still free with s_lo pieces per frame
-    if (s_lo < smax && left > 0) { p->S = int(s_lo + 1); p->S_nhi = int(std::min<int64_t>(F, left)); }
-    else { p->S = int(s_lo); p->S_nhi = int(F); }
+    int64_t W = std::max<int64_t>(1, std::min<int64_t>(budget, p->R / (8 * kRowWaves)));   // >= 32 rows a chunk
+    int64_t q = std::max<int64_t>(cdiv(p->R, W), cdiv(N, 6));          // (a frame meets at most (N - 1) / q + 2 <= 8 chunks)
+    p->S_q = int(q);
+    p->S_W = int(cdiv(p->R, q));
+    p->S = int(std::min<int64_t>(8, (N - 1) / q + 2));
   }
   {
     // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
@@ -2844,9 +2865,9 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
   if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
   int rc = allow_big_lds(&k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>, smem, "k_norm_colsum");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(int64_t(p.S_nhi) * p.S + (p.F - p.S_nhi) * (p.S - 1) + (rider.perm ? (rider.parts & 0xFF) : 0))),
+  hipLaunchKernelGGL((k_norm_colsum<DT, VEC, NPLB, ACC, RIDER>), dim3(unsigned(p.S_W + (rider.perm ? (rider.parts & 0xFF) : 0))),
                      dim3(kRowWaves * 64), smem, st, x,
-                     int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_nhi,
+                     int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_q, p.R,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
   return VC2_OK;
@@ -2937,7 +2958,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   { ProfScope ps_(KID_CENTRES, st);
   const int FG = int(cdiv(p.F, kCentreFL));
   VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
-                                           dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, p.S_nhi, int(p.N), C,
+                                           dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, p.S_q, int(p.N), C,
                                            wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
                                            wsp<float>(ws, p.o_den),
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
