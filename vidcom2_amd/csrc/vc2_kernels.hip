@@ -1598,19 +1598,22 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
       const int l0 = lane & ~(B - 1);
       float sgrp = __shfl(a, l0, 64);                // the block sums of my group, added in block order
       for (int u = 1; u < B; ++u) { const float t = __shfl(a, l0 + u, 64); if (u < nbl) sgrp += t; }
-      if (li == 0 && g1 < G1v) l1g[int64_t(cc) * vstride + g1] = sgrp;
+      // (published as an agent-scope atomic store -- it goes to the coherence point itself; a release fence instead
+      // would write back the XCD's whole L2, an acquire fence invalidate it: NOTES_r03.md)
+      if (li == 0 && g1 < G1v)
+        __hip_atomic_store(&l1g[int64_t(cc) * vstride + g1], sgrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  __threadfence();                                   // release my groups ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my groups have arrived ...
   int last = 0;
-  if (lane == 0) last = atomicAdd(&vtick[bx], 1) == Y - 1;
-  if (!__shfl(last, 0, 64)) return;
-  __threadfence();                                   // ... acquire everyone else's
+  if (lane == 0) last = __hip_atomic_fetch_add(&vtick[bx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == Y - 1;
+  if (!__shfl(last, 0, 64)) return;                  // ... and the last wave to arrive reads everyone's (coherent loads)
   for (uint64_t m = flagged; m; m &= m - 1) {
     const int vl = __builtin_ctzll(m), cc = bx * 64 + vl;
     const int col = __shfl(my_col, vl, 64), sp = __shfl(my_sp, vl, 64);
     if (sp >= simple_end) continue;
-    for (int g1 = lane; g1 < G1v; g1 += 64) l1s[g1] = l1g[int64_t(cc) * vstride + g1];
+    for (int g1 = lane; g1 < G1v; g1 += 64)
+      l1s[g1] = __hip_atomic_load(&l1g[int64_t(cc) * vstride + g1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wave_lds_fence();
     const float s = wave_cascade_final<DT>(l1s, nbv, x, D, col, den, 0, 1, R, lane, lp);
     wave_lds_fence();
