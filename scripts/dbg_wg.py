@@ -26,3 +26,12 @@ for slot, name in ((1, "k_norm_colsum"), (2, "k_dist")):
     print(f"{name}: {m.sum()} workgroups; begin p0/10/50/90/99/100: {pct(b)} | end: {pct(e)} | duration: {pct(e - b)}")
     late = np.argsort(e)[-8:]
     print("   last to end (wg: begin -> end):", ", ".join(f"{i}: {b[i]:.1f}->{e[i]:.1f}" for i in late))
+# k_dist: row loop / phase 2 (replays) / phase 3 per workgroup
+b, p2, p3, e = a[2, 0], a[0, 0], a[0, 1], a[2, 1]
+m = e > 0
+t0 = b[m].min()
+rl, r2, r3 = (p2 - b)[m], (p3 - p2)[m], (e - p3)[m]
+pct = lambda v: " ".join(f"{np.percentile(v, q):6.1f}" for q in (0, 10, 50, 90, 99, 100))
+print("k_dist row loop:", pct(rl), "| phase 2:", pct(r2), "| phase 3:", pct(r3))
+busy = r2 > 1.0
+print(f"   workgroups with replays: {busy.sum()}; their phase 2: {pct(r2[busy]) if busy.any() else ''}; row-loop end of those: {pct((p2 - t0)[m][busy]) if busy.any() else ''}")

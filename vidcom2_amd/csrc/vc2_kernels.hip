@@ -1986,6 +1986,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   }
   __syncthreads();
   // ---- phase 2: replay torch's cascade sum for the listed (row, centre) pairs ---------------------------
+  VC2_WGTIME(0, 0);                                               // (debug builds: phase 2 begins / ends)
   if (strict) {
     const int cnt = *lcount;
     float* sq = reinterpret_cast<float*>(smem);
@@ -2010,6 +2011,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     }
   }
   // ---- phase 3: Gaussian sums, total, partial frame sum ---------------------------------------------
+  VC2_WGTIME(0, 1);
   for (int t = tid; t < nrows * 10; t += kRowWaves * 64) {
     const int nl = t / 10, j = t - nl * 10;
     float e;
