@@ -798,16 +798,16 @@ __device__ float norm_torch_order(const float* sv, int C, int lane) {
 #pragma unroll
         for (int u = 0; u < 32; ++u) v[u] = sv[p + u];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) s = s + v[u] * v[u];       // fp16 x fp16 is exact in fp32
+        for (int u = 0; u < 32; ++u) s = __builtin_fmaf(v[u], v[u], s);   // (fp16 x fp16 is exact in fp32: the fused form rounds like s + v * v, at half the dependent latency)
       }
       for (; p + 8 <= C; p += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = sv[p + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s = s + v[u] * v[u];
+        for (int u = 0; u < 8; ++u) s = __builtin_fmaf(v[u], v[u], s);
       }
-      for (; p < C; ++p) { const float v = sv[p]; s = s + v * v; }
+      for (; p < C; ++p) { const float v = sv[p]; s = __builtin_fmaf(v, v, s); }
     }
     s = __shfl(s, 0, 64);
   } else {                                                      // 8 interleaved FMA chains, then lanes 0..7, then the tail
