@@ -234,20 +234,23 @@ int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
                       int64_t C, const int32_t* spos, const double* csum_all /*[P][csum_stride]*/, int64_t P,
                       int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes, void* v_T,
                       void* f_T, float* total_f32, float* s_f32, void* stream);
-/* Video-centre replay of the frame-sharded pass ("torch order" mode, 16-bit inputs, rows per rank % B == 0 with
- * B = 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 up to 2^25 -- torch's level_power 4 / 5 / 6 --,
- * R_total <= 2^25).  Between exchange 2 and phase 2:
+/* Video-centre replay of the frame-sharded pass ("torch order" mode, 16-bit inputs, every rank the same number of
+ * rows and at least B of them, B = 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 up to 2^25 -- torch's
+ * level_power 4 / 5 / 6).  Between exchange 2 and phase 2:
  *   vc2_video_centre_blocks  flags the boundary-near video-centre columns (identically on every rank) and writes, for
- *                            the first `cap` of them, the level-0 sums of THIS rank's rows (blocks of B rows, torch's
- *                            SumKernel cascade) to the first F*N/B entries of the rows of blocks_out[cap][F*N/16]
- *   (all-gather -> blocks_all[world][cap][F*N/16], rank order)
+ *                            the first `cap` of them, a record of 129 + F*N/16 floats to blocks_out[cap][129 + F*N/16]:
+ *                            [0,64) the x^ values of this rank's first rows that end a B-row block begun by the previous
+ *                            rank (row0 = the video row index of this rank's first row tells how many), [64,128) those
+ *                            of its last rows that begin a block the next rank ends, [128,..) the sums of its complete
+ *                            blocks (rows added in order: torch's SumKernel cascade, level 0)
+ *   (all-gather -> blocks_all[world][cap][129 + F*N/16], rank order)
  *   vc2_scores_phase2_blocks = vc2_scores_phase2, which then finishes the cascade over the whole video for those
  *                            columns, so their means round like the unsharded pass / the reference.
  * When the conditions do not hold both calls fall back to vc2_scores_phase2's behaviour (exact means, counted). */
 int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                             int64_t C, const int32_t* spos, const double* csum_all, int64_t P,
-                            int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes,
-                            float* blocks_out, int cap, void* stream);
+                            int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, int64_t row0, void* ws,
+                            size_t ws_bytes, float* blocks_out, int cap, void* stream);
 int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                              int64_t C, const int32_t* spos, const double* csum_all, int64_t P,
                              int64_t csum_stride, int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes,

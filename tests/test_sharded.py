@@ -83,7 +83,7 @@ def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev, vc_cap=64):
     for s in st:
         s.select_channels(stats_all, F * N)
     csum_all = torch.stack([s.phase1(xs).clone() for s, xs in zip(st, shards)])
-    blocks = [s.vc_blocks(xs, csum_all, F * N) for s, xs in zip(st, shards)]          # exchange 2b (may not apply)
+    blocks = [s.vc_blocks(xs, csum_all, F * N, p * Fl) for p, (s, xs) in enumerate(zip(st, shards))]   # exchange 2b (may not apply)
     if all(b is not None for b in blocks):
         blocks_all = torch.stack([b.clone() for b in blocks])
         s_all = torch.cat([s.phase2(xs, csum_all, F * N, blocks_all).clone() for s, xs in zip(st, shards)])
@@ -112,11 +112,16 @@ def test_world_size_invariance_on_gpu(case):
     O.set_mode("exact")
     whole = vc.compress(xd, N, base, want_scores=True)
     assert torch.equal(whole.global_idx.cpu(), ref["global_idx"])
+    import warnings
     for P in (1, 2, 4):
-        res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, base, P, dev)
-        if all(s.vc_fragile == 0 for s in st) and dtype != torch.float32:
-            # every boundary-near video-centre mean was replayed across the ranks: the scores themselves are the
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")       # (no "could not be replayed across ranks": 169-token frames included)
+            res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, base, P, dev)
+        if dtype != torch.float32:
+            # every boundary-near video-centre mean was replayed across the ranks -- also where a rank's row count is
+            # not a multiple of the cascade's 16-row blocks (169-token frames) --: the scores themselves are the
             # unsharded pass's bits, not only the decisions taken from them
+            assert all(s.vc_fragile == 0 for s in st)
             tot = torch.cat([s.total for s in st])
             assert torch.equal(tot, (whole.v_score + whole.f_score).float().flatten()), f"P={P}"
         gidx = torch.cat([r.global_idx for r in res]).cpu()
@@ -126,6 +131,38 @@ def test_world_size_invariance_on_gpu(case):
         assert all(torch.equal(s.mask, st[0].mask) for s in st)
         rows = torch.cat([r.rows for r in res])
         assert torch.equal(rows, whole.rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(6, 49, 64, "bf16", (2, 3)), (12, 169, 128, "f16", (2, 3, 4, 6)), (10, 100, 256, "bf16", (2, 5)),
+                                  (9, 37, 64, "f16", (3,))], ids=lambda c: "x".join(map(str, c[:4])))
+def test_video_centre_replay_across_unaligned_ranks(case):
+    """Debug mode 2 flags EVERY video-centre column, so all of them go through exchange 2b: ranks whose row count is
+    not a multiple of 16 share level-0 blocks with their neighbours (raw head / tail values in the record), and a video
+    whose row count is not a multiple of 16 ends in the cascade's tail rows.  Token by token the sharded scores must be
+    the unsharded pass's (same mode) and the oracle's."""
+    import vidcom2_amd as vc
+    from vidcom2_amd import _ffi
+    F, N, D, dn, worlds = case
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dn]
+    dev = torch.device("cuda:0")
+    x = synth.make(F, N, D, dtype, 2, "drift")
+    xd = x.to(dev)
+    O.set_mode("torch")
+    ref = O.compress_indices(x, N, 0.25)
+    O.set_mode("exact")
+    try:
+        assert _ffi.lib().vc2_set_mode(2) == 0
+        whole = vc.compress(xd, N, 0.25, want_scores=True)
+        assert torch.equal(whole.v_score.cpu().float(), ref["v"].float()) and torch.equal(whole.global_idx.cpu(), ref["global_idx"])
+        total = (whole.v_score + whole.f_score).float().flatten()
+        for P in worlds:
+            res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, 0.25, P, dev, vc_cap=D // 2)
+            assert all(s.vc_fragile == 0 for s in st), f"P={P}"
+            assert torch.equal(torch.cat([s.total for s in st]), total), f"P={P}"
+            assert torch.equal(torch.cat([r.global_idx for r in res]).cpu(), ref["global_idx"]), f"P={P}"
+    finally:
+        _ffi.set_mode("torch")
 
 
 @pytest.mark.gpu

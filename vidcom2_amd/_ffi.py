@@ -49,8 +49,8 @@ _SIGNATURES = {
     "vc2_scores_phase1": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp],
     "vc2_scores_phase2": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp, _vp,
                           _vp, _vp, _vp],
-    "vc2_video_centre_blocks": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp,
-                                _i32, _vp],
+    "vc2_video_centre_blocks": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _sz,
+                                _vp, _i32, _vp],
     "vc2_scores_phase2_blocks": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp,
                                  _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,

@@ -1230,7 +1230,7 @@ __device__ float wave_l1_group(const void* __restrict__ x, int D, int col, const
 template <int DT>
 __device__ float wave_cascade_final(const float* l1, int64_t nb, const void* __restrict__ x, int D, int col,
                                     const float* __restrict__ den, int64_t r0, int rs, int64_t n, int lane,
-                                    int lp = 4) {
+                                    int lp = 4, const float* __restrict__ tail_raw = nullptr) {
   const int B = 1 << lp;
   const int n1c = int(nb >> lp);                              // complete level-1 groups
   const int n2 = n1c >> lp;                                   // complete level-2 groups
@@ -1250,7 +1250,7 @@ __device__ float wave_cascade_final(const float* l1, int64_t nb, const void* __r
   const float acc1 = (nb & (B - 1)) ? l1[n1c] : 0.f;
   // the < B leftover rows: fetched by as many lanes at once, added in row order
   const int ntail = int(n - (nb << lp));
-  const float tv = lane < ntail ? xhat_at<DT>(x, r0 + ((nb << lp) + lane) * rs, D, col, den) : 0.f;
+  const float tv = lane < ntail ? (tail_raw ? tail_raw[lane] : xhat_at<DT>(x, r0 + ((nb << lp) + lane) * rs, D, col, den)) : 0.f;
   float r = 0.f;
   for (int u = 0; u < ntail; ++u) r += __shfl(tv, u, 64);
   r += acc1; r += acc2; r += acc3;
@@ -1623,11 +1623,20 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
 
 // ---- frame-sharded pass: the video-centre replay across ranks ------------------------------------------------
 // Every rank flags the same columns (the flags come from the all-gathered group sums).  Slot j = the j-th flagged
-// column in ascending order.  k_vc_blocks: level-0 sums of MY rows -- blocks of B = 2^lp consecutive rows (lp =
-// cascade_lp(R_total): 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 beyond), added in row order -- for the
-// first `cap` flagged columns, in rows of `bstride` = R_local / 16 floats whatever B is; these are all-gathered (rank
-// order = row order) and k_vc_finish runs the rest of torch's cascade over the whole video's blocks.  Needs
-// rows-per-rank % B == 0 (blocks do not straddle ranks) and the cascade's plain form (column in a full group of 32).
+// column in ascending order.  The cascade's level-0 blocks are B = 2^lp consecutive rows OF THE VIDEO (lp =
+// cascade_lp(R_total): 16 rows up to 2^19 tokens, 32 up to 2^23, 64 beyond), so a rank whose row count is not a
+// multiple of B holds the tail of a block that started in the previous rank and the head of one that ends in the next.
+// k_vc_blocks writes, per slot, a record of kVcRec(R_local) floats:
+//     [0, 64)   the x^ values of my first h rows (the end of a block begun by the previous rank), in row order
+//     [64, 128) the x^ values of my last t rows (the beginning of a block the next rank ends)
+//     [128, ..) the sums of my complete blocks (rows added in order)
+// The records are all-gathered (rank order = row order) and k_vc_finish runs the rest of torch's cascade over the
+// whole video: a straddling block is its tail values, then its head values, added one by one; the video's last
+// R_total % B rows (the cascade's tail) are the last rank's tail values.  Needs R_local >= B (a block meets at most
+// two ranks), equal row counts per rank, and the cascade's plain form (column in a full group of 32).
+constexpr int kVcEdge = 64;
+__host__ __device__ inline int64_t vc_rec_floats(int64_t R_local) { return 2 * kVcEdge + R_local / 16 + 1; }
+__host__ __device__ inline int vc_head_rows(int64_t row0, int B) { return int((B - row0 % B) % B); }
 __device__ __forceinline__ int nth_flagged_column(const uint8_t* __restrict__ vflag, int C, int j, int lane) {
   // lane-contiguous chunks, wave scan; returns the column of the j-th set flag or -1 (same value in every lane)
   const int E = (C + 63) / 64;
@@ -1648,23 +1657,32 @@ __device__ __forceinline__ int nth_flagged_column(const uint8_t* __restrict__ vf
 template <int DT>
 __global__ __launch_bounds__(64) void k_vc_blocks(const uint8_t* __restrict__ vflag, int C, const void* __restrict__ x,
                                                   int D, const int* __restrict__ cols, const int* __restrict__ spos,
-                                                  const float* __restrict__ den, int64_t nb_local, int lp,
-                                                  int64_t bstride, float* __restrict__ blocks_out) {
+                                                  const float* __restrict__ den, int64_t R_local, int64_t row0, int lp,
+                                                  float* __restrict__ blocks_out) {
   const int lane = threadIdx.x, j = blockIdx.y;
   const int cc = nth_flagged_column(vflag, C, j, lane);
   if (cc < 0) return;
   const int col = cols ? cols[cc] : cc;
+  const int B = 1 << lp;
+  const int h = int(min<int64_t>(R_local, vc_head_rows(row0, B)));
+  const int64_t nb = (R_local - h) >> lp;
+  const int t = int(R_local - h - (nb << lp));
+  float* rec = blocks_out + int64_t(j) * vc_rec_floats(R_local);
+  if (blockIdx.x == gridDim.x - 1) {                            // the raw edges
+    if (lane < h) rec[lane] = xhat_at<DT>(x, lane, D, col, den);
+    if (lane < t) rec[kVcEdge + lane] = xhat_at<DT>(x, h + (nb << lp) + lane, D, col, den);
+    return;
+  }
   const int64_t b = int64_t(blockIdx.x) * 64 + lane;
-  if (b >= nb_local) return;
-  blocks_out[int64_t(j) * bstride + b] = block_sum_rows<DT>(x, D, col, den, 0, 1, b << lp, lp);
+  if (b >= nb) return;
+  rec[2 * kVcEdge + b] = block_sum_rows<DT>(x, D, col, den, h, 1, b << lp, lp);
 }
 
 template <int DT>
 __global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ vflag, int C,
                                                    const int* __restrict__ spos, const float* __restrict__ blocks_all,
-                                                   int world, int cap, int64_t nb_local, int64_t bstride,
-                                                   int64_t R_total, float* __restrict__ vc,
-                                                   int* __restrict__ fragile_count) {
+                                                   int world, int cap, int64_t R_local, int64_t R_total,
+                                                   float* __restrict__ vc, int* __restrict__ fragile_count) {
   __shared__ float l1[kL1Cap + 4];
   const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x;
   const int cc = nth_flagged_column(vflag, C, j, lane);
@@ -1673,23 +1691,39 @@ __global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ v
   const int sp = spos ? spos[cc] : cc;
   if (sp >= (C / group) * group) return;                        // row_sum's interleaved chains: not replayed here
   const int lp = cascade_lp(R_total), B = 1 << lp;
-  const int64_t nbv = R_total >> lp;                            // (R_total % B == 0: checked by the caller)
+  const int64_t rec = vc_rec_floats(R_local);
+  auto record = [&](int64_t w) { return blocks_all + (w * cap + j) * rec; };
+  // the level-0 sum of the video's block b: a rank's own complete block, or the tail of one rank continued by the head
+  // of the next (row order)
+  auto block_value = [&](int64_t b) -> float {
+    const int64_t g0 = b << lp, w = g0 / R_local, off = g0 - w * R_local;
+    const int hw = vc_head_rows(w * R_local, B);
+    if (off + B <= R_local) return record(w)[2 * kVcEdge + ((off - hw) >> lp)];
+    const int tw = int(R_local - off);                           // rows of the block that rank w holds (its tail)
+    const float* ta = record(w) + kVcEdge;
+    const float* he = record(w + 1);
+    float a = ta[0];
+    for (int u = 1; u < tw; ++u) a += ta[u];
+    for (int u = 0; u < B - tw; ++u) a += he[u];
+    return a;
+  };
+  const int64_t nbv = R_total >> lp;
   const int G1 = int((nbv + B - 1) >> lp);
   for (int g = tid; g < G1; g += 256) {                         // level 1: B block sums in block order
     const int64_t b0 = int64_t(g) << lp;
     const int nbl = int(min<int64_t>(B, nbv - b0));
     float a = 0.f;
     for (int u = 0; u < nbl; ++u) {
-      const int64_t b = b0 + u;
-      const int64_t w = b / nb_local, bl = b - w * nb_local;
-      const float t = blocks_all[(w * cap + j) * bstride + bl];
+      const float t = block_value(b0 + u);
       a = u == 0 ? t : a + t;
     }
     l1[g] = a;
   }
   __syncthreads();
   if (tid < 64) {
-    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, nbv << lp, lane, lp);   // (no tail rows)
+    // the cascade's tail (R_total % B rows): the last rank's tail values
+    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, R_total, lane, lp,
+                                           record(world - 1) + kVcEdge);
     if (lane == 0) {
       vc[cc] = rnT<DT>(s / float(R_total));
       if (fragile_count) atomicSub(fragile_count, 1);            // one flagged column less that kept its exact mean
@@ -3203,15 +3237,16 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
 
 // can the frame-sharded pass replay its video-centre means (see k_vc_blocks)?
 static bool vc_blocks_ok(const Plan& p, int64_t R_total, int strict) {
-  const int64_t B = int64_t(1) << cascade_lp(R_total);
-  return strict != 0 && p.dt != VC2_F32 && p.R % B == 0 && R_total % B == 0 && cascade_modelled(R_total);
+  const int64_t B = int64_t(1) << cascade_lp(R_total);      // (a level-0 block meets at most two ranks)
+  return strict != 0 && p.dt != VC2_F32 && p.R >= B && R_total % p.R == 0 && cascade_modelled(R_total);
 }
 
 int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
                             const int32_t* spos, const double* csum_all, int64_t P, int64_t csum_stride,
-                            int64_t rows_per_rank, int64_t R_total, void* ws, size_t ws_bytes, float* blocks_out, int cap,
-                            void* stream) {
-  if (!x || !csum_all || !blocks_out || P <= 0 || csum_stride < C || cap <= 0 || rows_per_rank < 0 ||
+                            int64_t rows_per_rank, int64_t R_total, int64_t row0, void* ws, size_t ws_bytes,
+                            float* blocks_out, int cap, void* stream) {
+  if (!x || !csum_all || !blocks_out || P <= 0 || csum_stride < C || cap <= 0 || rows_per_rank < 0 || row0 < 0 ||
+      row0 + F * N > R_total ||
       (rows_per_rank > 0 && (rows_per_rank % 2 || P % rows_per_rank)))
     return fail(VC2_ERR_ARG, "bad video_centre_blocks arguments");
   { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
@@ -3230,10 +3265,10 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
                                             int(rows_per_rank), margin_depth(R_total, cs0.strict), FrameStatSrc{},
                                             (const float*)nullptr, 0));
   const int lpv = cascade_lp(R_total);
-  const int64_t nb = p.R >> lpv;
-  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64)), unsigned(cap)), dim3(64), 0, st,
-                                            vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), nb, lpv,
-                                            p.R / 16, blocks_out));
+  const int64_t nb = p.R >> lpv;                               // (at most; one more grid column for the raw edges)
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64) + 1), unsigned(cap)), dim3(64), 0,
+                                            st, vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), p.R, row0,
+                                            lpv, blocks_out));
   return check_launch("video_centre_blocks");
 }
 
@@ -3274,8 +3309,7 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   if (have_blocks)
     VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_finish<DT>), dim3(unsigned(cap)), dim3(256), 0, st,
                                               wsp<uint8_t>(ws, p.o_mask), int(C), spos, blocks_all, world, cap,
-                                              p.R >> cascade_lp(R_total), p.R / 16, R_total, wsp<float>(ws, p.o_vc),
-                                              wsp<int>(ws, p.o_ticket) + 5));
+                                              p.R, R_total, wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket) + 5));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, make_chanset(p, cols, spos, C), ws, v_T, f_T, total, s, st);

@@ -70,10 +70,11 @@ class HipStages:
         self.idx = torch.empty(self.cap, dtype=torch.int64, device=self.device)
         self.ks = torch.empty(F, dtype=torch.int64, device=self.device)
         self.kout = torch.zeros(4, dtype=torch.int64, device=self.device)     # K, capacity overflow, fragile centre columns
-        # exchange 2b (video-centre replay): level-0 block sums of this rank's rows for up to VC_CAP flagged columns
+        # exchange 2b (video-centre replay): level-0 block sums of this rank's rows for up to vc_cap flagged columns
         self.vc_cap = int(vc_cap)                             # flagged columns whose blocks one exchange carries
-        self.vc_replay = dtype != torch.float32 and (F * N) % 16 == 0
-        self.blocks = torch.zeros((self.vc_cap, max(1, F * N // 16)), dtype=torch.float32, device=self.device)
+        self.vc_replay = dtype != torch.float32
+        # per flagged column: 64 + 64 raw edge values and the sums of this rank's complete blocks (include/vc2.h)
+        self.blocks = torch.zeros((self.vc_cap, 129 + F * N // 16), dtype=torch.float32, device=self.device)
         self.rows = torch.empty((self.cap, D), dtype=dtype, device=self.device) if gather else None
 
         # device pointers of the fixed buffers, resolved once: the per-pass host work is five C calls plus
@@ -110,21 +111,24 @@ class HipStages:
               "vc2_scores_phase1")
         return self.csum
 
-    def vc_blocks(self, x, csum_all, R_total):
-        """Exchange 2b: this rank's level-0 block sums of the boundary-near video-centre columns, or None when the
-        replay does not apply (fp32, exact mode, rows per rank not a multiple of the cascade's block -- 16 rows up to
-        2^19 tokens per video, 32 up to 2^23, 64 beyond --, more tokens than the replay models) -- a decision every
-        rank takes identically."""
+    def vc_blocks(self, x, csum_all, R_total, f0=0):
+        """Exchange 2b: this rank's level-0 block sums (and the raw values of the blocks it shares with its neighbours)
+        of the boundary-near video-centre columns, or None when the replay does not apply (fp32, exact mode, fewer rows
+        per rank than the cascade's block -- 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 beyond --, unequal
+        ranks, more tokens than the replay models) -- a decision every rank takes identically.  f0 = the video index
+        of this rank's first frame."""
         from .vidcom2 import cascade_level_power, cascade_modelled
         B = 1 << cascade_level_power(R_total)
-        if (not self.vc_replay or _ffi.get_mode() != "torch" or not cascade_modelled(R_total) or R_total % B != 0
-                or (self.F * self.N) % B != 0):
+        Rl = self.F * self.N
+        if (not self.vc_replay or _ffi.get_mode() != "torch" or not cascade_modelled(R_total) or Rl < B
+                or R_total % Rl != 0):
             return None
         p = self._p
         parts = csum_all.reshape(-1, csum_all.shape[-1])
         check(self._L.vc2_video_centre_blocks(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
                                               ptr(parts), parts.shape[0], parts.shape[1], self.csum.shape[0], R_total,
-                                              p["ws"], self._ws_n, p["blocks"], self.vc_cap, self._st()),
+                                              int(f0) * self.N, p["ws"], self._ws_n, p["blocks"], self.vc_cap,
+                                              self._st()),
               "vc2_video_centre_blocks")
         return self.blocks
 
@@ -155,7 +159,7 @@ class HipStages:
         if vc_fragile and _ffi.get_mode() == "torch":
             import warnings
             warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within the replay margin "
-                          "of a rounding boundary and could not be replayed across ranks (rows per rank not a multiple of 16 -- 32 beyond 2^19 tokens per video --, "
+                          "of a rounding boundary and could not be replayed across ranks (fewer rows per rank than a cascade block, unequal ranks, "
                           f"more than {self.vc_cap} such columns, or a channel count that is not a multiple of 32); they keep "
                           "the exactly rounded mean, the reference's fp32 summation order could round the other way.",
                           RuntimeWarning, stacklevel=2)
@@ -250,8 +254,8 @@ class ShardedCompressor:
         stats_all = self._gather("stats", st.chan_stats(x_local))               # exchange 1: [W, 2, D] fp64
         st.select_channels(stats_all, R_total)
         csum_all = self._gather("csum", st.phase1(x_local))                     # exchange 2: [W, D] fp64
-        blocks = st.vc_blocks(x_local, csum_all, R_total) if hasattr(st, "vc_blocks") else None
-        if blocks is not None:                                                   # exchange 2b: [W, 16, R_local/16] fp32
+        blocks = st.vc_blocks(x_local, csum_all, R_total, self.f0) if hasattr(st, "vc_blocks") else None
+        if blocks is not None:                                                   # exchange 2b: [W, vc_cap, 129 + R_local/16] fp32
             s_loc = st.phase2(x_local, csum_all, R_total, self._gather("blocks", blocks))
         else:
             s_loc = st.phase2(x_local, csum_all, R_total)
