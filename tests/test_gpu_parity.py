@@ -549,3 +549,19 @@ def test_adversarial_centre_means(c, mode):
         assert not same_scores, "the empirical margin now covers this case: drop it from the list"
         return
     assert same_scores
+
+
+@pytest.mark.parametrize("shape", [(1024, 16, 256, "bf16"), (300, 7, 128, "f16"), (640, 40, 512, "bf16"), (97, 33, 192, "f16"),
+                                   (2000, 4, 64, "bf16")], ids=lambda s_: "x".join(map(str, s_)))
+def test_many_short_frames(shape):
+    """Sweep 2 cuts the rows into equal chunks whatever the frames are: with short frames a chunk holds several whole
+    frames and pieces of two more (one flush of the column sums per segment).  Scores, budgets and kept indices
+    against the oracle."""
+    F, N, D, dn = shape
+    x = make_input(F, N, D, dn, 5, "drift")
+    O.set_mode("torch")
+    ref = O.compress_indices(x, N, 0.25)
+    got = vc.compress(x.to(dev()), N, 0.25, want_scores=True)
+    assert nan_eq(got.v_score, ref["v"]) and nan_eq(got.f_score, ref["f"])
+    assert got.ks.cpu().tolist() == ref["ks"].tolist()
+    assert torch.equal(got.global_idx.cpu(), ref["global_idx"])
