@@ -1598,22 +1598,23 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
       const int l0 = lane & ~(B - 1);
       float sgrp = __shfl(a, l0, 64);                // the block sums of my group, added in block order
       for (int u = 1; u < B; ++u) { const float t = __shfl(a, l0 + u, 64); if (u < nbl) sgrp += t; }
-      // (published as an agent-scope atomic store -- it goes to the coherence point itself; a release fence instead
-      // would write back the XCD's whole L2, an acquire fence invalidate it: NOTES_r03.md)
-      if (li == 0 && g1 < G1v)
-        __hip_atomic_store(&l1g[int64_t(cc) * vstride + g1], sgrp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (li == 0 && g1 < G1v) l1g[int64_t(cc) * vstride + g1] = sgrp;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my groups have arrived ...
+  // Release / acquire FENCES around the ticket.  (A fence-free variant -- the groups as relaxed agent-scope atomic
+  // stores, s_waitcnt vmcnt(0), a relaxed ticket, coherent loads in the last arriver -- was 0.8 us faster and WRONG:
+  // the soak caught a stale group in 1 of 972 cases, 5 of 40 repeats of that case.  vmcnt(0) does not mean the
+  // write-through has reached the point the other XCDs read from.)
+  __threadfence();                                   // release my groups ...
   int last = 0;
-  if (lane == 0) last = __hip_atomic_fetch_add(&vtick[bx], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == Y - 1;
-  if (!__shfl(last, 0, 64)) return;                  // ... and the last wave to arrive reads everyone's (coherent loads)
+  if (lane == 0) last = atomicAdd(&vtick[bx], 1) == Y - 1;
+  if (!__shfl(last, 0, 64)) return;
+  __threadfence();                                   // ... acquire everyone else's
   for (uint64_t m = flagged; m; m &= m - 1) {
     const int vl = __builtin_ctzll(m), cc = bx * 64 + vl;
     const int col = __shfl(my_col, vl, 64), sp = __shfl(my_sp, vl, 64);
     if (sp >= simple_end) continue;
-    for (int g1 = lane; g1 < G1v; g1 += 64)
-      l1s[g1] = __hip_atomic_load(&l1g[int64_t(cc) * vstride + g1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int g1 = lane; g1 < G1v; g1 += 64) l1s[g1] = l1g[int64_t(cc) * vstride + g1];
     wave_lds_fence();
     const float s = wave_cascade_final<DT>(l1s, nbv, x, D, col, den, 0, 1, R, lane, lp);
     wave_lds_fence();
