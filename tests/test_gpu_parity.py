@@ -565,3 +565,17 @@ def test_many_short_frames(shape):
     assert nan_eq(got.v_score, ref["v"]) and nan_eq(got.f_score, ref["f"])
     assert got.ks.cpu().tolist() == ref["ks"].tolist()
     assert torch.equal(got.global_idx.cpu(), ref["global_idx"])
+
+
+def test_video_centre_hand_over_is_race_free():
+    """8 x 324 x 3584 fp16, seed 9428 (found by tests/tools/soak_gpu_vs_oracle.py): a video-centre mean sits EXACTLY on
+    an fp16 rounding midpoint, so its replay decides a score -- and the replay's level-1 groups travel between
+    workgroups of one launch.  A fence-free variant of that hand-over returned a stale group in one run of eight; the
+    scores must equal the oracle's in every one of 40 runs."""
+    x = make_input(8, 324, 3584, "f16", 9428, "drift")
+    O.set_mode("torch")
+    ref = O.compress_indices(x, 324, 0.25)
+    xd = x.to(dev())
+    for run in range(40):
+        got = vc.compress(xd, 324, 0.25, want_scores=True)
+        assert torch.equal(got.v_score.cpu(), ref["v"]) and torch.equal(got.f_score.cpu(), ref["f"]), f"run {run}"
