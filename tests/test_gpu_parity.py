@@ -579,3 +579,26 @@ def test_video_centre_hand_over_is_race_free():
     for run in range(40):
         got = vc.compress(xd, 324, 0.25, want_scores=True)
         assert torch.equal(got.v_score.cpu(), ref["v"]) and torch.equal(got.f_score.cpu(), ref["f"]), f"run {run}"
+
+
+@pytest.mark.parametrize("case", [(128, 196, 3584, "bf16", "drift"), (32, 196, 3584, "f16", "iid"), (64, 324, 1024, "bf16", "cancel")],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_runs_are_bitwise_repeatable(case):
+    """DESIGN.md "Determinism": no floating-point atomics, fixed reduction orders, the hand-overs between workgroups
+    fenced -- 25 runs of one input (default mode, then the proven-margin mode with its many replays) give the same
+    bytes: scores, budgets, kept indices, kept rows."""
+    F, N, D, dn, dist = case
+    xd = make_input(F, N, D, dn, 11, dist).to(dev())
+    for mode in ("torch", "torch_proven"):
+        try:
+            _ffi.set_mode(mode)
+            first = None
+            for run in range(25 if mode == "torch" else 8):
+                got = vc.compress(xd, N, 0.25, want_scores=True)
+                sig = (synth.sha256_tensor(got.v_score.cpu()), synth.sha256_tensor(got.f_score.cpu()),
+                       synth.sha256_tensor(got.global_idx.cpu()), synth.sha256_tensor(got.rows.cpu()), got.ks.cpu().tolist())
+                if first is None:
+                    first = sig
+                assert sig == first, f"{mode}: run {run} differs from run 0"
+        finally:
+            _ffi.set_mode("torch")
