@@ -196,6 +196,22 @@ __device__ __forceinline__ float wave_max_nanprop(float v) {  // NaN wins (torch
   return v;
 }
 
+// the same through DPP lane moves (VALU latency instead of six LDS-crossbar round trips); every lane returns the result
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_nanprop(float v) {
+  const float t = __int_as_float(__builtin_amdgcn_update_dpp(int(0xFF800000u), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+  return (v != v) ? v : ((t != t) ? t : fmaxf(v, t));          // (rows outside ROW_MASK see -inf: the identity)
+}
+__device__ __forceinline__ float wave_max_nanprop_bcast(float v) {
+  v = dpp_max_nanprop<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v = dpp_max_nanprop<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v = dpp_max_nanprop<0x141, 0xF>(v);    // row_half_mirror
+  v = dpp_max_nanprop<0x140, 0xF>(v);    // row_mirror        -> every lane holds its 16-lane row maximum
+  v = dpp_max_nanprop<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  v = dpp_max_nanprop<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave maximum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // torch mean (ReduceOps.cpp mean_out): fp32 sum -> fp32 divide by the count -> cast to T.
 template <int DT> __device__ __forceinline__ float mean_T(double exact_sum, int64_t count) {
   const float s = static_cast<float>(exact_sum);

@@ -2238,7 +2238,7 @@ constexpr int kFrameNT = 256;
 constexpr int kFusedScalesMaxF = 1024;      // up to this many frames every k_select workgroup derives the budgets itself
 
 __device__ __forceinline__ float block_max_nanprop_256(float v, float* sm) {
-  v = wave_max_nanprop(v);
+  v = wave_max_nanprop_bcast(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -2380,7 +2380,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       ee[j] = 0.f;
       if (i < F) { ee[j] = float(exp(double(zz[j] - zmax))); es += double(ee[j]); }
     }
-    es = wave_sum(es);
+    es = wave_sum_bcast(es);
     __syncthreads();
     if (lane == 0) smd[wave] = es;
     __syncthreads();
@@ -2392,7 +2392,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       pp[j] = 0.f;
       if (i < F) { pp[j] = rnT<DT>(float(double(ee[j]) / esum)); ps += double(pp[j]); }
     }
-    ps = wave_sum(ps);
+    ps = wave_sum_bcast(ps);
     __syncthreads();
     if (lane == 0) smd[wave] = ps;
     __syncthreads();
