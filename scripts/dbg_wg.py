@@ -12,11 +12,11 @@ F, N, D = 128, 196, 3584
 x = synth.make(F, N, D, torch.bfloat16, 0, sys.argv[2] if len(sys.argv) > 2 else "drift").cuda()
 plan = vc.vidcom2.CompressPlan(F, N, D, torch.bfloat16, x.device, 0.25)
 L = ctypes.CDLL(_ffi.LIB_PATH)
-buf = (ctypes.c_ulonglong * (3 * 2 * 4096))()
+buf = (ctypes.c_ulonglong * (4 * 2 * 4096))()
 for it in range(5):
     plan.enqueue(x); plan.finish()
 L.vc2_debug_wg(buf)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(3, 2, 4096).astype(np.float64) / 100.0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(4, 2, 4096).astype(np.float64) / 100.0
 for slot, name in ((1, "k_norm_colsum"), (2, "k_dist")):
     b, e = a[slot, 0], a[slot, 1]
     m = e > 0
@@ -35,3 +35,7 @@ pct = lambda v: " ".join(f"{np.percentile(v, q):6.1f}" for q in (0, 10, 50, 90, 
 print("k_dist row loop:", pct(rl), "| phase 2:", pct(r2), "| phase 3:", pct(r3))
 busy = r2 > 1.0
 print(f"   workgroups with replays: {busy.sum()}; their phase 2: {pct(r2[busy]) if busy.any() else ''}; row-loop end of those: {pct((p2 - t0)[m][busy]) if busy.any() else ''}")
+sqd, smd = a[3, 0], a[3, 1]
+one = busy & ((sqd - p2)[m] > 0) & ((sqd - p2)[m] < 50)
+if one.any():
+    print("   first entry: squares ready after", pct((sqd - p2)[m][one]), "| cascade sum + barrier", pct((smd - sqd)[m][one]))

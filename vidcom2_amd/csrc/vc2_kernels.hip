@@ -62,7 +62,7 @@ __device__ __forceinline__ void dbg_stamp(int tag) {      // (one lane) wall clo
 }
 #define VC2_STAMP(tag) dbg_stamp(tag)
 // per-workgroup begin / end times of the three sweeps (slot 0: k_chan_stats, 1: k_norm_colsum, 2: k_dist)
-namespace vc2 { __device__ unsigned long long g_dbg_wg[3][2][4096]; }
+namespace vc2 { __device__ unsigned long long g_dbg_wg[4][2][4096]; }
 #define VC2_WGTIME(slot, which) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_wg[slot][which][blockIdx.x] = wall_clock64(); } while (0)
 #else
 #define VC2_STAMP(tag) ((void)0)
@@ -2024,25 +2024,55 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   VC2_WGTIME(0, 0);                                               // (debug builds: phase 2 begins / ends)
   if (strict) {
     const int cnt = *lcount;
-    float* sq = reinterpret_cast<float*>(smem);
+    // The row comes back by DMA into wave 0's (idle) row buffer while every thread fetches its column indices, sorted
+    // positions and centre values -- ONE round of global loads per entry instead of two dependent ones (cols -> x) at
+    // a time when 900 other workgroups are streaming rows (in-kernel stamps: 4.1 us of an entry's 5.2 were spent
+    // getting the squares into LDS).  The squares go to wave 1's buffer.
+    constexpr int kP2 = (NPLB * 64 + kRowWaves * 64 - 1) / (kRowWaves * 64);        // positions per thread
+    const bool dma = DT != VC2_F32 && VEC > 1 && size_t(C) * 4 + 16 <= rowb && C <= NPLB * 64;
+    float* sq = reinterpret_cast<float*>(dma ? smem + rowb : smem);
     for (int e = 0; e < cnt; ++e) {
       const int ent = list[e];
       const int nl = ent >> 1, which = ent & 1;
       const int64_t row = int64_t(f) * N + n0 + nl;
       const double inv = 1.0 / double(dens[nl]);
       const float* cen = which ? fc + int64_t(f) * C : vc;
-      for (int p = tid; p < C; p += kRowWaves * 64) {
-        const int col = cols ? cols[p] : p, spp = spos ? spos[p] : p;
-        const float xh = rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), inv));
-        const float a = rnT<DT>(xh - cen[p]);
-        sq[spp] = rnT<DT>(a * a);
+      if (dma) {
+        if (wave == 0) row_issue<DT, VEC, VC2_AUX_S3>(x, row, D, CV, smem, lane);
+        int colv[kP2], sppv[kP2];
+        float cev[kP2];
+#pragma unroll
+        for (int i = 0; i < kP2; ++i) {
+          const int p = tid + i * kRowWaves * 64, pc = p < C ? p : C - 1;
+          colv[i] = cols ? cols[pc] : pc;
+          sppv[i] = spos ? spos[pc] : pc;
+          cev[i] = cen[pc];
+        }
+        if (wave == 0) row_wait();
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kP2; ++i) {
+          const int p = tid + i * kRowWaves * 64;
+          const float xh = rnT<DT>(div_via_f64(lds_elem<DT>(smem, colv[i]), inv));
+          const float a = rnT<DT>(xh - cev[i]);
+          if (p < C) sq[sppv[i]] = rnT<DT>(a * a);
+        }
+      } else {
+        for (int p = tid; p < C; p += kRowWaves * 64) {
+          const int col = cols ? cols[p] : p, spp = spos ? spos[p] : p;
+          const float xh = rnT<DT>(div_via_f64(ldT<DT>(x, row * D + col), inv));
+          const float a = rnT<DT>(xh - cen[p]);
+          sq[spp] = rnT<DT>(a * a);
+        }
       }
       __syncthreads();
+      if (e == 0) VC2_WGTIME(3, 0);                              // (debug builds: first entry's squares are in LDS)
       if (wave == 0) {
         const float r = sum_torch_order<DT>(sq, C, lane);
         if (lane == 0) dists[ent] = rnT<DT>(r);
       }
       __syncthreads();
+      if (e == 0) VC2_WGTIME(3, 1);
     }
   }
   // ---- phase 3: Gaussian sums, total, partial frame sum ---------------------------------------------
@@ -3645,9 +3675,9 @@ int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, i
 }
 
 #ifdef VC2_DEBUG_TIMING
-int vc2_debug_wg(unsigned long long* out /*[3][2][4096]*/) {
+int vc2_debug_wg(unsigned long long* out /*[4][2][4096]*/) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 3 * 2 * 4096);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 4 * 2 * 4096);
   return 0;
 }
 int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {
