@@ -39,3 +39,7 @@ sqd, smd = a[3, 0], a[3, 1]
 one = busy & ((sqd - p2)[m] > 0) & ((sqd - p2)[m] < 50)
 if one.any():
     print("   first entry: squares ready after", pct((sqd - p2)[m][one]), "| cascade sum + barrier", pct((smd - sqd)[m][one]))
+# structure of the row-loop time: by XCD (blockIdx % 8), by split (blockIdx % 8 is also the split when S2 = 8!), by frame
+idx = np.arange(4096)[m]
+for name, key in (("blockIdx % 8", idx % 8), ("(blockIdx // 8) % 16", (idx // 8) % 16), ("blockIdx // 256", idx // 256)):
+    print("   row loop by", name, ":", " ".join(f"{rl[key == k].mean():.1f}" for k in np.unique(key)))

@@ -1842,12 +1842,20 @@ __device__ __forceinline__ void wave_totals_f32(float (&v)[K]) {
 // (Round 3 also built the other data flow -- sweep 2 materialising x^ for a sweep 3 that streams it: same bytes per
 // pass, measured 3 % SLOWER at the target shape, 90 MB more workspace; NOTES_r03.md.)
 constexpr int kDistMaxRows = 64;
+// first row of split j (of S) of an N-row frame: rows_j ~ N/S * (1 + a (1 - 2 j / (S - 1))), a = skew_q10 / 1024
+__host__ __device__ inline int dist_split_cut(int j, int S, int N, int skew_q10) {
+  if (j <= 0) return 0;
+  if (j >= S) return N;
+  const long long num = (long long)N * j * (1024 + skew_q10) * (S - 1) - (long long)N * skew_q10 * j * (j - 1);
+  const long long den = 1024LL * S * (S > 1 ? S - 1 : 1);
+  return int((num + den / 2) / den);
+}
 
 template <int DT, int VEC, int NPLB, int ACC>
 __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
                                                          const int* __restrict__ cols,
                                                          const int* __restrict__ spos, int strict, int S,
-                                                         int rows_per_split, const float* __restrict__ den,
+                                                         int rows_per_split, int skew_q10, const float* __restrict__ den,
                                                          const uint8_t* __restrict__ rflag,
                                                          const float* __restrict__ vc,
                                                          const float* __restrict__ fc,
@@ -1858,10 +1866,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   constexpr bool kFast = ACC == 1 && DT == VC2_BF16;
   const size_t rowb = row_lds_bytes(D, ES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int f = blockIdx.x / S, sp = blockIdx.x % S;
-  const int n0 = sp * rows_per_split;
-  const int n1 = min(N, n0 + rows_per_split);
+  // Workgroup b = split b / F of frame b % F, and the splits of a frame SHRINK with their number (skew_q10 / 1024 =
+  // relative excess of the first over the mean; dist_split_cut): the hardware issues from the oldest wave first, so of
+  // the four workgroups that share a CU for the whole sweep the first-dispatched one runs its rows 30 % faster than
+  // the last (in-kernel stamps, scripts/dbg_wg.py: row loops of 25 rows ended at 21.8 / 23.5 / 25.6 / 28.6 us by
+  // dispatch quartile) -- with equal splits the sweep waited for the youngest workgroups, and for their replays.
+  const int F_ = int(gridDim.x) / S;
+  const int sp = int(blockIdx.x) / F_, f = int(blockIdx.x) - sp * F_;
+  const int n0 = dist_split_cut(sp, S, N, skew_q10), n1 = dist_split_cut(sp + 1, S, N, skew_q10);
   const int nrows = n1 - n0;
+  (void)rows_per_split;
   // One row buffer per wave and no intra-wave prefetch: measured faster than double buffering here
   // (45 vs 50 us at 128x196x3584) because the smaller LDS footprint doubles the resident waves.
   unsigned char* buf0 = smem + size_t(wave) * rowb;               // [kRowWaves][rowb]; phase 2: float sq[C]
@@ -2103,7 +2117,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
       vd = double(v);
     }
     vd = wave_sum(vd);                                            // fixed tree over T values: exact in fp64
-    if (lane == 0) vpart[blockIdx.x] = vd;
+    if (lane == 0) vpart[f * S + sp] = vd;
     if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) VC2_STAMP(709);
     VC2_WGTIME(2, 1);
   }
@@ -2659,6 +2673,7 @@ struct Plan {
   int S, S_q, S_W;              // sweep 2: S_W chunks of S_q consecutive rows (frame boundaries inside a chunk cut it in
                                 //   segments); a frame's segments fill its first slots of S in `part`
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
+  int skew2_q10;                // how much the first split of a frame exceeds the mean, in 1/1024 (k_dist)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
       o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_tmp_f32, total_bytes;
@@ -2728,7 +2743,13 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
     int64_t rps = std::max<int64_t>(VC2_DIST_RPS_MIN, std::min<int64_t>(25, cdiv(p->R, VC2_DIST_WGS)));
     rps = std::min<int64_t>(rps, N);
     p->S2 = int(cdiv(N, rps));
-    p->rows_per_split2 = int(cdiv(N, p->S2));
+#ifndef VC2_DIST_SKEW
+#define VC2_DIST_SKEW 138
+#endif
+    // the skew pays when the launch is ONE wave of workgroups with several of them per CU (4 at 1024 on 256 CUs)
+    const int64_t wgs = F * p->S2;
+    p->skew2_q10 = (p->S2 >= 4 && wgs > 512 && wgs <= 1024) ? int(VC2_DIST_SKEW * (wgs - 256) / 768) : 0;
+    p->rows_per_split2 = dist_split_cut(1, p->S2, int(N), p->skew2_q10);          // the longest split
   }
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += align_up(bytes); return r; };
@@ -2973,7 +2994,7 @@ int launch_dist_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
   if (rc) return rc;
   ProfScope ps_(KID_DIST, st);
   hipLaunchKernelGGL((k_dist<DT, VEC, NPLB, ACC>), dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st, x,
-                     int(p.N), int(p.D), p.CV, C, cols, cs.spos, cs.strict, p.S2, p.rows_per_split2,
+                     int(p.N), int(p.D), p.CV, C, cols, cs.spos, cs.strict, p.S2, p.rows_per_split2, p.skew2_q10,
                      wsp<float>(ws, p.o_den), wsp<uint8_t>(ws, p.o_rflag), wsp<float>(ws, p.o_vc),
                      wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total, wsp<double>(ws, p.o_vpart));
   return VC2_OK;
