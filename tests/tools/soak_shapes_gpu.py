@@ -8,7 +8,7 @@ from vidcom2_amd import synth, _ffi
 from vidcom2_amd.vidcom2 import compress
 O.set_mode("torch"); _ffi.set_mode("torch")
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-bad = n = 0
+bad = n = bad3 = 0
 t0 = time.time()
 for seed in range(lo, hi):
     rng = random.Random(seed)
@@ -42,5 +42,13 @@ for seed in range(lo, hi):
     n += 1
     if not ok:
         bad += 1
-        print("MISMATCH", seed, F, N, D, dt, dist, base, flush=True)
-print(f"{n} shape cases, {bad} mismatches, {time.time() - t0:.0f}s")
+        proven = None
+        if dt != torch.float32:              # the proven-margin mode must get it (`cancel` inputs)
+            _ffi.set_mode("torch_proven")
+            r3 = compress(x.cuda(), N, base, want_scores=True)
+            _ffi.set_mode("torch")
+            proven = (torch.equal(r3.global_idx.cpu(), o["global_idx"]) and eq(r3.v_score.cpu(), o["v"])
+                      and eq(r3.f_score.cpu(), o["f"]) and torch.equal(r3.ks.cpu(), o["ks"]))
+            bad3 += 0 if proven else 1
+        print("MISMATCH", seed, F, N, D, dt, dist, base, "| torch_proven mode matches:", proven, flush=True)
+print(f"{n} shape cases, {bad} mismatches in the default mode ({bad3} of them also in the proven-margin mode), {time.time() - t0:.0f}s")
