@@ -56,6 +56,12 @@ const char* vc2_version(void);
  *   3            mode 1 with a PROVEN bound deciding which centre means are replayed (forward error bound of torch's
  *                cascade relative to sum |x^|, bounded from sweep 1's statistics) instead of mode 1's empirical 16 ulps:
  *                flags 50x more means, costs a third more time; the test-suite runs every fixture in both.
+ *   4            "robust": mode 1 whose margin for the FRAME-centre means has, besides the 16 ulps of the mean, a term
+ *                relative to sum |x^| over the frame (4 u A / n, A bounded from sweep 1's statistics and the frame's
+ *                smallest denominator, evaluated only for means that pass a cheap pre-test): the margin then grows under
+ *                cancellation, where torch's cascade errs by far more than ulps OF THE MEAN.  Reproduces the reference on
+ *                every adversarial fixture and soak case known (mode 1 misses 0.2 % of random `cancel` inputs); ~3 %
+ *                slower than mode 1.  In the stage call vc2_scores (no statistics sweep of its own) it acts like mode 1.
  *   (2: debug -- every value is replayed.)
  * fp32 inputs are unaffected.  vc2_set_mode is PROCESS-WIDE (default 1) and also drops the calling thread's own
  * override; vc2_set_thread_mode(mode) overrides it for the calling thread only (-1: follow the process-wide setting

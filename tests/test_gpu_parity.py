@@ -525,13 +525,14 @@ ADV = load_json("adversarial_cases.json")["cases"]
 ADV_BEYOND_THE_EMPIRICAL_MARGIN = {("f16", 16, 196, 512)}
 
 
-@pytest.mark.parametrize("mode", ["torch", "torch_proven"])
+@pytest.mark.parametrize("mode", ["torch", "torch_robust", "torch_proven"])
 @pytest.mark.parametrize("c", ADV, ids=lambda c: f"adv-{c['F']}x{c['N']}x{c['D']}-{c['dtype']}")
 def test_adversarial_centre_means(c, mode):
     """tests/golden/make_adversarial_golden.py: inputs BUILT so that torch's fp32 cascade decides centre-mean roundings
     (tiny addends meet a large running sum that later cancels: `frame_centres_decided_by_order` > 0 in the fixture)
     and the cascade's error is hundreds of ulps of the mean.  Scores, budgets and kept indices must equal the
-    reference's in the default mode and in the proven-margin mode."""
+    reference's in the default mode (with ONE pinned exception), in the robust mode (mode 4: the frame means' margin
+    also has a term relative to sum |x^|) and in the proven-margin mode."""
     x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
     assert synth.sha256_tensor(x) == c["x_sha256"]
     try:

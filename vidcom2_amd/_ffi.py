@@ -159,13 +159,14 @@ def profile_collect() -> dict:
 # 'torch_proven': 'torch' with a PROVEN error bound instead of the empirical 16-ulp margin deciding which centre means
 # are replayed (include/vc2.h vc2_set_mode, mode 3): same results wherever the empirical margin suffices -- the parity
 # suite asserts that on every fixture -- at a quarter more time per pass
-MODE_CODE = {"exact": 0, "torch": 1, "torch_proven": 3}
+MODE_CODE = {"exact": 0, "torch": 1, "torch_proven": 3, "torch_robust": 4}
 
 
 def set_mode(mode: str) -> None:
     """'torch' (default): bit-exact to the CPU reference in half precision (replays torch's fp32 accumulation
-    order where it decides a rounding); 'exact': every reduction correctly rounded; 'torch_proven': see MODE_CODE.
-    get_mode() answers 'torch' for both torch modes."""
+    order where it decides a rounding); 'exact': every reduction correctly rounded; 'torch_robust': 'torch' whose replay
+    margin for the frame-centre means also has a term relative to sum |x^| (passes every adversarial fixture, ~3 % slower);
+    'torch_proven': proven margins for all centre means (~45 % slower).  get_mode() answers 'torch' for all torch modes."""
     check(lib().vc2_set_mode(MODE_CODE[mode]), "vc2_set_mode")
 
 

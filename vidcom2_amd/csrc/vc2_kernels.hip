@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ tk, unsigned long long* __restrict__ fixq,
                                                                 int nfix_cap, uint8_t* __restrict__ rflag,
-                                                                OrderArgs rider) {
+                                                                OrderArgs rider, unsigned* __restrict__ dminkey) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   double acc[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
+  float dmin_w = INFINITY;                                        // this wave's smallest denominator of the segment
   int n = n0 + wave;
   if (n < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, int64_t(f) * N + n, D, CV, buf0, lane);
   for (; n < n1; n += kRowWaves) {
@@ -1042,6 +1043,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
         if (j < nfix_cap) __hip_atomic_store(fixq + j, fixq_pack(row, dn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (lane == 0) den_out[row] = dn;
+      dmin_w = fminf(dmin_w, dn);                                 // (NaN does not enter)
       return dn;
     };
     // rflag[row] = 1 marks the rows that divide exactly (consumed by sweep 3; bf16 in "torch order" mode)
@@ -1139,6 +1141,10 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
     part[(int64_t(f) * S + sp) * C + p] = t;
   }
+  // modes 3 / 4: the frame's smallest denominator for the centre-mean margins -- 0x7F800000 - bits, ONE atomicMax per
+  // wave and segment, issued last so that nothing waits for it (per row it was 200 atomics on each of 128 addresses
+  // and doubled the sweep; in front of the combine the workgroup waited out its round trip: +3 us); key 0 = none yet
+  if (lane == 0 && dminkey && dmin_w < INFINITY) atomicMax(dminkey + f, 0x7F800000u - __float_as_uint(fabsf(dmin_w)));
   seg_a = seg_b;
   if (seg_a < row_b) __syncthreads();                            // (the next segment refills the row buffers)
   }
@@ -1371,7 +1377,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
                                                                    const NormCorr* __restrict__ corr, int strict,
                                                                    int* __restrict__ vtick, FrameStatSrc fs,
                                                                    double kk, int want_bounds,
-                                                                   float* __restrict__ dmin_out) {
+                                                                   float* __restrict__ dmin_out, double kk_a,
+                                                                   const unsigned* __restrict__ dminkey) {
   __shared__ double sm[kCentreFL][64];
   __shared__ double sb[kCentreFL][64];
   __shared__ float l1s_all[kCentreFL][kCFixSolo];
@@ -1389,9 +1396,11 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     if (g == 0 && blockIdx.x == 0) VC2_STAMP(500);
   }
   // the frame's smallest denominator (wave fl = frame f): |x^| <= |x| / it.  (The loads are in flight with the ones below.)
-  float dmin = INFINITY;
-  const bool bounded = replay && (strict == 3 || want_bounds);      // margins relative to sum |x^| (mode 3; exchange 2)
-  if (bounded && f < F) for (int r = cl; r < N; r += 64) dmin = fminf(dmin, den[int64_t(f) * N + r]);   // (NaN rows do not enter)
+  // kk_a > 0 (mode 4 "robust", the pass's own sweep-1 partials at hand): the empirical margin OR a boundary within
+  // (kk_a A / n + 4 |q|) u -- the term that grows under cancellation (see the note at kFragileUlpsMean)
+  const bool bounded = replay && dminkey && (strict == 3 || want_bounds || kk_a > 0.0);   // margins relative to sum |x^|
+  // (sweep 2 left 0x7F800000 - bits(min den) per frame: one load instead of the frame's N denominators)
+  const float dmin = (bounded && f < F) ? __uint_as_float(0x7F800000u - dminkey[f]) : INFINITY;
   __syncthreads();
   double sf = 0.0, ab = 0.0;
   float q = 0.f;
@@ -1424,8 +1433,6 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
     }
   } else if (replay) {                             // (wave-uniform)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
     if (dmin_out && blockIdx.x == 0 && cl == 0 && f < F) dmin_out[f] = dmin;     // (k_video_centre's lazy bounds)
     if (active) {
       // A >= sum_r |x^[r, c]| over the frame (see mean_delta).  |x^| <= 1 gives A <= N: only a mean with a boundary
@@ -1433,10 +1440,12 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       // every group's bound with exchange 2, so all of them)
       bool near = all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk))
                                       : mean_near_T_boundary<DT>(q));
-      if ((want_bounds || (near && strict == 3)) && fs.part) {
+      const bool pre_a = !near && strict != 3 && kk_a > 0.0 && T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk_a));
+      if ((want_bounds || (near && strict == 3) || pre_a) && fs.part) {
         const double b = abs_sum_bound(fs.sumsq<DT>(f, cols ? cols[c] : c, x, D), N, dmin);
         ab = b < double(N) ? b : double(N);        // (NaN: N)
         if (near && !all && strict == 3) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk));
+        if (pre_a) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk_a));
       } else {
         ab = double(N);
       }
@@ -2676,7 +2685,7 @@ struct Plan {
   int skew2_q10;                // how much the first split of a frame exceeds the mean, in 1/1024 (k_dist)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_tmp_f32, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_dminkey, o_tmp_f32, total_bytes;
   int vstride;
 };
 
@@ -2779,7 +2788,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_scales_T = take(size_t(F) * 4);
   p->o_offs = take(size_t(F + 1) * 8);
   p->o_ticket = take(256);                                    // 64 ints (kTk*)
-  p->o_nfixlist = take(size_t(p->R) * 8);                     // 8-byte queue granules (fixq_pack)
+  p->o_nfixlist = take(size_t(p->R) * 8 + size_t(cdiv(F, 2)) * 8);   // 8-byte queue granules (fixq_pack); behind them, zeroed with them:
+  p->o_dminkey = p->o_nfixlist + size_t(p->R) * 8;            //   per frame 0x7F800000 - bits(smallest denominator) (sweep 2, atomicMax)
   p->o_corr = take(size_t(p->R) * sizeof(NormCorr));
   {
     const int lpv = cascade_lp(p->R);           // level-1 groups of a video-centre column (k_video_centre's scratch)
@@ -2880,7 +2890,7 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, vo
                                              0, st, (const double*)nullptr, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
                                              zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src,
                                              zero_queue_counters ? wsp<unsigned long long>(ws, p.o_nfixlist) : nullptr,
-                                             int(p.R)));
+                                             int(p.R + cdiv(p.F, 2))));
   } }
   return check_launch("chan_stats");
 }
@@ -2960,7 +2970,8 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_q, p.R,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
-                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider,
+                     ((cs.strict == 3 || cs.strict == 4) && DT != VC2_F32) ? wsp<unsigned>(ws, p.o_dminkey) : (unsigned*)nullptr);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -3016,8 +3027,11 @@ int launch_dist_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, con
 // sweep 2 + centres.  single_rank: also the video centre; else only the rank's csum (for the all-gather).
 // The two strict-mode queue counters (ticket[2], ticket[3]) must be zero on entry (zero_counters).
 // rider: an ORDER job (chan_order_body) attached to sweep 2 -- it produces cs.spos for the fix-up kernels.
+#ifndef VC2_FRAME_A
+#define VC2_FRAME_A 4
+#endif
 int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, bool single_rank, hipStream_t st,
-                  const OrderArgs& rider = OrderArgs{}) {
+                  const OrderArgs& rider = OrderArgs{}, bool own_stats = false) {
   // (ws holds sweep 1's partials of x -- every caller ran the statistics sweep with this workspace: they bound
   // sum |x^| for the centre-mean replay margins)
   const FrameStatSrc fs{wsp<double>(ws, p.o_part_stats), p.stat_splits, p.BF, int(p.N),
@@ -3055,7 +3069,9 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
                                            wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs,
                                            margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0,
-                                           wsp<float>(ws, p.o_dmin)));
+                                           wsp<float>(ws, p.o_dmin),
+                                           (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0,
+                                           (cs.strict == 3 || cs.strict == 4) ? wsp<unsigned>(ws, p.o_dminkey) : (const unsigned*)nullptr));
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
     const int G1v = int(cdiv(p.R >> lpv, int64_t(1) << lpv));
@@ -3074,7 +3090,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
 
 int zero_counters(const Plan& p, void* ws, hipStream_t st) {
   hipError_t e = hipMemsetAsync(wsp<int>(ws, p.o_ticket), 0, 64, st);
-  if (e == hipSuccess) e = hipMemsetAsync(wsp<char>(ws, p.o_nfixlist), 0, size_t(p.R) * 8, st);
+  if (e == hipSuccess) e = hipMemsetAsync(wsp<char>(ws, p.o_nfixlist), 0, size_t(p.R) * 8 + size_t(cdiv(p.F, 2)) * 8, st);
   if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
   return VC2_OK;
 }
@@ -3157,13 +3173,13 @@ const char* vc2_last_error(void) { return g_err; }
 const char* vc2_version(void) { return "vidcom2_amd 0.1 (gfx950)"; }
 
 int vc2_set_mode(int mode) {
-  if (mode < 0 || mode > 3) return fail(VC2_ERR_ARG, "mode must be 0 (exact), 1 (torch order) or 3 (torch order, proven centre margins)");   // 2: debug
+  if (mode < 0 || mode > 4) return fail(VC2_ERR_ARG, "mode must be 0 (exact), 1 (torch order), 3 (torch order, proven centre margins) or 4 (torch order, robust frame margins)");   // 2: debug
   g_mode_default.store(mode, std::memory_order_relaxed);
   g_mode_thread = -1;                               // (the caller sees what it just set)
   return VC2_OK;
 }
 int vc2_set_thread_mode(int mode) {
-  if (mode < -1 || mode > 3) return fail(VC2_ERR_ARG, "mode must be -1 (follow the process), 0 (exact) or 1 (torch order)");
+  if (mode < -1 || mode > 4) return fail(VC2_ERR_ARG, "mode must be -1 (follow the process), 0 (exact), 1, 3 or 4 (torch order variants)");
   g_mode_thread = mode;
   return VC2_OK;
 }
@@ -3276,7 +3292,7 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   OrderArgs rider{};
   if (perm && cs.strict)      // torch.topk's ORDER of the channels (-> spos), replayed by a rider workgroup of sweep 2
     rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1, nullptr, nullptr};
-  rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider);
+  rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider, /*own_stats=*/true);   // (vc2_chan_stats ran with this workspace)
   if (rc) return rc;
   if (csum_parts) {       // per group of kCentreFL frames, in frame order: the fp64 sums of x^ [ceil(F/16)][C], then the
     //                        groups' bounds of sum |x^| [ceil(F/16)][C] (the replay margin of the video centre)
@@ -3541,7 +3557,7 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   OrderArgs rider{};
   if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc), 1,
                                 wperm, wcpos};
-  if ((rc = launch_phase1(p, x, cs, ws, true, st, rider))) return rc;
+  if ((rc = launch_phase1(p, x, cs, ws, true, st, rider, /*own_stats=*/true))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* scales = wsp<float>(ws, p.o_scales_f32);
   const double bs = base_scale < 0 ? 0.0 : base_scale;
