@@ -432,6 +432,15 @@ def main():
         out["exact_mode"] = {"ms_per_step": round(e3 / args.steps * 1e3, 4),
                              "tokens_per_s": round(F * N / (e3 / args.steps), 1),
                              "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / (e3 / args.steps) / 1e9, 1)}
+    # ---- side: the robust and the proven-margin variants of the default mode ------------
+    if extra and dtype != torch.float32:
+        for mname, key in (("torch_robust", "robust_mode"), ("torch_proven", "proven_mode")):
+            _ffi.set_mode(mname)
+            for _ in range(args.warmup):
+                step()
+            e4 = time_steps(step, args.steps, False)
+            _ffi.set_mode("torch")
+            out[key] = {"ms_per_step": round(e4 / args.steps * 1e3, 4), "tokens_per_s": round(F * N / (e4 / args.steps), 1)}
     # ---- side: cfg2 (LLaVA-OV shape) on one GPU ------------------------------------------------------
     if extra and args.workload == "target":
         F2, N2, D2, dt2, b2 = WORKLOADS["cfg2"]

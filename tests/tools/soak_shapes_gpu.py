@@ -6,7 +6,8 @@ import torch
 import oracle as O
 from vidcom2_amd import synth, _ffi
 from vidcom2_amd.vidcom2 import compress
-O.set_mode("torch"); _ffi.set_mode("torch")
+PRIMARY = os.environ.get("VC2_SOAK_MODE", "torch")       # the mode under test ("torch_robust": the cancel misses must vanish)
+O.set_mode("torch"); _ffi.set_mode(PRIMARY)
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = n = bad3 = 0
 t0 = time.time()
@@ -46,9 +47,9 @@ for seed in range(lo, hi):
         if dt != torch.float32:              # the robust mode must get it (`cancel` inputs)
             _ffi.set_mode(os.environ.get("VC2_SOAK_FALLBACK_MODE", "torch_robust"))
             r3 = compress(x.cuda(), N, base, want_scores=True)
-            _ffi.set_mode("torch")
+            _ffi.set_mode(PRIMARY)
             proven = (torch.equal(r3.global_idx.cpu(), o["global_idx"]) and eq(r3.v_score.cpu(), o["v"])
                       and eq(r3.f_score.cpu(), o["f"]) and torch.equal(r3.ks.cpu(), o["ks"]))
             bad3 += 0 if proven else 1
         print("MISMATCH", seed, F, N, D, dt, dist, base, "| robust mode matches:", proven, flush=True)
-print(f"{n} shape cases, {bad} mismatches in the default mode ({bad3} of them also in the robust mode), {time.time() - t0:.0f}s")
+print(f"[mode {PRIMARY}] {n} shape cases, {bad} mismatches in this mode ({bad3} of them also in the robust mode), {time.time() - t0:.0f}s")
