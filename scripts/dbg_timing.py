@@ -9,6 +9,7 @@ import vidcom2_amd as vc
 from vidcom2_amd import _ffi, synth
 F, N, D = 128, 196, 3584
 x = synth.make(F, N, D, torch.bfloat16, 0, "drift").cuda()
+_ffi.set_mode(os.environ.get('VC2_DBG_MODE', 'torch'))
 plan = vc.vidcom2.CompressPlan(F, N, D, torch.bfloat16, x.device, 0.25)
 L = ctypes.CDLL(_ffi.LIB_PATH)
 t = (ctypes.c_ulonglong * 512)(); v = (ctypes.c_int * 512)(); n = ctypes.c_int(0)

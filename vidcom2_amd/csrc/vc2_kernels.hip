@@ -1427,6 +1427,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
     q = float(sf) / float(N);
   }
+  if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(501);
   if (replay && !bounded) {                        // default: the empirical margin (see kFragileUlpsMean)
     if (active && (all || mean_near_T_boundary<DT>(q))) {
       const int j = atomicAdd(&count, 1);
@@ -1455,6 +1456,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       }
     }
   }
+  if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(503);
   sm[fl][cl] = sf;
   sb[fl][cl] = ab;
   __syncthreads();
