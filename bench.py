@@ -556,6 +556,21 @@ def main():
         e4 = time_steps(two, args.steps, False)
         out["two_clips_in_flight"] = {"ms_per_round": round(e4 / args.steps * 1e3, 4),
                                       "tokens_per_s": round(2 * F * N / (e4 / args.steps), 1)}
+        # ---- side: ONE clip at a time, but three different clips in turn: the input of a step is then not what the
+        #      previous step left in the Infinity Cache (the headline loop re-reads the same 171 MiB tensor) -----------
+        xs3 = xs2 + [synth.make(F, N, D, dtype, seed=2, dist="drift").to(dev)]
+        turn = [0]
+
+        def rotate():
+            plan.enqueue(xs3[turn[0] % 3])
+            turn[0] += 1
+        for _ in range(args.warmup):
+            rotate()
+        e5 = time_steps(rotate, args.steps, False)
+        out["rotating_inputs"] = {"ms_per_step": round(e5 / args.steps * 1e3, 4),
+                                  "tokens_per_s": round(F * N / (e5 / args.steps), 1),
+                                  "note": "three different clips in turn: 513 MiB of inputs against the 256 MiB Infinity Cache"}
+        del xs3
 
     # ---- side: the other dtypes of BASELINE.json's shapes, each behind its own parity gate (C++ oracle, same tensor):
     #      the target shape in fp32, and ONE clip of the batched-eval config (128 x 196 x 4096 fp16) --------------
