@@ -137,7 +137,8 @@ def cpu_baselines(x_cpu, N, base, budget_s=10.0):
         if time.perf_counter() - t0 > budget_s or reps >= 10:
             break
     dt = (time.perf_counter() - t0) / reps
-    out = {"value": x_cpu.shape[0] / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "torch-restatement",
+    out = {"value": x_cpu.shape[0] / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+           "flavour": "torch-restatement",       # (oracle/torch_restatement.py: the reference's own torch CPU ops, op for op)
            "sample": f"{reps} full passes of the same workload ({x_cpu.shape[0]} tokens each), {dt * 1e3:.1f} ms/pass, "
                      "torch CPU ops in the reference's order"}
     oracle.set_num_threads(cores)
