@@ -24,8 +24,8 @@ N > 1 : "target": weak scaling -- every rank holds 128 frames of ONE long video 
 One JSON line on rank 0 (see the repo prompt for the contract), with extra objects:
   "roofline"      the dominant kernel's achieved algorithmic HBM rate (hipEvent-timed inside this run)
   "roofline_big"  the same for a > 256 MiB working set (cfg3), where the Infinity Cache cannot hold X
-  "cpu_baseline"  the reference CPU path on this box's host cores: kind "torch-restatement" (the same aten ops,
-                  oracle/torch_restatement.py) and, in "port", the C++/OpenMP oracle
+  "cpu_baseline"  the reference CPU path on this box's host cores: kind "port", flavour "torch-restatement" (the same
+                  aten ops, oracle/torch_restatement.py) and, nested under "port", the C++/OpenMP oracle
 """
 from __future__ import annotations
 
