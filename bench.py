@@ -433,9 +433,10 @@ def main():
         out["exact_mode"] = {"ms_per_step": round(e3 / args.steps * 1e3, 4),
                              "tokens_per_s": round(F * N / (e3 / args.steps), 1),
                              "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / (e3 / args.steps) / 1e9, 1)}
-    # ---- side: the robust and the proven-margin variants of the default mode ------------
+    # ---- side: the opt-in fast variant (empirical margins only: no parity claim) and the proven-margin variant of the
+    #      default mode ---------------------------------------------------------------------
     if extra and dtype != torch.float32:
-        for mname, key in (("torch_robust", "robust_mode"), ("torch_proven", "proven_mode")):
+        for mname, key in (("torch_fast", "fast_mode_no_parity_claim"), ("torch_proven", "proven_mode")):
             _ffi.set_mode(mname)
             for _ in range(args.warmup):
                 step()

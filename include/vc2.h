@@ -48,22 +48,23 @@ const char* vc2_version(void);
 
 /* Accumulation semantics of the reference's fp32-accumulated reductions in half precision (token L2 norm,
  * squared-distance row sums, centre means):
- *   1 (default)  "torch order": wherever the exactly computed value lies within a few fp32-ulps (128 / 48 / 16)
+ *   4 (default)  "torch order": wherever the exactly computed value lies within a few fp32-ulps (128 / 48 / 16)
  *                of a T rounding boundary, torch's own CPU accumulation order (8 interleaved fp32 chains over the
  *                variance-sorted channels / cascade sum / outer-sum cascade over the rows) is replayed for that
- *                token or centre element -> bit-exact to the CPU reference;
+ *                token or centre element -> bit-exact to the CPU reference.  The margin of the FRAME-centre means has,
+ *                besides the 16 ulps of the mean, a term relative to sum |x^| over the frame (4 u A / n, A bounded from
+ *                sweep 1's statistics and the frame's smallest denominator, evaluated only for means that pass a cheap
+ *                pre-test): it grows under cancellation, where torch's cascade errs by far more than ulps OF THE MEAN.
+ *                Reproduces the reference on every fixture (incl. the adversarial `cancel` ones) and every soak case.
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
- *   3            mode 1 with a PROVEN bound deciding which centre means are replayed (forward error bound of torch's
- *                cascade relative to sum |x^|, bounded from sweep 1's statistics) instead of mode 1's empirical 16 ulps:
- *                flags 50x more means, costs a third more time; the test-suite runs every fixture in both.
- *   4            "robust": mode 1 whose margin for the FRAME-centre means has, besides the 16 ulps of the mean, a term
- *                relative to sum |x^| over the frame (4 u A / n, A bounded from sweep 1's statistics and the frame's
- *                smallest denominator, evaluated only for means that pass a cheap pre-test): the margin then grows under
- *                cancellation, where torch's cascade errs by far more than ulps OF THE MEAN.  Reproduces the reference on
- *                every adversarial fixture and soak case known (mode 1 misses 0.2 % of random `cancel` inputs); ~3 %
- *                slower than mode 1.  In the stage call vc2_scores (no statistics sweep of its own) it acts like mode 1.
+ *   3            "proven": a PROVEN bound decides which centre means are replayed (forward error bound of torch's
+ *                cascade relative to sum |x^|, bounded from sweep 1's statistics): flags 50x more means, costs a third
+ *                more time; the test-suite runs every fixture in it as well and asserts the same results.
+ *   1            "fast" (the default of rounds 1-3, now opt-in): the 16-ulp margin alone for all centre means.  ~3 %
+ *                faster than mode 4; NOT bit-exact under cancellation (0.2 % of random `cancel` inputs differ in last-bit
+ *                f scores, rarely a kept index) -- no claim of reference parity is made for it.
  *   (2: debug -- every value is replayed.)
- * fp32 inputs are unaffected.  vc2_set_mode is PROCESS-WIDE (default 1) and also drops the calling thread's own
+ * fp32 inputs are unaffected.  vc2_set_mode is PROCESS-WIDE (default 4) and also drops the calling thread's own
  * override; vc2_set_thread_mode(mode) overrides it for the calling thread only (-1: follow the process-wide setting
  * again), so that a worker thread follows the application's choice unless it asks otherwise; vc2_get_mode returns
  * what a pass issued by the calling thread would use.  (All ranks / threads of a frame-sharded pass must use the

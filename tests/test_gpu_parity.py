@@ -90,19 +90,24 @@ def test_full_pass(c, mode):
 @pytest.mark.parametrize("c", [c for c in CASES if c["dtype"] != "f32"], ids=case_id)
 def test_proven_centre_margins_agree_with_the_default(c):
     """Mode 3 decides which centre means to replay with a PROVEN bound on the cascade's error (relative to sum |x^|),
-    mode 1 with the empirical 16-ulp margin.  Same scores, budgets and kept indices on every half-precision fixture:
-    the evidence that the empirical margin -- 50x fewer replays -- loses nothing (and the end-to-end test of the bound's
-    machinery: sweep-1 partials -> sum x^2, per-frame smallest denominator, the boundary-distance test)."""
+    the default with 16 ulps of the mean plus (frame means) 4 u A / n.  Same scores, budgets and kept indices on every
+    half-precision fixture (and the end-to-end test of the bound's machinery: sweep-1 partials -> sum x^2, per-frame
+    smallest denominator, the boundary-distance test).  The opt-in 'torch_fast' mode (the 16 ulps alone) agrees on these
+    ordinary fixtures as well -- it is only the adversarial `cancel` inputs that it misses."""
     x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"]).to(dev())
     try:
         _ffi.set_mode("torch")
         a = vc.compress(x, c["N"], c["base"], want_scores=True)
         _ffi.set_mode("torch_proven")
         b = vc.compress(x, c["N"], c["base"], want_scores=True)
+        _ffi.set_mode("torch_fast")
+        f = vc.compress(x, c["N"], c["base"], want_scores=True)
     finally:
         _ffi.set_mode("torch")
     assert a.ks.tolist() == b.ks.tolist() and torch.equal(a.global_idx, b.global_idx)
     assert nan_eq(a.v_score, b.v_score) and nan_eq(a.f_score, b.f_score)
+    assert a.ks.tolist() == f.ks.tolist() and torch.equal(a.global_idx, f.global_idx)
+    assert nan_eq(a.v_score, f.v_score) and nan_eq(a.f_score, f.f_score)
     key = (c["name"], c["dtype"], c["dist"], c["seed"])
     if key not in KNOWN_RESIDUE:
         assert b.global_idx.cpu().tolist() == c["global_idx"] and synth.sha256_tensor(b.v_score) == c["v_sha256"]
@@ -522,17 +527,16 @@ def test_mode_is_process_wide_with_a_per_thread_override():
 
 
 ADV = load_json("adversarial_cases.json")["cases"]
-ADV_BEYOND_THE_EMPIRICAL_MARGIN = {("f16", 16, 196, 512)}
 
 
-@pytest.mark.parametrize("mode", ["torch", "torch_robust", "torch_proven"])
+@pytest.mark.parametrize("mode", ["torch", "torch_proven"])
 @pytest.mark.parametrize("c", ADV, ids=lambda c: f"adv-{c['F']}x{c['N']}x{c['D']}-{c['dtype']}")
 def test_adversarial_centre_means(c, mode):
     """tests/golden/make_adversarial_golden.py: inputs BUILT so that torch's fp32 cascade decides centre-mean roundings
     (tiny addends meet a large running sum that later cancels: `frame_centres_decided_by_order` > 0 in the fixture)
     and the cascade's error is hundreds of ulps of the mean.  Scores, budgets and kept indices must equal the
-    reference's in the default mode (with ONE pinned exception), in the robust mode (mode 4: the frame means' margin
-    also has a term relative to sum |x^|) and in the proven-margin mode."""
+    reference's in the default mode (since round 4 the frame means' replay margin has a term relative to sum |x^|: no
+    exception left) and in the proven-margin mode."""
     x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
     assert synth.sha256_tensor(x) == c["x_sha256"]
     try:
@@ -542,14 +546,7 @@ def test_adversarial_centre_means(c, mode):
         _ffi.set_mode("torch")
     assert got.ks.cpu().tolist() == c["ks"]
     assert got.global_idx.cpu().tolist() == c["global_idx"]
-    same_scores = synth.sha256_tensor(got.v_score) == c["v_sha256"] and synth.sha256_tensor(got.f_score) == c["f_sha256"]
-    if mode == "torch" and (c["dtype"], c["F"], c["N"], c["D"]) in ADV_BEYOND_THE_EMPIRICAL_MARGIN:
-        # The documented limit of the DEFAULT mode (DESIGN.md "Numerics contract"): here a frame mean sits farther than
-        # 16 ulps from a rounding boundary and torch's cascade still crosses it; some f scores differ in their last
-        # bit (kept indices and budgets -- asserted above -- do not).  The proven-margin mode gets it right.
-        assert not same_scores, "the empirical margin now covers this case: drop it from the list"
-        return
-    assert same_scores
+    assert synth.sha256_tensor(got.v_score) == c["v_sha256"] and synth.sha256_tensor(got.f_score) == c["f_sha256"]
 
 
 @pytest.mark.parametrize("shape", [(1024, 16, 256, "bf16"), (300, 7, 128, "f16"), (640, 40, 512, "bf16"), (97, 33, 192, "f16"),

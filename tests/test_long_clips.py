@@ -44,18 +44,11 @@ def _check(c, ks, gidx, v=None, f=None):
             "scores differ from the reference"
 
 
-def _beyond_the_empirical_margin(c):
-    """The documented limit of the DEFAULT mode (DESIGN.md "Numerics contract"): on the fp16 `cancel` inputs some FRAME
-    means sit farther than 16 ulps from a rounding boundary and torch's cascade still crosses it (nothing to do with
-    the clip's length: tests/test_gpu_parity.py::test_adversarial_centre_means pins the same at 16 frames).  The
-    robust mode (mode 4) and the proven-margin mode reproduce the reference on them; the default mode is asserted NOT
-    to, so that the list is dropped the day it does."""
-    return c["dtype"] == "f16" and c["dist"] == "cancel"
-
-
-@pytest.mark.parametrize("mode", ["torch", "torch_robust", "torch_proven"])
+@pytest.mark.parametrize("mode", ["torch", "torch_proven"])
 @pytest.mark.parametrize("c", LONG, ids=_id)
 def test_long_clip_matches_the_reference(c, mode):
+    """Budgets, kept indices and both score tensors equal the reference's -- in the default mode (every case, the fp16
+    `cancel` clips included: their frame means are the ones the pre-round-4 default missed) and in the proven-margin mode."""
     x = _x(c)
     try:
         _ffi.set_mode(mode)
@@ -64,10 +57,6 @@ def test_long_clip_matches_the_reference(c, mode):
             got = vc.compress(x.cuda(), c["N"], c["base"], want_scores=True)
     finally:
         _ffi.set_mode("torch")
-    if mode == "torch" and _beyond_the_empirical_margin(c):
-        assert synth.sha256_tensor(got.v_score.cpu()) == c["v_sha256"]          # the video centre (this file's subject)
-        assert synth.sha256_tensor(got.f_score.cpu()) != c["f_sha256"], "the default margin now covers this case"
-        return
     _check(c, got.ks.cpu(), got.global_idx.cpu(), got.v_score.cpu(), got.f_score.cpu())
 
 
@@ -89,7 +78,7 @@ def test_long_clip_frame_sharded(c):
     """3072 frames as 8 / 4 / 2 logical ranks through the stage entry points the RCCL path calls: rows per rank are a
     multiple of 32, so exchange 2b carries 32-row block sums and every rank finishes the level-power-5 cascade."""
     from test_sharded import _emulate_ranks_on_one_gpu
-    _ffi.set_mode("torch_robust" if _beyond_the_empirical_margin(c) else "torch")
+    _ffi.set_mode("torch")
     F, N, D = c["F"], c["N"], c["D"]
     x = _x(c).cuda()
     whole = vc.compress(x, N, c["base"], want_scores=True)

@@ -22,5 +22,5 @@ for (F, N, D), dt, dist, mode in itertools.product(shapes, (torch.float16, torch
         if not ok:
             bad += 1
             print("MISMATCH", F, N, D, dt, dist, mode, seed)
-_ffi.lib().vc2_set_mode(1)
+_ffi.set_mode("torch")
 print(n, "cases", bad, "mismatches")

@@ -156,17 +156,19 @@ def profile_collect() -> dict:
     return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(got) if cnt[i]}
 
 
-# 'torch_proven': 'torch' with a PROVEN error bound instead of the empirical 16-ulp margin deciding which centre means
-# are replayed (include/vc2.h vc2_set_mode, mode 3): same results wherever the empirical margin suffices -- the parity
-# suite asserts that on every fixture -- at a quarter more time per pass
-MODE_CODE = {"exact": 0, "torch": 1, "torch_proven": 3, "torch_robust": 4}
+# 'torch' = the library default (C mode 4): bit-exact to the CPU reference; the frame-mean replay margin has a term relative
+# to sum |x^| so that it grows under cancellation.  'torch_proven' (mode 3): a PROVEN error bound decides which centre
+# means are replayed -- same results (the parity suite asserts that on every fixture) at a third more time per pass.
+# 'torch_fast' (mode 1, the default of rounds 1-3): the 16-ulp empirical margin alone, ~3 % faster, NOT bit-exact on
+# adversarial cancellation inputs -- opt-in, no parity claim.  ('torch_robust': the name mode 4 had while it was opt-in.)
+MODE_CODE = {"exact": 0, "torch": 4, "torch_fast": 1, "torch_proven": 3, "torch_robust": 4}
 
 
 def set_mode(mode: str) -> None:
     """'torch' (default): bit-exact to the CPU reference in half precision (replays torch's fp32 accumulation
-    order where it decides a rounding); 'exact': every reduction correctly rounded; 'torch_robust': 'torch' whose replay
-    margin for the frame-centre means also has a term relative to sum |x^| (passes every adversarial fixture, ~3 % slower);
-    'torch_proven': proven margins for all centre means (~45 % slower).  get_mode() answers 'torch' for all torch modes."""
+    order where it decides a rounding); 'exact': every reduction correctly rounded; 'torch_proven': proven margins for
+    all centre means (~45 % slower); 'torch_fast': empirical margins only (opt-in, no parity claim under cancellation).
+    get_mode() answers 'torch' for all torch modes."""
     check(lib().vc2_set_mode(MODE_CODE[mode]), "vc2_set_mode")
 
 

@@ -2691,12 +2691,14 @@ struct Plan {
   int vstride;
 };
 
-// 1 (default): replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the
-// result is bit-exact to the CPU reference; 0: plain correctly-rounded-op semantics.  See vc2_set_mode.
+// non-zero: replay torch's fp32 accumulation order for boundary-fragile tokens (half precision) so that the result is
+// bit-exact to the CPU reference -- 4 (DEFAULT since round 4: the frame-mean margin grows under cancellation), 1 (the
+// faster empirical margins: opt-in), 3 (proven centre margins), 2 (debug); 0: plain correctly-rounded-op semantics.
+// See vc2_set_mode.
 // A process-wide setting (vc2_set_mode) that a thread may override for itself (vc2_set_thread_mode): a pass issued from
 // a worker thread (HF generate's streaming thread) follows what the application set, and two threads that need
 // different modes cannot disturb each other.
-std::atomic<int> g_mode_default{1};
+std::atomic<int> g_mode_default{4};
 thread_local int g_mode_thread = -1;             // -1: follow the process-wide setting
 inline int cur_mode() { return g_mode_thread >= 0 ? g_mode_thread : g_mode_default.load(std::memory_order_relaxed); }
 
@@ -3175,7 +3177,7 @@ const char* vc2_last_error(void) { return g_err; }
 const char* vc2_version(void) { return "vidcom2_amd 0.1 (gfx950)"; }
 
 int vc2_set_mode(int mode) {
-  if (mode < 0 || mode > 4) return fail(VC2_ERR_ARG, "mode must be 0 (exact), 1 (torch order), 3 (torch order, proven centre margins) or 4 (torch order, robust frame margins)");   // 2: debug
+  if (mode < 0 || mode > 4) return fail(VC2_ERR_ARG, "mode must be 0 (exact), 4 (torch order: the default), 1 (torch order, empirical margins only) or 3 (torch order, proven centre margins)");   // 2: debug
   g_mode_default.store(mode, std::memory_order_relaxed);
   g_mode_thread = -1;                               // (the caller sees what it just set)
   return VC2_OK;
@@ -3397,8 +3399,10 @@ int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ChanSet cs = make_chanset(p, cols, spos, C);
   if ((rc = zero_counters(p, ws, st))) return rc;
-  if (cs.strict == 3 && (rc = launch_stats_sweep(p, x, ws, PoolSrc{}, st))) return rc;   // (bounds sum |x^|: mean_delta)
-  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st))) return rc;
+  // modes 3 / 4 bound sum |x^| from sweep-1 statistics of THESE columns (mean_delta): the stage call runs that sweep itself
+  const bool stats = cs.strict == 3 || cs.strict == 4;
+  if (stats && (rc = launch_stats_sweep(p, x, ws, PoolSrc{}, st))) return rc;
+  if ((rc = launch_phase1(p, x, cs, ws, /*single_rank=*/true, st, OrderArgs{}, /*own_stats=*/stats))) return rc;
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, cs, ws, v_T, f_T, total, s, st);
