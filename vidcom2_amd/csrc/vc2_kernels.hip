@@ -39,7 +39,6 @@
 #include <vector>
 
 #include "vc2_device.h"
-#include "vc2_select2.h"
 
 #ifndef VC2_PROBE_D3
 #define VC2_PROBE_D3 0
@@ -68,6 +67,8 @@ namespace vc2 { __device__ unsigned long long g_dbg_wg[4][2][4096]; }
 #define VC2_STAMP(tag) ((void)0)
 #define VC2_WGTIME(slot, which) ((void)0)
 #endif
+
+#include "vc2_select2.h"        // (after the debug macros: the selection rounds carry stamps in debug builds)
 
 namespace {
 
@@ -312,11 +313,31 @@ __device__ __forceinline__ void chan_fold(ChanAgg& a, double nb, double mb, doub
   a.m2 = a.m2 + m2b + d * d * (a.n * nb / n);
   a.n = n;
 }
+// The second-level fold (16 lane aggregates in lane order) only depends on the block sizes, not on the column: its
+// two quotients per step -- nb / n and (a.n * nb) / n, each a ~40-instruction fp64 division, 30 of them in a serial
+// chain per column (2.5 us of the kernel's 6.9) -- are computed once on the host.  IEEE division on both sides: the
+// same bits as chan_fold's.
+struct FoldTab { double r1[kRedGL], r2[kRedGL], ntot; int kind[kRedGL]; };     // kind: 0 skip, 1 assign, 2 fold
+inline FoldTab make_fold_tab(int NB, int64_t n_each, int64_t n_last) {
+  FoldTab t{};
+  double an = 0.0;
+  for (int i = 0; i < kRedGL; ++i) {
+    double nb = 0.0;                                     // rows of lane i's blocks i, i + 16, ... (added like chan_fold does)
+    for (int b = i; b < NB; b += kRedGL) nb += double(b == NB - 1 ? n_last : n_each);
+    if (nb <= 0.0) { t.kind[i] = 0; continue; }
+    if (an <= 0.0) { t.kind[i] = 1; an = nb; continue; }
+    const double n = an + nb;
+    t.kind[i] = 2; t.r1[i] = nb / n; t.r2[i] = an * nb / n;
+    an = n;
+  }
+  t.ntot = an;
+  return t;
+}
 template <int DT>
 __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
                                                                 int64_t n_each, int64_t n_last, int D,
                                                                 void* __restrict__ var_T, float* __restrict__ var_f32,
-                                                                int* __restrict__ counters, PartSrc ps,
+                                                                int* __restrict__ counters, PartSrc ps, FoldTab ft,
                                                                 unsigned long long* __restrict__ fixq = nullptr,
                                                                 int nfixq = 0) {
   // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
@@ -340,7 +361,16 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
   if (gl != 0 || c >= D) return;
   ChanAgg t{0.0, 0.0, 0.0};
 #pragma unroll
-  for (int i = 0; i < kRedGL; ++i) chan_fold(t, sm[0][i][cl], sm[1][i][cl], sm[2][i][cl]);
+  for (int i = 0; i < kRedGL; ++i) {                     // chan_fold with the host's quotients (FoldTab)
+    const double mb = sm[1][i][cl], m2b = sm[2][i][cl];
+    if (ft.kind[i] == 1) { t.mean = mb; t.m2 = m2b; }
+    else if (ft.kind[i] == 2) {
+      const double d = mb - t.mean;
+      t.mean = t.mean + d * ft.r1[i];
+      t.m2 = t.m2 + m2b + d * d * ft.r2[i];
+    }
+  }
+  t.n = ft.ntot;
   const float v = rnT<DT>(float(t.m2 / t.n));
   if (var_f32) var_f32[c] = v;
   if (var_T) stT<DT>(var_T, c, v);
@@ -385,8 +415,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t c, uint32_t* xch, u
   return pre + incl - c;
 }
 
+constexpr int kSelPre = (8192 + kSelNT - 1) / kSelNT;     // variances a thread holds (D <= 8192)
 template <typename W>
-__device__ __forceinline__ void chan_select_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
+__device__ __forceinline__ void chan_select_body(unsigned char* smem, const float (&pre)[kSelPre], int D, int k,
                                                  uint8_t* __restrict__ mask, int* __restrict__ cols,
                                                  int* __restrict__ perm, uint32_t* __restrict__ wperm,
                                                  uint32_t* __restrict__ wcpos) {
@@ -394,7 +425,8 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   constexpr int NW = kSelNT / 64;
   const int tid = threadIdx.x;
   Sel2<W> S = sel2_carve<W>(smem, D);
-  for (int i = tid; i < D; i += kSelNT) S.w[i] = T::pack(topk_key(var_f32[i]), i);
+#pragma unroll
+  for (int j = 0; j < kSelPre; ++j) { const int i = tid + j * kSelNT; if (i < D) S.w[i] = T::pack(topk_key(pre[j]), i); }
   __syncthreads();
   if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
   else topk_smallest2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, k, tid);
@@ -434,11 +466,15 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int bad = 0;
   if (threadIdx.x == 0) VC2_STAMP(200);
-  for (int i = threadIdx.x; i < D; i += kSelNT) bad |= key_fits_u32(var_f32[i]) ? 0 : 1;
+  float pre[kSelPre];                                  // (one round of loads; the bodies pack from registers)
+#pragma unroll
+  for (int j = 0; j < kSelPre; ++j) { const int i = threadIdx.x + j * kSelNT; pre[j] = var_f32[i < D ? i : D - 1]; }
+#pragma unroll
+  for (int j = 0; j < kSelPre; ++j) bad |= key_fits_u32(pre[j]) ? 0 : 1;
   // widened 16-bit variances pack into 32-bit words (the common case); arbitrary fp32 ones take 64-bit words
   // (wperm / wcpos are only requested for 16-bit inputs)
-  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, var_f32, D, k, mask, cols, perm, nullptr, nullptr);
-  else chan_select_body<uint32_t>(smem, var_f32, D, k, mask, cols, perm, wperm, wcpos);
+  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr);
+  else chan_select_body<uint32_t>(smem, pre, D, k, mask, cols, perm, wperm, wcpos);
   if (threadIdx.x == 0) VC2_STAMP(209);
 }
 __host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
@@ -1158,7 +1194,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
                                                  float* __restrict__ den, const int* __restrict__ nfix_count,
                                                  const unsigned long long* __restrict__ fixq, int max_entries,
                                                  int* __restrict__ corr_count, NormCorr* __restrict__ corr,
-                                                 int N) {
+                                                 int N, unsigned* __restrict__ dminkey, int F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -1167,7 +1203,22 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   if (blockIdx.x == 0 && lane == 0) VC2_STAMP(400);
   const int count = min(*nfix_count, max_entries);
   if (blockIdx.x == 0 && lane == 0) VC2_STAMP(401);
-  if (int(blockIdx.x) >= count) return;
+  // modes 3 / 4: the frames' smallest denominators for the centre-mean margins (0x7F800000 - bits; key 0 = none), one
+  // wave per frame from den[] -- by the waves that have no queue entry, so that nothing waits for it.  (Until round 4
+  // sweep 2 left them behind through one atomicMax per wave and segment: +2 us on the sweep.  A denominator that
+  // another wave of this launch is correcting by an ulp may be read either way: abs_sum_bound allows for that.)
+  // (frames are dealt from the LAST workgroup down: the queue entries go to the first ones)
+  auto frame_dmins = [&]() {
+    if (!dminkey) return;
+    for (int f = int(gridDim.x) - 1 - int(blockIdx.x); f < F; f += int(gridDim.x)) {
+      float m = INFINITY;
+      for (int r = lane; r < N; r += 64) m = fminf(m, fabsf(den[int64_t(f) * N + r]));      // (NaN does not enter)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+      if (lane == 0) dminkey[f] = m < INFINITY ? 0x7F800000u - __float_as_uint(m) : 0u;
+    }
+  };
+  if (int(blockIdx.x) >= count) { frame_dmins(); return; }
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   unsigned long long g = fixq[blockIdx.x];
   row_issue<DT, VEC>(x, int64_t(uint32_t(g)) - 1, D, CV, buf0, lane);   // first row's DMA overlaps the index loads below
@@ -1178,6 +1229,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
     fx.row(buf0, rowb, int64_t(uint32_t(g)) - 1, __uint_as_float(uint32_t(g >> 32)), C, N, den, corr_count, corr,
            max_entries, lane);
   }
+  frame_dmins();
   if (blockIdx.x == 0 && lane == 0) VC2_STAMP(409);
 }
 
@@ -1378,12 +1430,12 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
                                                                    int* __restrict__ vtick, FrameStatSrc fs,
                                                                    double kk, int want_bounds,
                                                                    float* __restrict__ dmin_out, double kk_a,
-                                                                   const unsigned* __restrict__ dminkey) {
+                                                                   const unsigned* __restrict__ dminkey,
+                                                                   uint32_t* __restrict__ rlist, int rcap) {
   __shared__ double sm[kCentreFL][64];
   __shared__ double sb[kCentreFL][64];
-  __shared__ float l1s_all[kCentreFL][kCFixSolo];
   __shared__ uint32_t flist[kCen2List];            // local frame * 64 + local column
-  __shared__ int count;
+  __shared__ int count, rbase;
   const int tid = threadIdx.x, cl = tid & 63, fl = tid >> 6, lane = cl, wave = fl;
   const int c = blockIdx.x * 64 + cl;
   const int g = blockIdx.y;
@@ -1469,23 +1521,46 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(505);
   if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
-  // ---- the boundary-near frame means in torch's cascade order: one wave per entry (the list holds every pair of the
-  //      workgroup: 16 x 64 = kCen2List)
+  // ---- the boundary-near frame means are replayed in torch's cascade order by the NEXT launch (rider waves of
+  //      k_video_centre, frame_replay_wave): this workgroup only appends its entries (frame * C + column) to the pass's
+  //      list.  Replaying them here, one wave per entry, left the launch waiting for the few workgroups whose 64
+  //      columns hold most of the near-zero means (two or three rounds of ~2.5 us) while 3000 other waves idled.
+  const int nf = min(count, kCen2List);
+  if (tid == 0) rbase = nf ? atomicAdd(fs.diag, nf) : 0;        // (the list's length = replayed frame means of this pass)
+  __syncthreads();
+  for (int e = tid; e < nf; e += 64 * kCentreFL) {
+    const int ff = g * kCentreFL + int(flist[e] >> 6), cc = blockIdx.x * 64 + int(flist[e] & 63u);
+    if (rbase + e < rcap) rlist[rbase + e] = uint32_t(ff) * uint32_t(C) + uint32_t(cc);
+  }
+  if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(509);
+}
+
+// One boundary-near frame mean per wave (see k_frame_centres): the frame's N values of x^ in ONE round of loads, then
+// torch's outer-sum cascade from LDS (N <= kCFixSolo), else level-1 group by level-1 group.  xs: kCFixSolo floats of LDS.
+struct FrameReplay {
+  const uint32_t* list; const int* count; int cap;   // entries frame * C + column (count may exceed cap: never written beyond)
+  float* fc; int N;
+};
+template <int DT>
+__device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid, int nrid, float* xs,
+                                                  const void* __restrict__ x, int D, int C,
+                                                  const int* __restrict__ cols, const int* __restrict__ spos,
+                                                  const float* __restrict__ den, int lane) {
+  const int N = r.N;
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
-  const int nf = min(count, kCen2List);
-  if (tid == 0 && nf && fs.diag) atomicAdd(fs.diag, nf);       // (diagnostic: replayed frame means of this pass)
-  for (int e = wave; e < nf; e += kCentreFL) {
-    const int ff = g * kCentreFL + int(flist[e] >> 6), cc = blockIdx.x * 64 + int(flist[e] & 63u);
+  const int cnt = min(*r.count, r.cap);
+  for (int e = rid; e < cnt; e += nrid) {
+    const uint32_t ent = r.list[e];
+    const int ff = int(ent / uint32_t(C)), cc = int(ent - uint32_t(ff) * uint32_t(C));
     const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
     float s;
     if (N <= kCFixSolo) {                                         // the frame's values in one round of loads, then LDS
-      float* xs = l1s_all[wave];
       float v[kCFixSolo / 64];
 #pragma unroll
       for (int i = 0; i < kCFixSolo / 64; ++i) {
-        const int r = min(lane + 64 * i, N - 1);
-        v[i] = xhat_at<DT>(x, int64_t(ff) * N + r, D, col, den);
+        const int rr = min(lane + 64 * i, N - 1);
+        v[i] = xhat_at<DT>(x, int64_t(ff) * N + rr, D, col, den);
       }
 #pragma unroll
       for (int i = 0; i < kCFixSolo / 64; ++i) if (lane + 64 * i < N) xs[lane + 64 * i] = v[i];
@@ -1493,11 +1568,18 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       s = lds_column_short(xs, sp < simple_end, N, lane);
       wave_lds_fence();
     } else {
-      s = wave_column_solo<DT>(l1s_all[wave], sp < simple_end, x, D, col, den, int64_t(ff) * N, N, lane);
+      s = wave_column_solo<DT>(xs, sp < simple_end, x, D, col, den, int64_t(ff) * N, N, lane);
     }
-    if (lane == 0) fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
+    if (lane == 0) r.fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
   }
-  if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(509);
+}
+// the replays as their own launch (frame-sharded pass: its video centre is computed later, from the all-gathered sums)
+template <int DT>
+__global__ __launch_bounds__(64) void k_frame_replay(FrameReplay r, const void* __restrict__ x, int D, int C,
+                                                      const int* __restrict__ cols, const int* __restrict__ spos,
+                                                      const float* __restrict__ den) {
+  __shared__ float xs[kCFixSolo];
+  frame_replay_wave<DT>(r, int(blockIdx.x), int(gridDim.x), xs, x, D, C, cols, spos, den, int(threadIdx.x));
 }
 
 // parts[NP][stride]: the 16-frame group sums of one rank, or the all-gathered ones of every rank (frame order).
@@ -1517,9 +1599,17 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       int strict, int replay_rows, int* __restrict__ fragile_count,
                                                       float* __restrict__ l1g, int vstride, int* __restrict__ vtick,
                                                       uint8_t* __restrict__ vflag, int rpr, double kk,
-                                                      FrameStatSrc fs, const float* __restrict__ dmin, int F) {
+                                                      FrameStatSrc fs, const float* __restrict__ dmin, int F,
+                                                      FrameReplay frp = FrameReplay{}, int Ymain = 0) {
   __shared__ float l1s[kL1Cap + 4];                  // level-1 groups of one column
-  const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = gridDim.y;
+  // grid rows [Ymain, gridDim.y) (Ymain > 0) are RIDER waves: they replay the boundary-near frame means k_frame_centres
+  // listed -- work that is independent of the video centre and hides under this kernel's own latency chain
+  const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = Ymain > 0 ? Ymain : int(gridDim.y);
+  if (y >= Y) {
+    frame_replay_wave<DT>(frp, (y - Y) * int(gridDim.x) + bx, (int(gridDim.y) - Y) * int(gridDim.x), l1s, x, D, C, cols, spos,
+                          den, lane);
+    return;
+  }
   const bool replay = strict != 0 && DT != VC2_F32;
   const bool all = strict == 2;
   const int c = bx * 64 + lane;
@@ -2475,6 +2565,8 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
     }
   }
   // block sums of (before, all) and broadcast of this frame's k (exactly one thread holds it)
+  // (Budgets by ONE wave with wave-level reductions only -- no barriers -- were built twice, rounds 3 and 4: 1.2 us
+  //  SLOWER than this block-wide form, whose ten barriers cost less than one wave's serial exp / load slots.)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
   __syncthreads();
@@ -2489,13 +2581,14 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
     if (holder) { smi[0] = kmine; smf[0] = scmine; }
   }
   __syncthreads();
-  if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(801 + (fl ? 50 : 0));
   const int kraw = int(smi[0]);                                 // round(scale * tpf): may exceed N when tpf != N
+  const float scale_f = smf[0];
+  if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(801 + (fl ? 50 : 0));
   const int k = kraw < N ? kraw : N;
   if (tid == 0) {
     ks[fl] = kraw;                                              // (the caller turns k > N into torch.topk's error)
     offs[fl] = o0;
-    if (scales_out) scales_out[fl] = smf[0];
+    if (scales_out) scales_out[fl] = scale_f;
     if (fl == FS - 1) {
       offs[FS] = Ktot;
       K_out[0] = Ktot;
@@ -2687,7 +2780,7 @@ struct Plan {
   int skew2_q10;                // how much the first split of a frame exceeds the mean, in 1/1024 (k_dist)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_dminkey, o_tmp_f32, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_dminkey, o_tmp_f32, o_rlist, total_bytes;
   int vstride;
 };
 
@@ -2803,6 +2896,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_vticket = take(size_t(D) * 4);
   p->o_dmin = take(size_t(F) * 4);                 // per frame: the smallest denominator (centre-mean margins)
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
+  p->o_rlist = take(size_t(F) * D * 4);            // frame means to replay: frame * C + column (k_frame_centres -> frame_replay_wave)
   p->total_bytes = o;
   return VC2_OK;
 }
@@ -2893,6 +2987,7 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, vo
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
                                              0, st, (const double*)nullptr, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
                                              zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src,
+                                             make_fold_tab(p.NB, n_each, n_last),
                                              zero_queue_counters ? wsp<unsigned long long>(ws, p.o_nfixlist) : nullptr,
                                              int(p.R + cdiv(p.F, 2))));
   } }
@@ -2975,7 +3070,7 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_q, p.R,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider,
-                     ((cs.strict == 3 || cs.strict == 4) && DT != VC2_F32) ? wsp<unsigned>(ws, p.o_dminkey) : (unsigned*)nullptr);
+                     (unsigned*)nullptr);        // (the frames' smallest denominators: k_norm_fix derives them from den[], see there)
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -2995,7 +3090,8 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
                      cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + kTkFixCount,
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + kTkCorrCount,
-                     wsp<NormCorr>(ws, p.o_corr), int(p.N));
+                     wsp<NormCorr>(ws, p.o_corr), int(p.N),
+                     (cs.strict == 3 || cs.strict == 4) ? wsp<unsigned>(ws, p.o_dminkey) : (unsigned*)nullptr, int(p.F));
   return VC2_OK;
 }
 struct DistOut { void* v_T; void* f_T; float* total; };
@@ -3075,18 +3171,29 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                            margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0,
                                            wsp<float>(ws, p.o_dmin),
                                            (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0,
-                                           (cs.strict == 3 || cs.strict == 4) ? wsp<unsigned>(ws, p.o_dminkey) : (const unsigned*)nullptr));
+                                           (cs.strict == 3 || cs.strict == 4) ? wsp<unsigned>(ws, p.o_dminkey) : (const unsigned*)nullptr,
+                                           wsp<uint32_t>(ws, p.o_rlist), int(std::min<int64_t>(p.F * int64_t(C), INT32_MAX))));
+  // the frame means k_frame_centres listed are replayed by rider waves of the video-centre launch (single rank), or
+  // by a launch of their own (frame-sharded pass: its video centre comes later, from the all-gathered sums)
+  const bool replays = cs.strict != 0 && p.dt != VC2_F32;
+  const FrameReplay frp{wsp<uint32_t>(ws, p.o_rlist), wsp<int>(ws, p.o_ticket) + kTkFrameReplays,
+                        int(std::min<int64_t>(p.F * int64_t(C), INT32_MAX)), wsp<float>(ws, p.o_fc), int(p.N)};
+  const int rwaves = cs.strict == 2 ? 8192 : 1024;             // rider waves (debug mode 2 replays every mean)
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
     const int G1v = int(cdiv(p.R >> lpv, int64_t(1) << lpv));
     const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 64 >> std::min(lpv, 6)))));
-    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y)), dim3(64), 0,
+    const int RY = replays ? int(cdiv(rwaves, cdiv(C, 64))) : 0;
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y + RY)), dim3(64), 0,
                                              st, cpart, FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
                                              cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1,
                                              wsp<int>(ws, p.o_ticket) + kTkVcFragile,
                                              wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
                                              (uint8_t*)nullptr, 0, margin_depth(p.R, cs.strict), fs,
-                                             wsp<float>(ws, p.o_dmin), int(p.F)));
+                                             wsp<float>(ws, p.o_dmin), int(p.F), frp, Y));
+  } else if (replays) {
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_replay<DT>), dim3(unsigned(rwaves)), dim3(64), 0, st, frp, x, int(p.D),
+                                             C, cs.cols, cs.spos, wsp<float>(ws, p.o_den)));
   }
   }
   return check_launch("scores phase 1");
@@ -3229,7 +3336,8 @@ int vc2_chan_var_from_stats(const double* bstats, int64_t NB, int64_t rows_per_b
   hipStream_t st = static_cast<hipStream_t>(stream);
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(D, 64))), dim3(64 * kRedGL), 0, st,
                                             bstats, int(NB), rows_per_block, R_total - (NB - 1) * rows_per_block, int(D),
-                                            var_T, var_f32, (int*)nullptr, PartSrc{}));
+                                            var_T, var_f32, (int*)nullptr, PartSrc{},
+                                            make_fold_tab(int(NB), rows_per_block, R_total - (NB - 1) * rows_per_block)));
   return check_launch("var_from_stats");
 }
 

@@ -23,6 +23,13 @@
 
 #include "vc2_device.h"
 
+// debug builds (-DVC2_DEBUG_TIMING): wall-clock stamps per selection round of workgroup 0 (scripts/dbg_timing.py)
+#if defined(VC2_DEBUG_TIMING) && defined(VC2_STAMP)
+#define VC2_SEL_STAMP(tag) do { if (blockIdx.x == 0) VC2_STAMP(tag); } while (0)
+#else
+#define VC2_SEL_STAMP(tag) ((void)0)
+#endif
+
 namespace vc2 {
 
 // ---- element words -------------------------------------------------------------------------------
@@ -58,6 +65,7 @@ __device__ unsigned long long g_sel2_dbg[128];
 
 constexpr int kXchCut = 16, kXchDummy = 20;
 constexpr int kSel2Pad = 64;           // positions a round may read past the end of the range (never used)
+constexpr int kSel2XchBytes = 128;
 
 template <typename W> struct Sel2 {
   W* w;            // [n + kSel2Pad]
@@ -67,7 +75,7 @@ template <typename W> struct Sel2 {
   int dumw;        // index of a dummy word in w[] (predicated swaps of no-op elements land there)
 };
 __host__ __device__ inline size_t sel2_bytes(int n, int wbytes) {
-  return (size_t(n + kSel2Pad) * size_t(wbytes) + 15) / 16 * 16 + size_t(n + kSel2Pad) * 2 * 2 + 128 + 32;
+  return (size_t(n + kSel2Pad) * size_t(wbytes) + 15) / 16 * 16 + size_t(n + kSel2Pad) * 2 * 2 + kSel2XchBytes + 32;
 }
 template <typename W> __device__ __forceinline__ Sel2<W> sel2_carve(unsigned char* smem, int n) {
   Sel2<W> S;
@@ -75,7 +83,7 @@ template <typename W> __device__ __forceinline__ Sel2<W> sel2_carve(unsigned cha
   S.w = reinterpret_cast<W*>(smem);
   unsigned char* p = smem + wb;
   S.xch = reinterpret_cast<uint32_t*>(p);
-  S.la = reinterpret_cast<uint16_t*>(p + 128);
+  S.la = reinterpret_cast<uint16_t*>(p + kSel2XchBytes);
   S.lb = S.la + (n + kSel2Pad);
   S.dumw = n + kSel2Pad - 1;
   return S;
@@ -331,6 +339,112 @@ __device__ __forceinline__ int sel2_partition(const Sel2<W>& S, int lo, int hi, 
 // the longest range a group of NW waves partitions with 4*EQ elements per thread
 __host__ __device__ constexpr int sel2_capacity(int nw, int eq) { return 64 * nw * 4 * eq - 4; }
 
+// ---- the last rounds of introselect in REGISTERS (ranges of at most 64 elements, one wave) -----------------------
+// An LDS round costs a lone wave ~0.6 us whatever the range (three dependent LDS trips, two DPP scans, ~350
+// instructions), and the last six or seven of the ~12 rounds of a 3584-element selection work on <= 64 elements.  Here
+// the range lives one element per lane for all those rounds and a round needs no memory at all:
+//   * the pivot's three candidates come by v_readlane, the median is scalar code;
+//   * the two stop sets of __unguarded_partition are 64-bit ballots: A = "not less than the pivot", B = "not greater";
+//     with rA = #A left of me (v_mbcnt) and Bge = #B at or right of me, the serial loop's i-th swap pairs the i-th A
+//     from the left with the i-th B from the right while the A stands left of the B, i.e. an A element is swapped
+//     iff more than rA B's stand strictly right of it and a B element iff at least Bge A's stand strictly left of it
+//     -- decided per lane, no positions looked up;
+//   * the swapped elements change lanes through rank space: A number r sends itself to slot r, B number s (from the
+//     right) to slot 63 - s (ds_permute_b32: the LDS crossbar, no LDS memory), then A number r fetches slot 63 - r and
+//     B number s slot s (ds_bpermute_b32).  At most 31 pairs: slot 31 stays free for everybody else;
+//   * the cut is where std::__unguarded_partition's `first` halts: the first A that is not swapped, or the last
+//     (= leftmost) swapped B if that comes first -- two s_ff1 on ballots.
+// A round is ~40 instructions and two crossbar trips.  Depth limit, the final insertion sort of <= 3 elements and the
+// heap-select fallback are libstdc++'s (stl_algo.h __introselect).  (A first version replayed the swaps one by one
+// in scalar code -- v_readlane / select pairs, ~150 cycles per swap: no faster than the LDS rounds.)
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return uint32_t(__builtin_amdgcn_readlane(int(v), l)); }
+__device__ __forceinline__ uint64_t rdlane(uint64_t v, int l) {
+  return uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v)), l))) |
+         (uint64_t(uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v >> 32)), l))) << 32);
+}
+template <typename W> __device__ __forceinline__ W wrlane(W old, W val, int l, int lane) {
+  return lane == l ? val : old;
+}
+__device__ __forceinline__ uint32_t xbar_push(int slot, uint32_t v) { return uint32_t(__builtin_amdgcn_ds_permute(slot << 2, int(v))); }
+__device__ __forceinline__ uint64_t xbar_push(int slot, uint64_t v) {
+  return uint64_t(xbar_push(slot, uint32_t(v))) | (uint64_t(xbar_push(slot, uint32_t(v >> 32))) << 32);
+}
+__device__ __forceinline__ uint32_t xbar_pull(int slot, uint32_t v) { return uint32_t(__builtin_amdgcn_ds_bpermute(slot << 2, int(v))); }
+__device__ __forceinline__ uint64_t xbar_pull(int slot, uint64_t v) {
+  return uint64_t(xbar_pull(slot, uint32_t(v))) | (uint64_t(xbar_pull(slot, uint32_t(v >> 32))) << 32);
+}
+constexpr int kSel2TailMax = 64;
+
+// finishes std::__introselect on S.w[lo, hi) (hi - lo <= 64) for position nth, `depth` partitions left before the
+// heap-select fallback; whole wave (all 64 lanes active), identical arguments in every lane
+template <typename W>
+__device__ __forceinline__ void introselect_tail64(const Sel2<W>& S, int lo_, int hi_, int nth_, int depth_, int lane) {
+  using T = WordTr<W>;
+  const int lo = __builtin_amdgcn_readfirstlane(lo_), hi = __builtin_amdgcn_readfirstlane(hi_);
+  const int nr = __builtin_amdgcn_readfirstlane(nth_) - lo;
+  int depth = __builtin_amdgcn_readfirstlane(depth_);
+  const int n = hi - lo;
+  W el = S.w[lo + (lane < n ? lane : 0)];
+  int l = 0, h = n;
+  bool fallback = false;
+  for (int guard = 0; h - l > 3 && guard < 256; ++guard) {
+    if (depth == 0) { fallback = true; break; }
+    --depth;
+    const int pa = l + 1, pb = l + (h - l) / 2, pc = h - 1;
+    const W wlo = rdlane(el, l), wa = rdlane(el, pa), wb = rdlane(el, pb), wc = rdlane(el, pc);
+    const uint32_t ka = T::key(wa), kb = T::key(wb), kc = T::key(wc);
+    const bool ab = ka < kb, bc = kb < kc, ac = ka < kc;          // __move_median_to_first
+    const int sel = ab ? (bc ? 1 : (ac ? 2 : 0)) : (ac ? 0 : (bc ? 2 : 1));
+    const int msrc = sel == 0 ? pa : (sel == 1 ? pb : pc);
+    const W wp = sel == 0 ? wa : (sel == 1 ? wb : wc);
+    el = lane == l ? wp : (lane == msrc ? wlo : el);              // iter_swap(first, median)
+    const uint32_t pk = T::key(wp), k = T::key(el);
+    const bool in = lane > l && lane < h;
+    const bool isA = in && k >= pk, isB = in && k <= pk;
+    const uint64_t mA = __ballot(isA), mB = __ballot(isB);
+    const int rA = int(__builtin_amdgcn_mbcnt_hi(uint32_t(mA >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mA), 0u)));
+    const int Bge = int(__builtin_popcountll(mB)) -
+                    int(__builtin_amdgcn_mbcnt_hi(uint32_t(mB >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mB), 0u)));
+    const bool swapA = isA && (Bge - (isB ? 1 : 0)) > rA;         // B's strictly right of me > A's left of me
+    const bool swapB = isB && rA >= Bge;                          // A's strictly left of me > B's strictly right (= Bge - 1)
+    const int slot = swapA ? rA : (swapB ? 64 - Bge : 31);        // A number r -> slot r, B number s = Bge - 1 -> slot 63 - s
+    const W inbox = xbar_push(slot, el);
+    const int from = swapA ? 63 - rA : Bge - 1;
+    const W got = xbar_pull(from, inbox);
+    el = (swapA || swapB) ? got : el;
+    const uint64_t nsA = __ballot(isA && !swapA), sB = __ballot(swapB);
+    const int am = nsA ? int(__builtin_ctzll(nsA)) : h;
+    const int bl = sB ? int(__builtin_ctzll(sB)) : h;
+    const int cut = am < bl ? am : bl;
+    if (cut <= nr) l = cut; else h = cut;
+    if (guard == 255 && lane == 0) guard_hit(1);
+  }
+  if (!fallback) {                                               // __insertion_sort on the <= 3 elements left
+    const int m = h - l;
+    if (m >= 2) {
+      W w0 = rdlane(el, l), w1 = rdlane(el, l + 1);
+      if (w_less(w1, w0)) { const W t = w0; w0 = w1; w1 = t; }
+      if (m == 3) {
+        const W v = rdlane(el, l + 2);
+        if (w_less(v, w0)) { el = wrlane(el, v, l, lane); el = wrlane(el, w0, l + 1, lane); el = wrlane(el, w1, l + 2, lane); }
+        else if (w_less(v, w1)) { el = wrlane(el, w0, l, lane); el = wrlane(el, v, l + 1, lane); el = wrlane(el, w1, l + 2, lane); }
+        else { el = wrlane(el, w0, l, lane); el = wrlane(el, w1, l + 1, lane); }
+      } else {
+        el = wrlane(el, w0, l, lane); el = wrlane(el, w1, l + 1, lane);
+      }
+    }
+  }
+  if (lane < n) S.w[lo + lane] = el;
+  wave_lds_order();
+  if (fallback) {                                                // depth limit: __heap_select(first, nth + 1, last); iter_swap(first, nth)
+    if (lane == 0) {
+      s2_heap_select(S.w, lo + l, lo + nr + 1, lo + h);
+      const W t = S.w[lo + l]; S.w[lo + l] = S.w[lo + nr]; S.w[lo + nr] = t;
+    }
+    wave_lds_order();
+  }
+}
+
 // std::nth_element(first, first + nth, first + n) on S.w[0, n).  All 64*NW threads of the workgroup call this
 // (tid = threadIdx.x).  Ranges longer than sel2_capacity(1, SOLO) are partitioned by all NW waves together
 // (n <= sel2_capacity(NW, COOP)), shorter ones by wave 0 alone.
@@ -351,6 +465,7 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
         break;
       }
       --depth;
+      if (tid == 0) VC2_SEL_STAMP(210);                           // a cooperative round begins
       int cut;
       if constexpr (NWA == NW) {
         cut = sel2_partition<W, NW, 1, COOP>(S, lo, hi, S.la, S.lb, tid);
@@ -370,12 +485,23 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
   }
   if (!done && tid < 64) {
     for (int guard = 0; hi - lo > 3 && guard < 256; ++guard) {
+#ifndef VC2_NO_REG_TAIL
+      // (one-wave selections only: in the 16-wave channel selection the same tail measured 0.7 us SLOWER than the LDS
+      //  rounds it replaces -- 21.3 against 20.6 us over 1500 launches -- while k_select gained 2.2 us)
+      if (NW == 1 && hi - lo <= kSel2TailMax) {                    // the rest in registers (incl. the final insertion sort)
+        if (tid == 0) VC2_SEL_STAMP(250);
+        introselect_tail64<W>(S, lo, hi, nth, depth, tid);
+        done = true;
+        break;
+      }
+#endif
       if (depth == 0) {
         if (tid == 0) { s2_heap_select(S.w, lo, nth + 1, hi); const W t = S.w[lo]; S.w[lo] = S.w[nth]; S.w[nth] = t; }
         done = true;
         break;
       }
       --depth;
+      if (tid == 0) VC2_SEL_STAMP(230);                           // a one-wave LDS round begins
       const int cut = sel2_partition<W, 1, 0, SOLO>(S, lo, hi, S.la, S.lb, tid);
       if (cut <= nth) lo = cut; else hi = cut;
       if (guard == 255 && tid == 0) guard_hit(1);
