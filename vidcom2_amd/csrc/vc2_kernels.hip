@@ -951,6 +951,11 @@ constexpr uint32_t kBf16SpanLen = 0x3880u;    // ... up to 2^50 (0x5880)
 // T-rounded norm equals the exactly-rounded one already in den[]; when it does not, den[] is corrected and
 // the row is recorded so that k_centres can correct the column sums of its frame.  One wave per entry.
 struct NormCorr { int row; float den_old; float den_new; int frame; };   // capacity: one per row (cannot overflow)
+// Fused centre launch (k_frame_centres with the fix-ups as rider workgroups): the frame sums are formed WITHOUT the
+// corrections, so a frame with a corrected row is put on the pass's replay list as correction entries, one per block of
+// 64 columns (frame_replay_wave redoes those means with the corrections); fmark[frame] makes that happen once per
+// frame.  list == nullptr: off.
+struct FixPush { uint32_t* list; int* count; int cap; int* fmark; };
 
 // The queue of rows whose norm sits next to a T rounding boundary: 8-byte granules (row + 1) | den bits << 32 (den =
 // the denominator the sweep computed from the exactly rounded norm), each written by ONE store; the list is zeroed at
@@ -977,7 +982,8 @@ struct NormFixer {
   // the row's DMA into buf0 must have been issued (row_issue); buf0's zero pad element must be in place
   __device__ __forceinline__ void row(unsigned char* buf0, size_t rowb, int64_t row, float dn_old, int C, int N,
                                       float* __restrict__ den, int* __restrict__ corr_count,
-                                      NormCorr* __restrict__ corr, int max_entries, int lane) {
+                                      NormCorr* __restrict__ corr, int max_entries, int lane,
+                                      const FixPush& push = FixPush{nullptr, nullptr, 0, nullptr}) {
     row_wait();
     float xv[NPLB];
 #pragma unroll
@@ -996,6 +1002,16 @@ struct NormFixer {
       const int j = atomicAdd(corr_count, 1);
       if (j < max_entries) { corr[j].row = int(row); corr[j].den_old = dn_old; corr[j].den_new = dn; corr[j].frame = int(row / N); }
     }
+    if (changed && push.list) {                                  // (wave-uniform)
+      const int fr = int(row / N);
+      const int nbx = (C + 63) / 64;
+      int base = -1;
+      if (lane == 0 && atomicExch(push.fmark + fr, 1) == 0) base = atomicAdd(push.count, nbx);
+      base = __shfl(base, 0, 64);
+      if (base >= 0)                                              // one correction entry per block of 64 columns (frame_replay_wave)
+        for (int bx = lane; bx < nbx; bx += 64)
+          if (base + bx < push.cap) push.list[base + bx] = 0x80000000u | (uint32_t(fr) * uint32_t(nbx) + uint32_t(bx));
+    }
     wave_lds_fence();
     if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   }
@@ -1013,7 +1029,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
                                                                 float* __restrict__ den_out, double* __restrict__ part,
                                                                 int* __restrict__ tk, unsigned long long* __restrict__ fixq,
                                                                 int nfix_cap, uint8_t* __restrict__ rflag,
-                                                                OrderArgs rider, unsigned* __restrict__ dminkey) {
+                                                                OrderArgs rider) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Rider: when an ORDER job is attached, workgroup 0 replays torch.topk's sort of the kept channels (needed only by
   // the kernels AFTER this sweep) while the other workgroups stream -- no side stream, no extra kernel boundary.
@@ -1058,7 +1074,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   double acc[NPLB];
 #pragma unroll
   for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
-  float dmin_w = INFINITY;                                        // this wave's smallest denominator of the segment
   int n = n0 + wave;
   if (n < n1) row_issue<DT, VEC, VC2_AUX_S2>(x, int64_t(f) * N + n, D, CV, buf0, lane);
   for (; n < n1; n += kRowWaves) {
@@ -1079,7 +1094,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
         if (j < nfix_cap) __hip_atomic_store(fixq + j, fixq_pack(row, dn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (lane == 0) den_out[row] = dn;
-      dmin_w = fminf(dmin_w, dn);                                 // (NaN does not enter)
       return dn;
     };
     // rflag[row] = 1 marks the rows that divide exactly (consumed by sweep 3; bf16 in "torch order" mode)
@@ -1177,10 +1191,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     for (int w = 1; w < kRowWaves; ++w) t += sacc[w * NPLB * 64 + p];
     part[(int64_t(f) * S + sp) * C + p] = t;
   }
-  // modes 3 / 4: the frame's smallest denominator for the centre-mean margins -- 0x7F800000 - bits, ONE atomicMax per
-  // wave and segment, issued last so that nothing waits for it (per row it was 200 atomics on each of 128 addresses
-  // and doubled the sweep; in front of the combine the workgroup waited out its round trip: +3 us); key 0 = none yet
-  if (lane == 0 && dminkey && dmin_w < INFINITY) atomicMax(dminkey + f, 0x7F800000u - __float_as_uint(fabsf(dmin_w)));
   seg_a = seg_b;
   if (seg_a < row_b) __syncthreads();                            // (the next segment refills the row buffers)
   }
@@ -1194,7 +1204,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
                                                  float* __restrict__ den, const int* __restrict__ nfix_count,
                                                  const unsigned long long* __restrict__ fixq, int max_entries,
                                                  int* __restrict__ corr_count, NormCorr* __restrict__ corr,
-                                                 int N, unsigned* __restrict__ dminkey, int F) {
+                                                 int N, FixPush push) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = Tr<DT>::ES;
   const size_t rowb = row_lds_bytes(D, ES);
@@ -1203,22 +1213,7 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   if (blockIdx.x == 0 && lane == 0) VC2_STAMP(400);
   const int count = min(*nfix_count, max_entries);
   if (blockIdx.x == 0 && lane == 0) VC2_STAMP(401);
-  // modes 3 / 4: the frames' smallest denominators for the centre-mean margins (0x7F800000 - bits; key 0 = none), one
-  // wave per frame from den[] -- by the waves that have no queue entry, so that nothing waits for it.  (Until round 4
-  // sweep 2 left them behind through one atomicMax per wave and segment: +2 us on the sweep.  A denominator that
-  // another wave of this launch is correcting by an ulp may be read either way: abs_sum_bound allows for that.)
-  // (frames are dealt from the LAST workgroup down: the queue entries go to the first ones)
-  auto frame_dmins = [&]() {
-    if (!dminkey) return;
-    for (int f = int(gridDim.x) - 1 - int(blockIdx.x); f < F; f += int(gridDim.x)) {
-      float m = INFINITY;
-      for (int r = lane; r < N; r += 64) m = fminf(m, fabsf(den[int64_t(f) * N + r]));      // (NaN does not enter)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-      if (lane == 0) dminkey[f] = m < INFINITY ? 0x7F800000u - __float_as_uint(m) : 0u;
-    }
-  };
-  if (int(blockIdx.x) >= count) { frame_dmins(); return; }
+  if (int(blockIdx.x) >= count) return;
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   unsigned long long g = fixq[blockIdx.x];
   row_issue<DT, VEC>(x, int64_t(uint32_t(g)) - 1, D, CV, buf0, lane);   // first row's DMA overlaps the index loads below
@@ -1227,9 +1222,8 @@ __global__ __launch_bounds__(64) void k_norm_fix(const void* __restrict__ x, int
   for (int e = blockIdx.x; e < count; e += gridDim.x) {
     if (e != int(blockIdx.x)) { g = fixq[e]; row_issue<DT, VEC>(x, int64_t(uint32_t(g)) - 1, D, CV, buf0, lane); }
     fx.row(buf0, rowb, int64_t(uint32_t(g)) - 1, __uint_as_float(uint32_t(g >> 32)), C, N, den, corr_count, corr,
-           max_entries, lane);
+           max_entries, lane, push);
   }
-  frame_dmins();
   if (blockIdx.x == 0 && lane == 0) VC2_STAMP(409);
 }
 
@@ -1417,28 +1411,95 @@ struct FrameStatSrc {
   }
 };
 
+// Does the frame mean q = RN_f32(RN_f32(exact sum) / N) of (frame f, channel col) have to be replayed in torch's order?
+// (see kFragileUlpsMean / mean_delta; ab: the bound of sum |x^| used, for exchange 2 of the frame-sharded pass)
 template <int DT>
+__device__ __forceinline__ bool frame_mean_near(float q, bool bounded, bool all, int strict, double kk, double kk_a,
+                                                bool want_bounds, const FrameStatSrc& fs, int f, int col,
+                                                const void* __restrict__ x, int D, int N, float dmin, double& ab) {
+  if (!bounded) return all || mean_near_T_boundary<DT>(q);       // the empirical margin alone
+  // A >= sum_r |x^[r, c]| over the frame (see mean_delta).  |x^| <= 1 gives A <= N: only a mean with a boundary
+  // inside that margin fetches sweep 1's partials for the real one (want_bounds: the frame-sharded pass ships
+  // every group's bound with exchange 2, so all of them)
+  bool near = all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk))
+                                  : mean_near_T_boundary<DT>(q));
+  const bool pre_a = !near && strict != 3 && kk_a > 0.0 && T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk_a));
+  if ((want_bounds || (near && strict == 3) || pre_a) && fs.part) {
+    const double b = abs_sum_bound(fs.sumsq<DT>(f, col, x, D), N, dmin);
+    ab = b < double(N) ? b : double(N);            // (NaN: N)
+    if (near && !all && strict == 3) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk));
+    if (pre_a) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk_a));
+  } else {
+    ab = double(N);
+  }
+  return near;
+}
+
+// FUSED centre launch (round 4; single rank, 16-bit inputs, vector path): the norm fix-ups of sweep 2 (k_norm_fix's work)
+// run as RIDER workgroups of this launch -- its first fy grid rows, kFixWaves waves each, one queue entry per wave, row
+// buffers in dynamic LDS -- next to the frame workgroups, and NOBODY WAITS for anybody: the frame sums are formed without
+// the corrections; a rider that corrects a norm puts all means of that frame on the replay list (FixPush) and the
+// next launch (k_video_centre) adds the corrections to the video-centre sums.  One kernel boundary and the fix-ups'
+// latency chain (~7.5 us) off the critical path.  (An earlier form of this round had the frame workgroups WAIT for the
+// riders through an agent-scope counter: 26.7 us against 20.3 for the two kernels back to back -- every waiting
+// workgroup's acquire empties its XCD's L2.)
+struct FixRiders {
+  int fy;                                   // grid rows of rider workgroups (0: none -- k_norm_fix ran before this launch)
+  int CV, max_entries;
+  const int* nfix_count; const unsigned long long* fixq;
+  int* corr_count; NormCorr* corr; float* den;
+  FixPush push;
+};
+constexpr int kFixWaves = 4;
+
+template <int DT, int VEC, int NPLB>        // NPLB = 0: no rider code compiled in
 __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_q, int N,
                                                                    int C, float* __restrict__ fc,
                                                                    double* __restrict__ csum_part,
                                                                    const void* __restrict__ x, int D,
                                                                    const int* __restrict__ cols,
                                                                    const int* __restrict__ spos,
-                                                                   const float* __restrict__ den,
+                                                                   const float* den,
                                                                    const int* __restrict__ corr_count,
                                                                    const NormCorr* __restrict__ corr, int strict,
                                                                    int* __restrict__ vtick, FrameStatSrc fs,
                                                                    double kk, int want_bounds,
                                                                    float* __restrict__ dmin_out, double kk_a,
-                                                                   const unsigned* __restrict__ dminkey,
-                                                                   uint32_t* __restrict__ rlist, int rcap) {
+                                                                   uint32_t* __restrict__ rlist, int rcap, FixRiders fr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fix_rows[];     // riders: kFixWaves row buffers
   __shared__ double sm[kCentreFL][64];
   __shared__ double sb[kCentreFL][64];
   __shared__ uint32_t flist[kCen2List];            // local frame * 64 + local column
   __shared__ int count, rbase;
   const int tid = threadIdx.x, cl = tid & 63, fl = tid >> 6, lane = cl, wave = fl;
+  const int fy = NPLB > 0 ? fr.fy : 0;
+  if constexpr (NPLB > 0) {
+    if (int(blockIdx.y) < fy) {                                  // ---- a rider workgroup: one queue entry per wave
+      constexpr int ES = Tr<DT>::ES;
+      const size_t rowb = row_lds_bytes(D, ES);
+      const size_t stride = (std::max(rowb, size_t(C) * 4 + 16) + 15) / 16 * 16;
+      if (wave >= kFixWaves) return;
+      const int cnt = min(*fr.nfix_count, fr.max_entries);
+      const int nslots = fy * int(gridDim.x) * kFixWaves;
+      const int first = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kFixWaves + wave;
+      if (first >= cnt) return;
+      unsigned char* buf0 = fix_rows + size_t(wave) * stride;
+      if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
+      unsigned long long q = fr.fixq[first];
+      row_issue<DT, VEC>(x, int64_t(uint32_t(q)) - 1, D, fr.CV, buf0, lane);       // the first row's DMA overlaps the index loads
+      NormFixer<DT, VEC, NPLB> fx;
+      fx.init(cols, spos, C, int((rowb - 16) / ES), lane);
+      for (int e = first; e < cnt; e += nslots) {
+        if (e != first) { q = fr.fixq[e]; row_issue<DT, VEC>(x, int64_t(uint32_t(q)) - 1, D, fr.CV, buf0, lane); }
+        fx.row(buf0, rowb, int64_t(uint32_t(q)) - 1, __uint_as_float(uint32_t(q >> 32)), C, N, fr.den, fr.corr_count, fr.corr,
+               fr.max_entries, lane, fr.push);
+      }
+      return;
+    }
+  }
   const int c = blockIdx.x * 64 + cl;
-  const int g = blockIdx.y;
+  const int g = int(blockIdx.y) - fy;
+  const int FGn = int(gridDim.y) - fy;                           // frame groups of this launch
   const int f = g * kCentreFL + fl;
   const bool replay = strict != 0 && DT != VC2_F32;
   const bool all = strict == 2;
@@ -1450,9 +1511,16 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   // the frame's smallest denominator (wave fl = frame f): |x^| <= |x| / it.  (The loads are in flight with the ones below.)
   // kk_a > 0 (mode 4 "robust", the pass's own sweep-1 partials at hand): the empirical margin OR a boundary within
   // (kk_a A / n + 4 |q|) u -- the term that grows under cancellation (see the note at kFragileUlpsMean)
-  const bool bounded = replay && dminkey && (strict == 3 || want_bounds || kk_a > 0.0);   // margins relative to sum |x^|
-  // (sweep 2 left 0x7F800000 - bits(min den) per frame: one load instead of the frame's N denominators)
-  const float dmin = (bounded && f < F) ? __uint_as_float(0x7F800000u - dminkey[f]) : INFINITY;
+  const bool bounded = replay && (strict == 3 || want_bounds || kk_a > 0.0);   // margins relative to sum |x^|
+  // (wave fl reads its frame's N denominators -- in flight with the partial sums below.  A denominator that a rider of
+  //  this launch is correcting by an ulp may be read either way: abs_sum_bound allows for that.  Rounds 3 / early 4 had
+  //  sweep 2 leave the minimum behind through atomics: +2 us on the sweep.)
+  float dmin = INFINITY;
+  if (bounded && f < F) {
+    for (int r = lane; r < N; r += 64) dmin = fminf(dmin, fabsf(den[int64_t(f) * N + r]));          // (NaN does not enter)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+  }
   __syncthreads();
   double sf = 0.0, ab = 0.0;
   float q = 0.f;
@@ -1480,32 +1548,12 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     q = float(sf) / float(N);
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(501);
-  if (replay && !bounded) {                        // default: the empirical margin (see kFragileUlpsMean)
-    if (active && (all || mean_near_T_boundary<DT>(q))) {
+  if (replay) {
+    if (bounded && dmin_out && blockIdx.x == 0 && cl == 0 && f < F) dmin_out[f] = dmin;     // (k_video_centre's lazy bounds)
+    if (active && frame_mean_near<DT>(q, bounded, all, strict, kk, kk_a, want_bounds != 0, fs, f, cols ? cols[c] : c, x, D, N,
+                                      dmin, ab)) {
       const int j = atomicAdd(&count, 1);
       if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
-    }
-  } else if (replay) {                             // (wave-uniform)
-    if (dmin_out && blockIdx.x == 0 && cl == 0 && f < F) dmin_out[f] = dmin;     // (k_video_centre's lazy bounds)
-    if (active) {
-      // A >= sum_r |x^[r, c]| over the frame (see mean_delta).  |x^| <= 1 gives A <= N: only a mean with a boundary
-      // inside that margin fetches sweep 1's partials for the real one (want_bounds: the frame-sharded pass ships
-      // every group's bound with exchange 2, so all of them)
-      bool near = all || (strict == 3 ? T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk))
-                                      : mean_near_T_boundary<DT>(q));
-      const bool pre_a = !near && strict != 3 && kk_a > 0.0 && T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk_a));
-      if ((want_bounds || (near && strict == 3) || pre_a) && fs.part) {
-        const double b = abs_sum_bound(fs.sumsq<DT>(f, cols ? cols[c] : c, x, D), N, dmin);
-        ab = b < double(N) ? b : double(N);        // (NaN: N)
-        if (near && !all && strict == 3) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk));
-        if (pre_a) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk_a));
-      } else {
-        ab = double(N);
-      }
-      if (near) {
-        const int j = atomicAdd(&count, 1);
-        if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
-      }
     }
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(503);
@@ -1517,7 +1565,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 #pragma unroll
     for (int i = 0; i < kCentreFL; ++i) { t += sm[i][cl]; tb += sb[i][cl]; }
     csum_part[int64_t(g) * C + c] = t;
-    if (want_bounds) csum_part[(int64_t(gridDim.y) + g) * C + c] = tb;   // second half of the buffer: the groups' bounds
+    if (want_bounds) csum_part[(int64_t(FGn) + g) * C + c] = tb;         // second half of the buffer: the groups' bounds
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(505);
   if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
@@ -1537,10 +1585,20 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 
 // One boundary-near frame mean per wave (see k_frame_centres): the frame's N values of x^ in ONE round of loads, then
 // torch's outer-sum cascade from LDS (N <= kCFixSolo), else level-1 group by level-1 group.  xs: kCFixSolo floats of LDS.
+// Entries with bit 31 set (fused centre launch only) are CORRECTION entries: (frame f, block of 64 columns) of a frame
+// that holds a row whose norm a fix-up rider corrected -- k_frame_centres formed that frame's sums without the
+// correction.  The wave redoes k_frame_centres' arithmetic for those 64 means with the corrections added (same sum,
+// same margins: frame_mean_near) and replays the ones that need it on the spot.
+struct FrameFix {
+  const double* part; int S, S_q, strict; double kk, kk_a; FrameStatSrc fs;
+  const int* corr_count; const NormCorr* corr;
+};
 struct FrameReplay {
   const uint32_t* list; const int* count; int cap;   // entries frame * C + column (count may exceed cap: never written beyond)
   float* fc; int N;
+  FrameFix fix;
 };
+constexpr uint32_t kReplayFixTag = 0x80000000u;
 template <int DT>
 __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid, int nrid, float* xs,
                                                   const void* __restrict__ x, int D, int C,
@@ -1550,9 +1608,7 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
   const int cnt = min(*r.count, r.cap);
-  for (int e = rid; e < cnt; e += nrid) {
-    const uint32_t ent = r.list[e];
-    const int ff = int(ent / uint32_t(C)), cc = int(ent - uint32_t(ff) * uint32_t(C));
+  auto replay_one = [&](int ff, int cc) {                          // (wave-uniform arguments)
     const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
     float s;
     if (N <= kCFixSolo) {                                         // the frame's values in one round of loads, then LDS
@@ -1571,6 +1627,53 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
       s = wave_column_solo<DT>(xs, sp < simple_end, x, D, col, den, int64_t(ff) * N, N, lane);
     }
     if (lane == 0) r.fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
+  };
+  for (int e = rid; e < cnt; e += nrid) {
+    const uint32_t ent = r.list[e];
+    if (!(ent & kReplayFixTag)) {
+      const int ff = int(ent / uint32_t(C));
+      replay_one(ff, int(ent - uint32_t(ff) * uint32_t(C)));
+      continue;
+    }
+    // ---- a correction entry: lane = column bx * 64 + lane of frame f
+    const FrameFix& m = r.fix;
+    const int nbx = (C + 63) / 64;
+    const int f = int((ent & ~kReplayFixTag) / uint32_t(nbx)), bx = int((ent & ~kReplayFixTag) - uint32_t(f) * uint32_t(nbx));
+    const int c = bx * 64 + lane;
+    const bool active = c < C, all = m.strict == 2;
+    const bool bounded = m.strict == 3 || m.kk_a > 0.0;
+    float dmin = INFINITY;
+    if (bounded) {
+      for (int rr = lane; rr < N; rr += 64) dmin = fminf(dmin, fabsf(den[int64_t(f) * N + rr]));
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
+    }
+    bool near = false;
+    if (active) {
+      double sf = 0.0, ab = 0.0;
+      const int Sf = int((int64_t(f + 1) * N - 1) / m.S_q) - int((int64_t(f) * N) / m.S_q) + 1;
+      for (int s0 = 0; s0 < Sf; s0 += 8) {                        // (k_frame_centres' sum: split order)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = m.part[(int64_t(f) * m.S + min(s0 + u, Sf - 1)) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (s0 + u < Sf) sf += v[u];
+      }
+      const int col = cols ? cols[c] : c;
+      const int nc = *m.corr_count;
+      for (int e2 = 0; e2 < nc; ++e2) {
+        if (m.corr[e2].frame == f) {
+          const float v = ldT<DT>(x, int64_t(m.corr[e2].row) * D + col);
+          const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(m.corr[e2].den_old)));
+          const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(m.corr[e2].den_new)));
+          sf += double(xn) - double(xo);
+        }
+      }
+      r.fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
+      near = frame_mean_near<DT>(float(sf) / float(N), bounded, all, m.strict, m.kk, m.kk_a, false, m.fs, f, col, x, D, N, dmin, ab);
+    }
+    wave_lds_fence();
+    for (uint64_t mk = __ballot(near); mk; mk &= mk - 1) replay_one(f, bx * 64 + int(__builtin_ctzll(mk)));
   }
 }
 // the replays as their own launch (frame-sharded pass: its video centre is computed later, from the all-gathered sums)
@@ -1600,7 +1703,9 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       float* __restrict__ l1g, int vstride, int* __restrict__ vtick,
                                                       uint8_t* __restrict__ vflag, int rpr, double kk,
                                                       FrameStatSrc fs, const float* __restrict__ dmin, int F,
-                                                      FrameReplay frp = FrameReplay{}, int Ymain = 0) {
+                                                      FrameReplay frp = FrameReplay{}, int Ymain = 0,
+                                                      const int* __restrict__ vcorr_count = nullptr,
+                                                      const NormCorr* __restrict__ vcorr = nullptr) {
   __shared__ float l1s[kL1Cap + 4];                  // level-1 groups of one column
   // grid rows [Ymain, gridDim.y) (Ymain > 0) are RIDER waves: they replay the boundary-near frame means k_frame_centres
   // listed -- work that is independent of the video centre and hides under this kernel's own latency chain
@@ -1635,6 +1740,14 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (p0 + u < half) { t += v[u]; ab += w[u]; }
       }
+    }
+    // fused centre launch: the group sums were formed before the norm fix-ups -> their corrections are added here
+    const int nvc = vcorr_count ? *vcorr_count : 0;
+    for (int e = 0; e < nvc; ++e) {                               // (normally none)
+      const float v = ldT<DT>(x, int64_t(vcorr[e].row) * D + my_col);
+      const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(vcorr[e].den_old)));
+      const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(vcorr[e].den_new)));
+      t += double(xn) - double(xo);
     }
     if (y == 0) vc[c] = mean_T<DT>(t, R);
     q = float(t) / float(R);
@@ -2780,7 +2893,7 @@ struct Plan {
   int skew2_q10;                // how much the first split of a frame exceeds the mean, in 1/1024 (k_dist)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_dminkey, o_tmp_f32, o_rlist, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_fmark, o_tmp_f32, o_rlist, total_bytes;
   int vstride;
 };
 
@@ -2886,7 +2999,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_offs = take(size_t(F + 1) * 8);
   p->o_ticket = take(256);                                    // 64 ints (kTk*)
   p->o_nfixlist = take(size_t(p->R) * 8 + size_t(cdiv(F, 2)) * 8);   // 8-byte queue granules (fixq_pack); behind them, zeroed with them:
-  p->o_dminkey = p->o_nfixlist + size_t(p->R) * 8;            //   per frame 0x7F800000 - bits(smallest denominator) (sweep 2, atomicMax)
+  p->o_fmark = p->o_nfixlist + size_t(p->R) * 8;              //   per frame: "all its means are on the replay list" (FixPush)
   p->o_corr = take(size_t(p->R) * sizeof(NormCorr));
   {
     const int lpv = cascade_lp(p->R);           // level-1 groups of a video-centre column (k_video_centre's scratch)
@@ -2896,7 +3009,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_vticket = take(size_t(D) * 4);
   p->o_dmin = take(size_t(F) * 4);                 // per frame: the smallest denominator (centre-mean margins)
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
-  p->o_rlist = take(size_t(F) * D * 4);            // frame means to replay: frame * C + column (k_frame_centres -> frame_replay_wave)
+  p->o_rlist = take(size_t(2) * F * D * 4);        // frame means to replay: frame * C + column (k_frame_centres / fix riders -> frame_replay_wave)
   p->total_bytes = o;
   return VC2_OK;
 }
@@ -2997,16 +3110,17 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, vo
 // Opt a kernel into > 48 KiB of dynamic LDS -- once per (kernel, device), not per launch.
 std::mutex g_attr_mu;
 std::set<std::pair<const void*, int>> g_attr_done;
-template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what) {
-  if (smem <= 48 * 1024) return VC2_OK;
-  if (smem > 160 * 1024 - 256) return fail(VC2_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (D too large)", what, smem);
+// (static_lds: the kernel's own __shared__ arrays -- the dynamic part can only grow to what they leave)
+template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what, size_t static_lds = 0) {
+  if (smem <= 48 * 1024 - static_lds) return VC2_OK;
+  if (smem > 160 * 1024 - 256 - static_lds) return fail(VC2_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (D too large)", what, smem);
   int dev = 0;
   (void)hipGetDevice(&dev);
   const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
   std::lock_guard<std::mutex> lk(g_attr_mu);
   if (g_attr_done.count(key)) return VC2_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024 - 256);
+                                     int(160 * 1024 - 256 - static_lds));
   if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
   g_attr_done.insert(key);
   return VC2_OK;
@@ -3069,8 +3183,7 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                      dim3(kRowWaves * 64), smem, st, x,
                      int(p.N), int(p.D), p.CV, C, cols, cs.strict, p.S, p.S_q, p.R,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
-                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider,
-                     (unsigned*)nullptr);        // (the frames' smallest denominators: k_norm_fix derives them from den[], see there)
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -3090,8 +3203,7 @@ int launch_norm_fix_t(const Plan& p, const void* x, const ChanSet& cs, void* ws,
   hipLaunchKernelGGL((k_norm_fix<DT, VEC, NPLB>), dim3(unsigned(nfix)), dim3(64), smem1, st, x, int(p.D), p.CV, cs.C,
                      cs.cols, cs.spos, wsp<float>(ws, p.o_den), wsp<int>(ws, p.o_ticket) + kTkFixCount,
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<int>(ws, p.o_ticket) + kTkCorrCount,
-                     wsp<NormCorr>(ws, p.o_corr), int(p.N),
-                     (cs.strict == 3 || cs.strict == 4) ? wsp<unsigned>(ws, p.o_dminkey) : (unsigned*)nullptr, int(p.F));
+                     wsp<NormCorr>(ws, p.o_corr), int(p.N), FixPush{});
   return VC2_OK;
 }
 struct DistOut { void* v_T; void* f_T; float* total; };
@@ -3154,7 +3266,19 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   int rc = VC2_OK;
   VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_t, p, x, cs, ws, ride, st));
   if (rc) return rc; }
-  if (cs.strict) {
+  // Fused centre launch (see k_frame_centres): the norm fix-ups as rider workgroups -- single rank (the corrections of the
+  // video-centre sums are added by k_video_centre), 16-bit inputs on the vector path, <= 32 compact positions per lane
+  // (the rider's registers must fit a 1024-thread workgroup), frames short enough for the replays; else, and for
+  // per-kernel timing, k_norm_fix runs first and k_frame_centres applies its corrections itself.
+  const bool replays = cs.strict != 0 && p.dt != VC2_F32;
+  const int rcap = int(std::min<int64_t>(2 * p.F * int64_t(C), INT32_MAX));
+#ifdef VC2_NO_FUSED_FIX
+  const bool fused = false;
+#else
+  const bool fused = replays && single_rank && !g_prof && p.VEC > 1 && npl <= 32 && (((p.N >> 4) + 15) >> 4) <= kCFixSolo &&
+                     2 * p.F * int64_t(C) <= INT32_MAX;
+#endif
+  if (cs.strict && !fused) {
     ProfScope ps_(KID_OTHER, st);
     int rc = VC2_OK;
     VC2_DISPATCH_VEC(p, rc = VC2_DISPATCH_NPL(npl, launch_norm_fix_t, p, x, cs, ws, st));
@@ -3162,22 +3286,43 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   }
   { ProfScope ps_(KID_CENTRES, st);
   const int FG = int(cdiv(p.F, kCentreFL));
-  VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_centres<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(FG)),
-                                           dim3(64 * kCentreFL), 0, st, part, int(p.F), p.S, p.S_q, int(p.N), C,
-                                           wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
-                                           wsp<float>(ws, p.o_den),
-                                           cs.strict ? wsp<int>(ws, p.o_ticket) + 3 : (int*)nullptr,
-                                           wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs,
-                                           margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0,
-                                           wsp<float>(ws, p.o_dmin),
-                                           (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0,
-                                           (cs.strict == 3 || cs.strict == 4) ? wsp<unsigned>(ws, p.o_dminkey) : (const unsigned*)nullptr,
-                                           wsp<uint32_t>(ws, p.o_rlist), int(std::min<int64_t>(p.F * int64_t(C), INT32_MAX))));
+  // rider rows: fp16 queues ~3 % of the rows (its T ulp is 2^13 fp32 ulps), bf16 ~0.4 %; debug mode 2 all of them
+  const int bxn = int(cdiv(C, 64));
+  const int fy = !fused ? 0 : int(cdiv(cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 1024 : 256), bxn * kFixWaves));
+  const FixRiders fr{fy, p.CV, int(p.R), wsp<int>(ws, p.o_ticket) + kTkFixCount, wsp<unsigned long long>(ws, p.o_nfixlist),
+                     wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr), wsp<float>(ws, p.o_den),
+                     FixPush{wsp<uint32_t>(ws, p.o_rlist), wsp<int>(ws, p.o_ticket) + kTkFrameReplays, rcap, wsp<int>(ws, p.o_fmark)}};
+  const size_t fix_lds = !fused ? 0 : kFixWaves * ((std::max(row_lds_bytes(int(p.D), p.ES), size_t(C) * 4 + 16) + 15) / 16 * 16);
+  int rcl = VC2_OK;
+  auto launch_fc = [&](auto kernel) {
+    if ((rcl = allow_big_lds(kernel, fix_lds, "k_frame_centres", 24 * 1024))) return;
+    hipLaunchKernelGGL(kernel, dim3(unsigned(bxn), unsigned(FG + fy)), dim3(64 * kCentreFL), fix_lds, st,
+                       part, int(p.F), p.S, p.S_q, int(p.N), C, wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
+                       wsp<float>(ws, p.o_den),
+                       (cs.strict && !fused) ? wsp<int>(ws, p.o_ticket) + kTkCorrCount : (int*)nullptr,
+                       wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs,
+                       margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0, wsp<float>(ws, p.o_dmin),
+                       (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, wsp<uint32_t>(ws, p.o_rlist), rcap, fr);
+  };
+  if (!fused) {
+    VC2_DISPATCH_DT(p.dt, launch_fc(k_frame_centres<DT, 1, 0>));
+  } else if (p.dt == VC2_BF16) {
+    constexpr int DT = VC2_BF16, VEC = Tr<VC2_BF16>::VEC;
+    if (npl <= 8) launch_fc(k_frame_centres<DT, VEC, 8>); else if (npl <= 16) launch_fc(k_frame_centres<DT, VEC, 16>);
+    else if (npl <= 28) launch_fc(k_frame_centres<DT, VEC, 28>); else launch_fc(k_frame_centres<DT, VEC, 32>);
+  } else {
+    constexpr int DT = VC2_F16, VEC = Tr<VC2_F16>::VEC;
+    if (npl <= 8) launch_fc(k_frame_centres<DT, VEC, 8>); else if (npl <= 16) launch_fc(k_frame_centres<DT, VEC, 16>);
+    else if (npl <= 28) launch_fc(k_frame_centres<DT, VEC, 28>); else launch_fc(k_frame_centres<DT, VEC, 32>);
+  }
+  if (rcl) return rcl;
   // the frame means k_frame_centres listed are replayed by rider waves of the video-centre launch (single rank), or
   // by a launch of their own (frame-sharded pass: its video centre comes later, from the all-gathered sums)
-  const bool replays = cs.strict != 0 && p.dt != VC2_F32;
-  const FrameReplay frp{wsp<uint32_t>(ws, p.o_rlist), wsp<int>(ws, p.o_ticket) + kTkFrameReplays,
-                        int(std::min<int64_t>(p.F * int64_t(C), INT32_MAX)), wsp<float>(ws, p.o_fc), int(p.N)};
+  const FrameReplay frp{wsp<uint32_t>(ws, p.o_rlist), wsp<int>(ws, p.o_ticket) + kTkFrameReplays, rcap,
+                        wsp<float>(ws, p.o_fc), int(p.N),
+                        FrameFix{part, p.S, p.S_q, cs.strict, margin_depth(p.N, cs.strict),
+                                 (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, fs,
+                                 wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr)}};
   const int rwaves = cs.strict == 2 ? 8192 : 1024;             // rider waves (debug mode 2 replays every mean)
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
@@ -3190,7 +3335,9 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                              wsp<int>(ws, p.o_ticket) + kTkVcFragile,
                                              wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
                                              (uint8_t*)nullptr, 0, margin_depth(p.R, cs.strict), fs,
-                                             wsp<float>(ws, p.o_dmin), int(p.F), frp, Y));
+                                             wsp<float>(ws, p.o_dmin), int(p.F), frp, Y,
+                                             fused ? wsp<int>(ws, p.o_ticket) + kTkCorrCount : (const int*)nullptr,
+                                             wsp<NormCorr>(ws, p.o_corr)));
   } else if (replays) {
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_replay<DT>), dim3(unsigned(rwaves)), dim3(64), 0, st, frp, x, int(p.D),
                                              C, cs.cols, cs.spos, wsp<float>(ws, p.o_den)));
