@@ -1010,7 +1010,7 @@ struct NormFixer {
       base = __shfl(base, 0, 64);
       if (base >= 0)                                              // one correction entry per block of 64 columns (frame_replay_wave)
         for (int bx = lane; bx < nbx; bx += 64)
-          if (base + bx < push.cap) push.list[base + bx] = 0x80000000u | (uint32_t(fr) * uint32_t(nbx) + uint32_t(bx));
+          if (base + bx < push.cap) push.list[base + bx] = uint32_t(fr) * uint32_t(nbx) + uint32_t(bx);
     }
     wave_lds_fence();
     if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
@@ -1451,6 +1451,7 @@ struct FixRiders {
   FixPush push;
 };
 constexpr int kFixWaves = 4;
+constexpr int kTkFixEntries = 8;             // ticket word: correction entries of the pass (FixPush)
 
 template <int DT, int VEC, int NPLB>        // NPLB = 0: no rider code compiled in
 __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_q, int N,
@@ -1585,7 +1586,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 
 // One boundary-near frame mean per wave (see k_frame_centres): the frame's N values of x^ in ONE round of loads, then
 // torch's outer-sum cascade from LDS (N <= kCFixSolo), else level-1 group by level-1 group.  xs: kCFixSolo floats of LDS.
-// Entries with bit 31 set (fused centre launch only) are CORRECTION entries: (frame f, block of 64 columns) of a frame
+// The second list (fused centre launch only) holds CORRECTION entries: (frame f, block of 64 columns) of a frame
 // that holds a row whose norm a fix-up rider corrected -- k_frame_centres formed that frame's sums without the
 // correction.  The wave redoes k_frame_centres' arithmetic for those 64 means with the corrections added (same sum,
 // same margins: frame_mean_near) and replays the ones that need it on the spot.
@@ -1597,8 +1598,8 @@ struct FrameReplay {
   const uint32_t* list; const int* count; int cap;   // entries frame * C + column (count may exceed cap: never written beyond)
   float* fc; int N;
   FrameFix fix;
-};
-constexpr uint32_t kReplayFixTag = 0x80000000u;
+  const uint32_t* list2; const int* count2; int cap2;   // correction entries frame * nbx + column block: taken FIRST (the
+};                                                      // longest items -- a block's sums, margins, then its replays one by one)
 template <int DT>
 __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid, int nrid, float* xs,
                                                   const void* __restrict__ x, int D, int C,
@@ -1607,7 +1608,7 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
   const int N = r.N;
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
-  const int cnt = min(*r.count, r.cap);
+  const int cnt1 = min(*r.count, r.cap), cnt2 = r.list2 ? min(*r.count2, r.cap2) : 0;
   auto replay_one = [&](int ff, int cc) {                          // (wave-uniform arguments)
     const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
     float s;
@@ -1628,17 +1629,18 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
     }
     if (lane == 0) r.fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
   };
-  for (int e = rid; e < cnt; e += nrid) {
-    const uint32_t ent = r.list[e];
-    if (!(ent & kReplayFixTag)) {
+  for (int e = rid; e < cnt1 + cnt2; e += nrid) {
+    if (e >= cnt2) {
+      const uint32_t ent = r.list[e - cnt2];
       const int ff = int(ent / uint32_t(C));
       replay_one(ff, int(ent - uint32_t(ff) * uint32_t(C)));
       continue;
     }
     // ---- a correction entry: lane = column bx * 64 + lane of frame f
+    const uint32_t ent = r.list2[e];
     const FrameFix& m = r.fix;
     const int nbx = (C + 63) / 64;
-    const int f = int((ent & ~kReplayFixTag) / uint32_t(nbx)), bx = int((ent & ~kReplayFixTag) - uint32_t(f) * uint32_t(nbx));
+    const int f = int(ent / uint32_t(nbx)), bx = int(ent - uint32_t(f) * uint32_t(nbx));
     const int c = bx * 64 + lane;
     const bool active = c < C, all = m.strict == 2;
     const bool bounded = m.strict == 3 || m.kk_a > 0.0;
@@ -3271,12 +3273,13 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   // (the rider's registers must fit a 1024-thread workgroup), frames short enough for the replays; else, and for
   // per-kernel timing, k_norm_fix runs first and k_frame_centres applies its corrections itself.
   const bool replays = cs.strict != 0 && p.dt != VC2_F32;
-  const int rcap = int(std::min<int64_t>(2 * p.F * int64_t(C), INT32_MAX));
+  const int rcap = int(std::min<int64_t>(p.F * int64_t(C), INT32_MAX / 2));      // regular entries: every mean at most once
+  const int rcap2 = int(p.F * cdiv(C, 64));                                        // correction entries: every (frame, column block) once
 #ifdef VC2_NO_FUSED_FIX
   const bool fused = false;
 #else
   const bool fused = replays && single_rank && !g_prof && p.VEC > 1 && npl <= 32 && (((p.N >> 4) + 15) >> 4) <= kCFixSolo &&
-                     2 * p.F * int64_t(C) <= INT32_MAX;
+                     p.F * int64_t(C) <= INT32_MAX / 2;
 #endif
   if (cs.strict && !fused) {
     ProfScope ps_(KID_OTHER, st);
@@ -3291,7 +3294,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   const int fy = !fused ? 0 : int(cdiv(cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 1024 : 256), bxn * kFixWaves));
   const FixRiders fr{fy, p.CV, int(p.R), wsp<int>(ws, p.o_ticket) + kTkFixCount, wsp<unsigned long long>(ws, p.o_nfixlist),
                      wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr), wsp<float>(ws, p.o_den),
-                     FixPush{wsp<uint32_t>(ws, p.o_rlist), wsp<int>(ws, p.o_ticket) + kTkFrameReplays, rcap, wsp<int>(ws, p.o_fmark)}};
+                     FixPush{wsp<uint32_t>(ws, p.o_rlist) + rcap, wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2, wsp<int>(ws, p.o_fmark)}};
   const size_t fix_lds = !fused ? 0 : kFixWaves * ((std::max(row_lds_bytes(int(p.D), p.ES), size_t(C) * 4 + 16) + 15) / 16 * 16);
   int rcl = VC2_OK;
   auto launch_fc = [&](auto kernel) {
@@ -3322,7 +3325,9 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                         wsp<float>(ws, p.o_fc), int(p.N),
                         FrameFix{part, p.S, p.S_q, cs.strict, margin_depth(p.N, cs.strict),
                                  (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, fs,
-                                 wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr)}};
+                                 wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr)},
+                        fused ? wsp<uint32_t>(ws, p.o_rlist) + rcap : (const uint32_t*)nullptr,
+                        wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2};
   const int rwaves = cs.strict == 2 ? 8192 : 1024;             // rider waves (debug mode 2 replays every mean)
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
