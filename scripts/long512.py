@@ -1,5 +1,6 @@
 """Timing of the 512-frame clip (720 MB) for a library build: VC2_LIB_PATH=... python scripts/long512.py"""
-import time, torch
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vidcom2_amd as vc
 F, N, D = 512, 196, 3584
 x = torch.randn(F * N, D, device="cuda", dtype=torch.float32).to(torch.bfloat16)
