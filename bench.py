@@ -25,7 +25,9 @@ One JSON line on rank 0 (see the repo prompt for the contract), with extra objec
   "roofline"      the dominant kernel's achieved algorithmic HBM rate (hipEvent-timed inside this run)
   "roofline_big"  the same for a > 256 MiB working set (cfg3), where the Infinity Cache cannot hold X
   "cpu_baseline"  the reference CPU path on this box's host cores: kind "port", flavour "torch-restatement" (the same
-                  aten ops, oracle/torch_restatement.py) and, nested under "port", the C++/OpenMP oracle
+                  aten ops, oracle/torch_restatement.py) and, nested under "port", the C++/OpenMP oracle -- each at the
+                  best of several thread counts (all 256 hardware threads oversubscribe torch's small ops)
+  "pass_roofline" the whole pass against 8 TB/s in three states of the input: warm (= value), cold, producer_warm
 """
 from __future__ import annotations
 
@@ -123,38 +125,55 @@ def median_step_ms(fn, steps):
 def cpu_baselines(x_cpu, N, base, budget_s=10.0):
     """The reference CPU path on this box's host cores, two ways, on full passes of the same workload:
     'torch-restatement' -- the same aten ops in the same order (oracle/torch_restatement.py, pinned bit-exact against
-    the reference's fixtures) with torch's own threading; 'port' -- the C++/OpenMP oracle (oracle/vc2_oracle.cpp)."""
+    the reference's fixtures) with torch's own threading; 'port' -- the C++/OpenMP oracle (oracle/vc2_oracle.cpp).
+    Both are run at several thread counts (one pass each) and then timed at the best one: with every hardware thread
+    (256 here) torch's small ops oversubscribe and the same pass runs an order of magnitude slower than with 16-32."""
     import oracle
     from oracle import torch_restatement as T
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    T.compress(x_cpu[: 8 * N], N, base)                 # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        rt = T.compress(x_cpu, N, base)
-        reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 10:
-            break
-    dt = (time.perf_counter() - t0) / reps
-    out = {"value": x_cpu.shape[0] / dt, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    counts = sorted({c for c in (8, 16, 32, 64, 128, 256, cores) if c <= cores})
+
+    def best_of(run, set_threads):
+        tried = {}
+        for c in counts:
+            set_threads(c)
+            run(x_cpu[: 8 * N])                         # warm at this count (thread pool, page-in)
+            ts = []
+            for _ in range(2):                          # (the second pass: caches and the thread pool are warm)
+                t0 = time.perf_counter()
+                run(x_cpu)
+                ts.append(time.perf_counter() - t0)
+            tried[c] = min(ts)
+            if tried[c] > 4 * min(tried.values()):      # far off the best already: larger counts only get worse
+                break
+        c = min(tried, key=tried.get)
+        set_threads(c)
+        t0 = time.perf_counter()
+        reps, last = 0, None
+        while True:
+            last = run(x_cpu)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= 10:
+                break
+        return c, (time.perf_counter() - t0) / reps, reps, last, tried
+
+    c1, dt, reps, rt, tried1 = best_of(lambda xx: T.compress(xx, N, base), torch.set_num_threads)
+    out = {"value": x_cpu.shape[0] / dt, "unit": "tokens/s", "cores": c1, "kind": "port",
            "flavour": "torch-restatement",       # (oracle/torch_restatement.py: the reference's own torch CPU ops, op for op)
            "sample": f"{reps} full passes of the same workload ({x_cpu.shape[0]} tokens each), {dt * 1e3:.1f} ms/pass, "
-                     "torch CPU ops in the reference's order"}
-    oracle.set_num_threads(cores)
+                     f"torch CPU ops in the reference's order, {c1} threads = the best of "
+                     + ", ".join(f"{c}: {t * 1e3:.0f} ms" for c, t in tried1.items()) + f" (host has {cores})"}
     oracle.set_mode("torch")             # same semantics as the HIP path's default mode
-    oracle.compress_indices(x_cpu[: 8 * N], N, base)   # warm (library load, page-in)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        o = oracle.compress_indices(x_cpu, N, base)
-        _ = x_cpu[o["global_idx"]]
-        reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 10:
-            break
-    dt2 = (time.perf_counter() - t0) / reps
-    out["port"] = {"value": x_cpu.shape[0] / dt2, "unit": "tokens/s", "cores": cores, "kind": "port",
-                   "sample": f"{reps} full passes, {dt2 * 1e3:.1f} ms/pass, C++/OpenMP oracle in 'torch order' mode"}
+
+    def run_oracle(xx):
+        o = oracle.compress_indices(xx, N, base)
+        _ = xx[o["global_idx"]]
+        return o
+    c2, dt2, reps2, o, tried2 = best_of(run_oracle, oracle.set_num_threads)
+    out["port"] = {"value": x_cpu.shape[0] / dt2, "unit": "tokens/s", "cores": c2, "kind": "port",
+                   "sample": f"{reps2} full passes, {dt2 * 1e3:.1f} ms/pass, C++/OpenMP oracle in 'torch order' mode, {c2} threads "
+                             "= the best of " + ", ".join(f"{c}: {t * 1e3:.0f} ms" for c, t in tried2.items())}
+    torch.set_num_threads(cores)
     # the two CPU statements and the reference agree: same kept indices
     assert rt["ks"] == o["ks"].tolist() and torch.equal(rt["global_idx"], o["global_idx"]), "CPU baselines disagree"
     return out, o
@@ -383,6 +402,44 @@ def main():
     out["mode"] = _ffi.get_mode() + (" (bit-exact to the CPU reference: boundary-fragile tokens replay torch's fp32 "
                                      "accumulation order)" if _ffi.get_mode() == "torch" else "")
     if not dist_on:
+        # `value` / ms_per_step above is the WARM number: the loop re-reads one tensor, and X (171 MiB at the target
+        # shape) is largely still in the 256 MiB Infinity Cache when the next step starts.  Two more states of the input,
+        # same plan, same kernels, each with its fraction of the 8 TB/s roofline:
+        #   cold            three different clips in turn (513 MiB of inputs: a step's X was evicted by the two before)
+        #   producer_warm   X is WRITTEN by a device copy right before every pass, as the projector / pooling kernel
+        #                   of the model would leave it (the copy is not timed: hipEvents around the pass only)
+        ab = alg_bytes_pass(F, N, D, es, base)
+        pr = out["pass_roofline"]
+        pr["input_state"] = "warm (the same tensor every step)"
+        nst = max(args.steps, 20)
+        xs3 = [x] + [synth.make(F, N, D, dtype, seed=sd, dist="drift").to(dev) for sd in (1, 2)]
+        turn = [0]
+
+        def rotate():
+            plan.enqueue(xs3[turn[0] % 3])
+            turn[0] += 1
+        for _ in range(max(args.warmup, 6)):
+            rotate()
+        e_cold = time_steps(rotate, nst, False) / nst
+        pr["cold_ms_per_step"] = round(e_cold * 1e3, 4)
+        pr["cold_frac_of_8TBs"] = round(ab / e_cold / 1e9 / HBM_PEAK_GBS, 4)
+        pr["cold_tokens_per_s"] = round(F * N / e_cold, 1)
+        xw = torch.empty_like(x)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nst)]
+        for i in range(5):
+            xw.copy_(xs3[i % 3]); plan.enqueue(xw)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(ev):
+            xw.copy_(xs3[i % 3])
+            a.record(); plan.enqueue(xw); b.record()
+        torch.cuda.synchronize()
+        e_pw = statistics.mean(a.elapsed_time(b) for a, b in ev) * 1e-3
+        pr["producer_warm_ms_per_step"] = round(e_pw * 1e3, 4)
+        pr["producer_warm_frac_of_8TBs"] = round(ab / e_pw / 1e9 / HBM_PEAK_GBS, 4)
+        pr["note"] = ("value / ms_per_step = the warm state; cold = three clips in turn; producer_warm = X written by a "
+                      "device copy immediately before each pass (hipEvents around the pass)")
+        del xs3, xw
+    if not dist_on:
         out["median_ms_per_step"] = round(median_step_ms(step, max(args.steps, 20)), 4)
     else:
         # the exchanges of the sharded pass, one by one: hipEvents around every all-gather of `steps` more passes
@@ -558,21 +615,6 @@ def main():
         e4 = time_steps(two, args.steps, False)
         out["two_clips_in_flight"] = {"ms_per_round": round(e4 / args.steps * 1e3, 4),
                                       "tokens_per_s": round(2 * F * N / (e4 / args.steps), 1)}
-        # ---- side: ONE clip at a time, but three different clips in turn: the input of a step is then not what the
-        #      previous step left in the Infinity Cache (the headline loop re-reads the same 171 MiB tensor) -----------
-        xs3 = xs2 + [synth.make(F, N, D, dtype, seed=2, dist="drift").to(dev)]
-        turn = [0]
-
-        def rotate():
-            plan.enqueue(xs3[turn[0] % 3])
-            turn[0] += 1
-        for _ in range(args.warmup):
-            rotate()
-        e5 = time_steps(rotate, args.steps, False)
-        out["rotating_inputs"] = {"ms_per_step": round(e5 / args.steps * 1e3, 4),
-                                  "tokens_per_s": round(F * N / (e5 / args.steps), 1),
-                                  "note": "three different clips in turn: 513 MiB of inputs against the 256 MiB Infinity Cache"}
-        del xs3
 
     # ---- side: the other dtypes of BASELINE.json's shapes, each behind its own parity gate (C++ oracle, same tensor):
     #      the target shape in fp32, and ONE clip of the batched-eval config (128 x 196 x 4096 fp16) --------------
