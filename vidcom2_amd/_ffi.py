@@ -121,7 +121,30 @@ def on_device(device):
     """Context: make `device` the current HIP device for the duration of a library call.  The C ABI launches on the
     stream it is given but keys per-device state (LDS opt-in, events) on the CURRENT device, and a tensor may live on
     a GPU that is not current (HF device_map='auto' puts the vision tower's output anywhere)."""
-    return torch.cuda.device(device)
+    return _OnDevice(device)
+
+
+class _OnDevice:
+    """torch.cuda.device(device), but free when `device` is current already (the usual case: three nested guards on
+    the one-shot path cost ~12 us of hipGetDevice / hipSetDevice pairs)."""
+    __slots__ = ("_idx", "_ctx")
+
+    def __init__(self, device):
+        d = torch.device(device) if not isinstance(device, int) else None
+        self._idx = device if d is None else d.index
+        self._ctx = None
+
+    def __enter__(self):
+        if self._idx is not None and torch.cuda.current_device() != self._idx:
+            self._ctx = torch.cuda.device(self._idx)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
 
 
 def ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:

@@ -339,12 +339,13 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
                                                                 void* __restrict__ var_T, float* __restrict__ var_f32,
                                                                 int* __restrict__ counters, PartSrc ps, FoldTab ft,
                                                                 unsigned long long* __restrict__ fixq = nullptr,
-                                                                int nfixq = 0) {
+                                                                int nfixq = 0, unsigned long long* __restrict__ kstatus = nullptr) {
   // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
   // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
   __shared__ double sm[3][kRedGL][64];
   if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(100);
   if (counters && blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;  // strict-mode queues of this pass
+  if (kstatus && blockIdx.x == 0 && threadIdx.x == 0) *kstatus = 0ull;             // K_out[1]: k_select ORs its bits in
   if (fixq) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfixq; i += gridDim.x * blockDim.x) fixq[i] = 0ull;
   const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -420,11 +421,11 @@ template <typename W>
 __device__ __forceinline__ void chan_select_body(unsigned char* smem, const float (&pre)[kSelPre], int D, int k,
                                                  uint8_t* __restrict__ mask, int* __restrict__ cols,
                                                  int* __restrict__ perm, uint32_t* __restrict__ wperm,
-                                                 uint32_t* __restrict__ wcpos) {
+                                                 uint32_t* __restrict__ wcpos, int* status) {
   using T = WordTr<W>;
   constexpr int NW = kSelNT / 64;
   const int tid = threadIdx.x;
-  Sel2<W> S = sel2_carve<W>(smem, D);
+  Sel2<W> S = sel2_carve<W>(smem, D, status);
 #pragma unroll
   for (int j = 0; j < kSelPre; ++j) { const int i = tid + j * kSelNT; if (i < D) S.w[i] = T::pack(topk_key(pre[j]), i); }
   __syncthreads();
@@ -462,7 +463,7 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
 __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
                                                         int* __restrict__ perm, uint32_t* __restrict__ wperm,
-                                                        uint32_t* __restrict__ wcpos) {
+                                                        uint32_t* __restrict__ wcpos, int* status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int bad = 0;
   if (threadIdx.x == 0) VC2_STAMP(200);
@@ -473,8 +474,8 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   for (int j = 0; j < kSelPre; ++j) bad |= key_fits_u32(pre[j]) ? 0 : 1;
   // widened 16-bit variances pack into 32-bit words (the common case); arbitrary fp32 ones take 64-bit words
   // (wperm / wcpos are only requested for 16-bit inputs)
-  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr);
-  else chan_select_body<uint32_t>(smem, pre, D, k, mask, cols, perm, wperm, wcpos);
+  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr, status);
+  else chan_select_body<uint32_t>(smem, pre, D, k, mask, cols, perm, wperm, wcpos, status);
   if (threadIdx.x == 0) VC2_STAMP(209);
 }
 __host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
@@ -489,11 +490,11 @@ __device__ __forceinline__ void chan_order_body(unsigned char* smem, const float
                                                 int* __restrict__ order, int* __restrict__ opos,
                                                 int* __restrict__ spos, int part, int nparts,
                                                 const uint32_t* __restrict__ wperm = nullptr,
-                                                const uint32_t* __restrict__ wcpos = nullptr) {
+                                                const uint32_t* __restrict__ wcpos = nullptr, int* status = nullptr) {
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
-  Sel2<W> S = sel2_carve<W>(smem, k);
+  Sel2<W> S = sel2_carve<W>(smem, k, status);
   unsigned char* p = smem + (sel2_bytes(k, int(sizeof(W))) + 15) / 16 * 16;
   SortScratch2 Q = sort2_carve(p, NW);
   uint16_t* cpos = reinterpret_cast<uint16_t*>(p + (sort2_bytes(k, NW) + 15) / 16 * 16);   // [D] channel -> position in cols
@@ -529,6 +530,7 @@ __host__ inline size_t chan_order_lds(int D, int k, int wbytes) {
 struct OrderArgs {          // the ORDER job (all null: none), done by `parts` workgroups side by side
   const float* var_f32; const int* perm; const int* cols; int* order; int* opos; int* spos; int D; int k; int parts;
   const uint32_t* wperm; const uint32_t* wcpos;        // optional: k_chan_select's packed words / cols positions
+  int* status;                                         // optional: the pass's status word (selection guard hits)
 };
 // workgroups for the ORDER job: 2^L arrival segments of >= 128 positions on average
 #ifndef VC2_RIDER_PARTS
@@ -554,10 +556,10 @@ __global__ __launch_bounds__(kOrdNT) void k_chan_order(OrderArgs a) {
   for (int i = threadIdx.x; i < a.k; i += kOrdNT) bad |= key_fits_u32(a.var_f32[a.perm[i]]) ? 0 : 1;
   if (__syncthreads_or(bad))
     chan_order_body<uint64_t, NW, 4, 8>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
-                                        int(blockIdx.x), int(gridDim.x));
+                                        int(blockIdx.x), int(gridDim.x), nullptr, nullptr, a.status);
   else
     chan_order_body<uint32_t, NW, 4, 8>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
-                                        int(blockIdx.x), int(gridDim.x), a.wperm, a.wcpos);
+                                        int(blockIdx.x), int(gridDim.x), a.wperm, a.wcpos, a.status);
 }
 
 template <int DT>
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
     if (int(blockIdx.x) < nrider) {
       chan_order_body<uint32_t, kRowWaves, 4, 4>(smem, rider.var_f32, rider.D, rider.k, rider.perm, rider.cols,
                                                  rider.order, rider.opos, rider.spos,    // (16-bit variances: 32-bit words)
-                                                 int(blockIdx.x), nrider, rider.wperm, rider.wcpos);
+                                                 int(blockIdx.x), nrider, rider.wperm, rider.wcpos, rider.status);
       VC2_WGTIME(1, 1);
       return;
     }
@@ -1566,7 +1568,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 #pragma unroll
     for (int i = 0; i < kCentreFL; ++i) { t += sm[i][cl]; tb += sb[i][cl]; }
     csum_part[int64_t(g) * C + c] = t;
-    if (want_bounds) csum_part[(int64_t(FGn) + g) * C + c] = tb;         // second half of the buffer: the groups' bounds
+    csum_part[(int64_t(FGn) + g) * C + c] = tb;    // second half of the buffer: the groups' bounds (zeros unless want_bounds:
+                                                   // exchange 2 of the frame-sharded pass ships both halves)
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(505);
   if (!replay || (((N >> 4) + 15) >> 4) > kCFixSolo) return;
@@ -2519,10 +2522,10 @@ __device__ __forceinline__ void select_frame_load(unsigned char* smem, const flo
 template <int DT, typename W>
 __device__ __forceinline__ void select_frame_body(unsigned char* smem, const float* __restrict__ total, int f, int N, int k,
                                   int64_t o0, int map_mode, int grid_h, int64_t stride, int64_t cap,
-                                  int64_t* __restrict__ idx_out) {
+                                  int64_t* __restrict__ idx_out, int* status) {
   using T = WordTr<W>;
   const int tid = threadIdx.x;
-  Sel2<W> S = sel2_carve<W>(smem, N);
+  Sel2<W> S = sel2_carve<W>(smem, N, status);
   // (the frame's words were packed into S.w by select_frame_load before the budgets were derived)
   __syncthreads();
   if (tid == 0 && f == 0) VC2_STAMP(802);
@@ -2573,7 +2576,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
                                                      const double* __restrict__ vpart, int S2,
                                                      const float* __restrict__ frame_scores, float base,
                                                      float temp, float* __restrict__ scales_out,
-                                                     const int* __restrict__ status = nullptr) {
+                                                     int* status = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float smf[4];
   __shared__ double smd[4];
@@ -2709,11 +2712,22 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       K_out[0] = Ktot;
       // status word: 1 = capacity exceeded, 2 = a bounded wait inside a launch of this pass expired (kTkStatus),
       // 4 = a loop bound of the selection engine expired since the last pass that reported (vc2_select2.h)
-      K_out[1] = (Ktot > cap ? 1 : 0) | ((status && *status) ? 2 : 0) | (atomicExch(&g_sel2_dirty, 0) ? 4 : 0);
+      // (bit 4 covers the selection replays of the EARLIER kernels of the pass -- channel selection, ORDER riders; a hit
+      //  inside this launch's own replays is ORed in by the workgroup that sees it, below)
+      const int stw = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      const long long wv = (Ktot > cap ? 1 : 0) | ((stw & kStatusSpinExpired) ? 2 : 0) | ((stw & kSel2StatusGuard) ? 4 : 0);
+      // (one-launch pass: its first kernel zeroed the word and every workgroup ORs -- order-free; stage calls store)
+      if (status) atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), (unsigned long long)wv); else K_out[1] = wv;
     }
   }
-  if constexpr (DT == VC2_F32) select_frame_body<DT, uint64_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
-  else select_frame_body<DT, uint32_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out);
+  __shared__ int st_local;
+  if (tid == 0) st_local = 0;
+  if constexpr (DT == VC2_F32) select_frame_body<DT, uint64_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out, &st_local);
+  else select_frame_body<DT, uint32_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out, &st_local);
+  __syncthreads();
+  if (tid == 0 && st_local) {                                    // (cannot happen; reported, never swallowed)
+    if (status) { atomicOr(status, kSel2StatusGuard); atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), 4ull); }
+  }
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(809 + (fl ? 50 : 0));
 }
 
@@ -3089,7 +3103,8 @@ int launch_stats_sweep(const Plan& p, const void* x, void* ws, const PoolSrc& po
 }
 
 int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, void* var_T, float* var_f32,
-                      hipStream_t st, bool zero_queue_counters = false, bool have_partials = false) {
+                      hipStream_t st, bool zero_queue_counters = false, bool have_partials = false,
+                      int64_t* kstatus = nullptr) {
   double* part = wsp<double>(ws, p.o_part_stats);
   if (!have_partials) { int rcs = launch_stats_sweep(p, x, ws, PoolSrc{}, st); if (rcs) return rcs; }
   { ProfScope ps_(KID_STATS_REDUCE, st);
@@ -3104,7 +3119,7 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, vo
                                              zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src,
                                              make_fold_tab(p.NB, n_each, n_last),
                                              zero_queue_counters ? wsp<unsigned long long>(ws, p.o_nfixlist) : nullptr,
-                                             int(p.R + cdiv(p.F, 2))));
+                                             int(p.R + cdiv(p.F, 2)), reinterpret_cast<unsigned long long*>(kstatus)));
   } }
   return check_launch("chan_stats");
 }
@@ -3129,14 +3144,14 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what,
 }
 
 int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* perm,
-                       hipStream_t st, uint32_t* wperm = nullptr, uint32_t* wcpos = nullptr) {
+                       hipStream_t st, uint32_t* wperm = nullptr, uint32_t* wcpos = nullptr, int* status = nullptr) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = chan_select_lds(int(D));
   { int rca = allow_big_lds(&k_chan_select, smem, "k_chan_select"); if (rca) return rca; }
   { ProfScope ps_(KID_CHAN_SELECT, st);
   hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, perm, wperm,
-                     wcpos); }
+                     wcpos, status); }
   return check_launch("chan_select");
 }
 // torch.topk's ORDER of the kept channels as its own kernel (the scoring entry points attach it to sweep 2 instead)
@@ -3389,7 +3404,7 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 // Budgets: vpart (sweep-3 partials, S2 per frame) or frame_scores -> compute_scales in the kernel; else scales_f32[F].
 struct BudgetSrc { const float* scales_f32; const double* vpart; int S2; const float* frame_scores; double base; double temp;
                    float* scales_out; int64_t tpf = 0;         // tpf: the multiplier of vidcom2.py:72 (0: N)
-                   const int* status = nullptr; };             // the pass's kTkStatus word (reported in K_out[1])
+                   int* status = nullptr; };                   // the pass's kTkStatus word (reported in K_out[1])
 int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_sel, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   const BudgetSrc& b, hipStream_t st) {
@@ -3513,7 +3528,7 @@ int vc2_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, i
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = launch_chan_select(var_f32, D, k, mask, cols, perm, st);
   if (rc || !(order || opos || spos)) return rc;
-  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k), 1, nullptr, nullptr}, st);
+  return launch_chan_order(OrderArgs{var_f32, perm, cols, order, opos, spos, int(D), int(k), 1, nullptr, nullptr, nullptr}, st);
 }
 
 int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_t* idx, int64_t C, void* out,
@@ -3555,7 +3570,8 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
   const ChanSet cs = make_chanset(p, cols, spos, C);
   OrderArgs rider{};
   if (perm && cs.strict)      // torch.topk's ORDER of the channels (-> spos), replayed by a rider workgroup of sweep 2
-    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1, nullptr, nullptr};
+    rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(C), 1, nullptr, nullptr,
+                      wsp<int>(ws, p.o_ticket) + kTkStatus};
   rc = launch_phase1(p, x, cs, ws, /*single_rank=*/false, st, rider, /*own_stats=*/true);   // (vc2_chan_stats ran with this workspace)
   if (rc) return rc;
   if (csum_parts) {       // per group of kCentreFL frames, in frame order: the fp64 sums of x^ [ceil(F/16)][C], then the
@@ -3807,7 +3823,7 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
   int* cols = wsp<int>(ws, p.o_cols);
   if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true,
-                              /*have_partials=*/(flags & VC2_FLAG_HAVE_STATS) != 0)))
+                              /*have_partials=*/(flags & VC2_FLAG_HAVE_STATS) != 0, /*kstatus=*/K_out + 1)))
     return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
   const bool strict = cur_mode() && p.ES == 2;
@@ -3816,13 +3832,14 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   // (wperm / wcpos live in the o_tmp_f32 scratch, free until the selection stage: 2 * kc words <= R or D floats)
   uint32_t* wperm = strict && 2 * kc <= std::max<int64_t>(p.R, D) ? wsp<uint32_t>(ws, p.o_tmp_f32) : nullptr;
   uint32_t* wcpos = wperm ? wperm + kc : nullptr;
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos))) return rc;
+  int* const status = wsp<int>(ws, p.o_ticket) + kTkStatus;       // the pass's status word (-> K_out[1])
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos, status))) return rc;
   const ChanSet cs = make_chanset(p, cols, spos, kc);
   // torch.topk's ORDER of the selected channels (needed only by the "torch order" fix-ups, which run after sweep 2)
   // is replayed by a rider workgroup of sweep 2 itself
   OrderArgs rider{};
   if (strict) rider = OrderArgs{var_f32, perm, cols, wsp<int>(ws, p.o_order), wsp<int>(ws, p.o_opos), spos, int(D), int(kc), 1,
-                                wperm, wcpos};
+                                wperm, wcpos, status};
   if ((rc = launch_phase1(p, x, cs, ws, true, st, rider, /*own_stats=*/true))) return rc;
   float* total = wsp<float>(ws, p.o_total);
   float* scales = wsp<float>(ws, p.o_scales_f32);

@@ -56,8 +56,15 @@ __device__ __forceinline__ bool key_fits_u32(float f) {
 // self-check: every loop of the engine is bounded; a bound that actually expires is counted here (read back by
 // vc2_selftest_counters; the test-suite asserts zeros)
 __device__ int g_sel2_guard_hits[8];
-__device__ int g_sel2_dirty;             // set by a hit, read-and-cleared by the pass's last kernel -> K_out[1] bit 2
-__device__ __forceinline__ void guard_hit(int which) { atomicAdd(&g_sel2_guard_hits[which], 1); atomicExch(&g_sel2_dirty, 1); }
+// A hit is also reported by the pass it happened in: bit kSel2StatusGuard of the pass's status word (Sel2::status, the
+// workspace ticket the launching entry point hands down; nullptr for stand-alone stage calls) -> K_out[1] bit 2.  (Until
+// round 4 this was ONE device-global flag, read and cleared by whichever pass's k_select came first: with two passes in
+// flight on two streams a hit in clip A could be reported by clip B.)
+constexpr int kSel2StatusGuard = 2;
+__device__ __forceinline__ void guard_hit(int which, int* status) {
+  atomicAdd(&g_sel2_guard_hits[which], 1);
+  if (status) atomicOr(status, kSel2StatusGuard);
+}
 
 #ifdef VC2_SEL2_DEBUG
 __device__ unsigned long long g_sel2_dbg[128];
@@ -73,12 +80,14 @@ template <typename W> struct Sel2 {
   uint16_t* lb;    // [n + kSel2Pad] right-stop positions by rank (numbered from the left)
   uint32_t* xch;   // [24] cross-wave exchange: [0,16) per-wave totals, [16] cut, [20..21] dummy cells (predicated stores)
   int dumw;        // index of a dummy word in w[] (predicated swaps of no-op elements land there)
+  int* status;     // the pass's status word (guard_hit), or nullptr
 };
 __host__ __device__ inline size_t sel2_bytes(int n, int wbytes) {
   return (size_t(n + kSel2Pad) * size_t(wbytes) + 15) / 16 * 16 + size_t(n + kSel2Pad) * 2 * 2 + kSel2XchBytes + 32;
 }
-template <typename W> __device__ __forceinline__ Sel2<W> sel2_carve(unsigned char* smem, int n) {
+template <typename W> __device__ __forceinline__ Sel2<W> sel2_carve(unsigned char* smem, int n, int* status = nullptr) {
   Sel2<W> S;
+  S.status = status;
   const size_t wb = (size_t(n + kSel2Pad) * sizeof(W) + 15) / 16 * 16;
   S.w = reinterpret_cast<W*>(smem);
   unsigned char* p = smem + wb;
@@ -417,7 +426,7 @@ __device__ __forceinline__ void introselect_tail64(const Sel2<W>& S, int lo_, in
     const int bl = sB ? int(__builtin_ctzll(sB)) : h;
     const int cut = am < bl ? am : bl;
     if (cut <= nr) l = cut; else h = cut;
-    if (guard == 255 && lane == 0) guard_hit(1);
+    if (guard == 255 && lane == 0) guard_hit(1, S.status);
   }
   if (!fallback) {                                               // __insertion_sort on the <= 3 elements left
     const int m = h - l;
@@ -480,7 +489,7 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
         // (the cut cell is reset by thread 0 after the NEXT round's first barrier: every reader is done by then)
       }
       if (cut <= nth) lo = cut; else hi = cut;
-      if (guard == 255 && tid == 0) guard_hit(0);
+      if (guard == 255 && tid == 0) guard_hit(0, S.status);
     }
   }
   if (!done && tid < 64) {
@@ -504,7 +513,7 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
       if (tid == 0) VC2_SEL_STAMP(230);                           // a one-wave LDS round begins
       const int cut = sel2_partition<W, 1, 0, SOLO>(S, lo, hi, S.la, S.lb, tid);
       if (cut <= nth) lo = cut; else hi = cut;
-      if (guard == 255 && tid == 0) guard_hit(1);
+      if (guard == 255 && tid == 0) guard_hit(1, S.status);
     }
     if (!done && tid == 0) s2_insertion_sort(S.w, lo, hi);
   }
@@ -576,7 +585,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
   uint32_t s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
   auto seglen = [](uint32_t sg) { return int((sg >> 13) & 0x1FFFu) - int(sg & 0x1FFFu); };
   auto push_mine = [&](uint32_t sg) {
-    if (nmine < kSortOwnCap) { if (lane == 0) mine[nmine] = sg; ++nmine; } else if (lane == 0) guard_hit(4);
+    if (nmine < kSortOwnCap) { if (lane == 0) mine[nmine] = sg; ++nmine; } else if (lane == 0) guard_hit(4, S.status);
   };
   auto deal = [&](uint32_t sg) {                                  // round-robin over the waves (uniform decision)
     if ((ndealt % NW) == wave) push_mine(sg);
@@ -636,7 +645,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
 #endif
       push_uniform(first, cut, depth - 1);
       push_uniform(cut, last, depth - 1);
-      if (guard == 4 * 8192 - 1 && tid == 0) guard_hit(2);
+      if (guard == 4 * 8192 - 1 && tid == 0) guard_hit(2, S.status);
     }
     if (s0 != 0u) deal(s0);
     if (s1 != 0u) deal(s1);
@@ -659,7 +668,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
     cur = 0u;
     if (depth == 0 || last - first > sel2_capacity(1, SOLO)) {  // __partial_sort(first, last, last): heapsort
       if (lane == 0) { s2_heap_select(S.w, first, last, last); s2_sort_heap(S.w, first, last); }
-      if (depth != 0 && lane == 0) guard_hit(5);               // (a long segment that phase A could not take)
+      if (depth != 0 && lane == 0) guard_hit(5, S.status);               // (a long segment that phase A could not take)
       wave_lds_order();
       continue;
     }
@@ -677,7 +686,7 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
     } else if (right) {
       cur = seg_pack(cut, last, depth - 1);
     }
-    if (guard == 4 * 8192 - 1 && lane == 0) guard_hit(3);
+    if (guard == 4 * 8192 - 1 && lane == 0) guard_hit(3, S.status);
   }
   __syncthreads();
 #ifdef VC2_SEL2_DEBUG

@@ -15,6 +15,7 @@ import collections
 import ctypes
 import os
 import threading
+import time
 import warnings
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
@@ -130,19 +131,32 @@ class CompressPlan:
         # tail_rows: extra rows (LLaVA's newline embedding) the gather launch appends behind the kept ones
         self.tail_rows = int(tail_rows) if gather else 0
         self._gather, self._want_scores = bool(gather), bool(want_scores)
+        self._spare = None
         self.new_outputs()
+
+    def _alloc_outputs(self):
+        dt, dev = self.dtype, self.device
+        return (torch.empty(self.cap, dtype=torch.int64, device=dev),
+                torch.empty(self.F, dtype=torch.int64, device=dev),
+                torch.empty((self.cap + self.tail_rows, self.D), dtype=dt, device=dev) if self._gather else None,
+                torch.empty((self.F, self.N), dtype=dt, device=dev) if self._want_scores else None,
+                torch.empty((self.F, self.N), dtype=dt, device=dev) if self._want_scores else None,
+                torch.empty(2, dtype=torch.int64, device=dev))    # (K, status): both words written by every pass
 
     def new_outputs(self) -> None:
         """Fresh output tensors (kept rows, indices, budgets, scores) for the next pass.  A plan that is re-used for
         independent calls (the one-shot API's plan cache) calls this before every enqueue, so that a result handed out
-        earlier is never overwritten -- the reference returns fresh tensors as well; workspace and status words stay."""
-        dt, dev = self.dtype, self.device
-        self.idx = torch.empty(self.cap, dtype=torch.int64, device=dev)
-        self.ks = torch.empty(self.F, dtype=torch.int64, device=dev)
-        self.rows = torch.empty((self.cap + self.tail_rows, self.D), dtype=dt, device=dev) if self._gather else None
-        self.v = torch.empty((self.F, self.N), dtype=dt, device=dev) if self._want_scores else None
-        self.f = torch.empty((self.F, self.N), dtype=dt, device=dev) if self._want_scores else None
-        self.kout = torch.empty(2, dtype=torch.int64, device=dev)    # (K, status): both words written by every pass
+        earlier is never overwritten -- the reference returns fresh tensors as well; workspace and status words stay.
+        (`prepare_spare` may have made the set already, while the previous pass was running.)"""
+        spare, self._spare = self._spare, None
+        self.idx, self.ks, self.rows, self.v, self.f, self.kout = spare if spare is not None else self._alloc_outputs()
+
+    def prepare_spare(self) -> None:
+        """Allocate the NEXT call's output tensors now -- called by the one-shot API between enqueue and finish, i.e.
+        while the GPU is busy with this pass -- so that the next call launches its first kernel ~25 us earlier (five
+        allocations).  Still fresh tensors per call: nothing a caller holds is ever overwritten."""
+        if self._spare is None:
+            self._spare = self._alloc_outputs()
 
     def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None,
                 tail: Optional[torch.Tensor] = None, have_stats: bool = False) -> None:
@@ -169,6 +183,8 @@ class CompressPlan:
         check(rc, "vc2_compress")
 
     def finish(self) -> CompressionResult:
+        # (spinning on an event behind a copy to pinned memory instead of this blocking copy: measured, no gain -- torch's
+        #  blocking copy already spins)
         K, status = self.kout.tolist()                   # the single host sync of the path
         return self._result(self.take(), K, status)
 
@@ -201,6 +217,9 @@ class CompressPlan:
 # another stream or thread gets its own plan.  Outputs are NOT cached (CompressPlan.new_outputs).
 _PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _PLAN_CACHE_MAX = int(os.environ.get("VC2_PLAN_CACHE", "8"))       # 0 disables the cache
+_PLAN_CACHE_BYTES = int(os.environ.get("VC2_PLAN_CACHE_MB", "1024")) << 20   # workspaces kept alive by the cache
+_PLAN_LOCK = threading.Lock()
+_PREALLOC = os.environ.get("VC2_PREALLOC", "1") != "0"             # next call's outputs allocated while this pass runs
 
 
 def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores, gather, tail_rows) -> "CompressPlan":
@@ -209,21 +228,29 @@ def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores
         device = torch.device(device.type, torch.cuda.current_device())
     key = (F, N, D, dtype, device, float(base_scale), mapper, int(grid_h), bool(want_scores), bool(gather),
            int(tail_rows), torch.cuda.current_stream(device).cuda_stream, threading.get_ident(), _ffi.get_mode())
-    plan = _PLAN_CACHE.get(key) if _PLAN_CACHE_MAX > 0 else None
+    # (the key holds the thread id, so a plan is only ever USED by one thread; the dictionary itself is shared: another
+    #  thread's eviction between get and move_to_end raised KeyError before the lock)
+    with _PLAN_LOCK:
+        plan = _PLAN_CACHE.get(key) if _PLAN_CACHE_MAX > 0 else None
+        if plan is not None:
+            _PLAN_CACHE.move_to_end(key)
     if plan is None:
         plan = CompressPlan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores, gather, tail_rows)
         if _PLAN_CACHE_MAX > 0:
-            _PLAN_CACHE[key] = plan
-            while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
-                _PLAN_CACHE.popitem(last=False)
+            with _PLAN_LOCK:
+                _PLAN_CACHE[key] = plan
+                # bounded by entries AND by bytes (a long clip's workspace is hundreds of MB): oldest first
+                while len(_PLAN_CACHE) > _PLAN_CACHE_MAX or \
+                        (len(_PLAN_CACHE) > 1 and sum(p.ws.numel() for p in _PLAN_CACHE.values()) > _PLAN_CACHE_BYTES):
+                    _PLAN_CACHE.popitem(last=False)
     else:
-        _PLAN_CACHE.move_to_end(key)
         plan.new_outputs()
     return plan
 
 
 def clear_plan_cache() -> None:
-    _PLAN_CACHE.clear()
+    with _PLAN_LOCK:
+        _PLAN_CACHE.clear()
 
 
 def _raise_status(status: int, cap: int, K: int) -> None:
@@ -284,6 +311,8 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
     else:
         plan = _cached_plan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather, ntail)
     plan.enqueue(x, src, tail, have_stats=stats_ws is not None)
+    if stats_ws is None and _PREALLOC:
+        plan.prepare_spare()              # (the GPU is busy for the next ~190 us: the next call's outputs cost nothing here)
     return plan.finish()
 
 
