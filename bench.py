@@ -399,6 +399,7 @@ def main():
                           "frac_of_8TBs_per_gpu": round(alg_bytes_pass(F, N, D, es, base) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "kernels_us": kern,
     }
+    extra_wanted = not dist_on and not args.no_extra
     out["mode"] = _ffi.get_mode() + (" (bit-exact to the CPU reference: boundary-fragile tokens replay torch's fp32 "
                                      "accumulation order)" if _ffi.get_mode() == "torch" else "")
     if not dist_on:
@@ -438,6 +439,7 @@ def main():
         pr["producer_warm_frac_of_8TBs"] = round(ab / e_pw / 1e9 / HBM_PEAK_GBS, 4)
         pr["note"] = ("value / ms_per_step = the warm state; cold = three clips in turn; producer_warm = X written by a "
                       "device copy immediately before each pass (hipEvents around the pass)")
+        x_long = torch.cat([xs3[0], xs3[1], xs3[2], xs3[0]]) if (extra_wanted and args.workload == "target") else None
         del xs3, xw
     if not dist_on:
         out["median_ms_per_step"] = round(median_step_ms(step, max(args.steps, 20)), 4)
@@ -525,10 +527,11 @@ def main():
                        "pass_alg_GBs": round(alg_bytes_pass(F3, N3, D3, 2, b3) / (e3 / args.steps) / 1e9, 1)}
         del x3, p3
     # ---- side: a working set beyond the 256 MiB Infinity Cache: 512 frames x 196 x 3584 bf16 = 360 MB of X (the
-    #      long-video config on ONE GPU; N(0,1) data made on the device -- a timing leg, parity is tested elsewhere)
+    #      long-video config on ONE GPU; the `drift` generator's data -- until round 4 this leg used N(0,1) noise, whose
+    #      zero-mean channels put 8 % of the frame means on the replay list; a timing leg, parity is tested elsewhere)
     if extra and args.workload == "target":
         Fb = 512
-        xb = torch.randn(Fb * N, D, device=dev, dtype=torch.float32).to(dtype)
+        xb = x_long               # four 128-frame `drift` clips in a row (three different ones: a video of four scenes)
         pb = vc.vidcom2.CompressPlan(Fb, N, D, dtype, dev, base)
         pb.enqueue(xb)
         Kb = pb.finish().K
@@ -543,7 +546,7 @@ def main():
                           "pass_alg_GBs": round(alg_bytes_pass(Fb, N, D, es, base) / (eb / nb) / 1e9, 1),
                           "pass_frac_of_8TBs": round(alg_bytes_pass(Fb, N, D, es, base) / (eb / nb) / 1e9 / HBM_PEAK_GBS, 4),
                           "kernels_us": kb}
-        del xb, pb
+        del xb, pb, x_long
     # ---- side (f3): LLaVA's get_2dPool fused with sweep 1.  Projector output 128 x (27x27) x 3584 bf16, bilinear pool
     #      to 14x14 = 196 tokens: torch's permute/interpolate/permute on the device + the full pass, against
     #      fused.pool_stats + the pass without its first sweep -------------------------------------------------
