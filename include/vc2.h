@@ -264,6 +264,25 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
                              void* v_T, void* f_T, float* total_f32, float* s_f32, const float* blocks_all, int world,
                              int cap, void* stream);
 
+/* More flagged columns than one exchange carries (only the proven-margin and debug modes flag that many): further
+ * ROUNDS of exchange 2b.  After vc2_video_centre_blocks (round 0: flags, count, records of the first `cap` columns) the
+ * caller reads the count (vc2_video_centre_flagged; every rank reads the same number), and for every round r:
+ *   vc2_video_centre_blocks_round(col_offset = r * cap)   records of flagged columns [r * cap, (r + 1) * cap)   (r >= 1)
+ *   (all-gather)
+ *   vc2_video_centre_finish_round(col_offset = r * cap)   torch's cascade over the whole video for those columns; the
+ *                                                         video centre in the workspace is corrected in place  (r >= 0)
+ * and finally vc2_scores_phase2_blocks(blocks_all = NULL, world = -1): "the centre is final", sweep 3 only.
+ * A level-0 block may meet any number of ranks (ranks with fewer rows than a block included); the ranks must hold
+ * equal row counts. */
+int vc2_video_centre_blocks_round(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+                                  int64_t C, const int32_t* spos, int64_t R_total, int64_t row0, void* ws,
+                                  size_t ws_bytes, float* blocks_out, int cap, int col_offset, void* stream);
+int vc2_video_centre_flagged(int64_t F, int64_t N, int64_t D, int dtype, int64_t R_total, const void* ws, size_t ws_bytes,
+                             int32_t* count_host, void* stream);   /* synchronises `stream`; host pointer */
+int vc2_video_centre_finish_round(int64_t F, int64_t N, int64_t D, int dtype, int64_t C, const int32_t* spos,
+                                  int64_t R_total, void* ws, size_t ws_bytes, const float* blocks_all, int world,
+                                  int cap, int col_offset, void* stream);
+
 /* Step 3 of the sharded path: s_all_f32[F_total] = the all-gathered per-frame uniqueness scores
  * (fp32-widened T values); budgets are computed over all F_total frames, selection + gather only for
  * this rank's frames [f0, f0+F_local).  idx_out holds LOCAL linear indices (f_local*N + n).  K_out is int64[3] here:

@@ -84,7 +84,18 @@ def _emulate_ranks_on_one_gpu(x, F, N, D, dtype, base, P, dev, vc_cap=64):
         s.select_channels(stats_all, F * N)
     csum_all = torch.stack([s.phase1(xs).clone() for s, xs in zip(st, shards)])
     blocks = [s.vc_blocks(xs, csum_all, F * N, p * Fl) for p, (s, xs) in enumerate(zip(st, shards))]   # exchange 2b (may not apply)
-    if all(b is not None for b in blocks):
+    if all(b is not None for b in blocks) and st[0].needs_rounds():
+        # proven / debug modes: rounds of exchange 2b, all ranks in lock step (ShardedCompressor._enqueue)
+        counts = [s.flagged_columns() for s in st]
+        assert len(set(counts)) == 1, counts
+        for j0 in range(0, max(counts[0], 1), st[0].vc_cap):
+            if j0:
+                blocks = [s.vc_blocks_round(xs, F * N, p * Fl, j0) for p, (s, xs) in enumerate(zip(st, shards))]
+            blocks_all = torch.stack([b.clone() for b in blocks])
+            for s in st:
+                s.vc_finish_round(F * N, blocks_all, j0)
+        s_all = torch.cat([s.phase2(xs, csum_all, F * N, vc_final=True).clone() for s, xs in zip(st, shards)])
+    elif all(b is not None for b in blocks):
         blocks_all = torch.stack([b.clone() for b in blocks])
         s_all = torch.cat([s.phase2(xs, csum_all, F * N, blocks_all).clone() for s, xs in zip(st, shards)])
     else:
@@ -135,7 +146,12 @@ def test_world_size_invariance_on_gpu(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [(6, 49, 64, "bf16", (2, 3)), (12, 169, 128, "f16", (2, 3, 4, 6)), (10, 100, 256, "bf16", (2, 5)),
-                                  (9, 37, 64, "f16", (3,))], ids=lambda c: "x".join(map(str, c[:4])))
+                                  (9, 37, 64, "f16", (3,)),
+                                  # ranks with FEWER rows than a 16-row cascade block: a block meets three and more ranks
+                                  (8, 7, 64, "bf16", (2, 4, 8)), (12, 5, 128, "f16", (3, 6, 12)), (6, 3, 64, "bf16", (6,)),
+                                  # more flagged columns than one exchange carries: rounds (cap 8 of 32 / 64 columns)
+                                  (6, 49, 64, "bf16", (2, 3), 8), (10, 100, 128, "f16", (2, 5), 8)],
+                         ids=lambda c: "x".join(map(str, c[:4])) + ("-cap%d" % c[5] if len(c) > 5 else ""))
 def test_video_centre_replay_across_unaligned_ranks(case):
     """Debug mode 2 flags EVERY video-centre column, so all of them go through exchange 2b: ranks whose row count is
     not a multiple of 16 share level-0 blocks with their neighbours (raw head / tail values in the record), and a video
@@ -143,7 +159,8 @@ def test_video_centre_replay_across_unaligned_ranks(case):
     the unsharded pass's (same mode) and the oracle's."""
     import vidcom2_amd as vc
     from vidcom2_amd import _ffi
-    F, N, D, dn, worlds = case
+    F, N, D, dn, worlds = case[:5]
+    cap = case[5] if len(case) > 5 else D // 2
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dn]
     dev = torch.device("cuda:0")
     x = synth.make(F, N, D, dtype, 2, "drift")
@@ -157,10 +174,41 @@ def test_video_centre_replay_across_unaligned_ranks(case):
         assert torch.equal(whole.v_score.cpu().float(), ref["v"].float()) and torch.equal(whole.global_idx.cpu(), ref["global_idx"])
         total = (whole.v_score + whole.f_score).float().flatten()
         for P in worlds:
-            res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, 0.25, P, dev, vc_cap=D // 2)
+            res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, 0.25, P, dev, vc_cap=cap)
             assert all(s.vc_fragile == 0 for s in st), f"P={P}"
             assert torch.equal(torch.cat([s.total for s in st]), total), f"P={P}"
             assert torch.equal(torch.cat([r.global_idx for r in res]).cpu(), ref["global_idx"]), f"P={P}"
+    finally:
+        _ffi.set_mode("torch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(32, 196, 3584, "bf16", "iid"), (16, 169, 1024, "f16", "iid"), (16, 196, 1024, "bf16", "cancel")],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_proven_margin_mode_sharded_goes_in_rounds(case):
+    """Mode 3 (proven centre margins) flags hundreds of video-centre columns on zero-mean data -- far more than one
+    exchange 2b carries (64): the sharded pass then goes in rounds and must still give the unsharded pass's bits, with no
+    column left at its exactly rounded mean (until round 4 those were counted and warned about)."""
+    import warnings
+    import vidcom2_amd as vc
+    from vidcom2_amd import _ffi
+    F, N, D, dn, dist_ = case
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[dn]
+    dev = torch.device("cuda:0")
+    x = synth.make(F, N, D, dtype, 5, dist_)
+    xd = x.to(dev)
+    try:
+        _ffi.set_mode("torch_proven")
+        whole = vc.compress(xd, N, 0.25, want_scores=True)
+        total = (whole.v_score + whole.f_score).float().flatten()
+        for P in (2, 4):
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                res, st = _emulate_ranks_on_one_gpu(xd, F, N, D, dtype, 0.25, P, dev)
+            assert st[0].needs_rounds()
+            assert all(s.vc_fragile == 0 for s in st), f"P={P}"
+            assert torch.equal(torch.cat([s.total for s in st]), total), f"P={P}"
+            assert torch.equal(torch.cat([r.global_idx for r in res]), whole.global_idx), f"P={P}"
     finally:
         _ffi.set_mode("torch")
 

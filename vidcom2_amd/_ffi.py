@@ -53,6 +53,9 @@ _SIGNATURES = {
                                 _vp, _i32, _vp],
     "vc2_scores_phase2_blocks": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _sz, _vp,
                                  _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "vc2_video_centre_blocks_round": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _sz, _vp, _i32, _i32, _vp],
+    "vc2_video_centre_flagged": [_i64, _i64, _i64, _i32, _i64, _vp, _sz, _vp, _vp],
+    "vc2_video_centre_finish_round": [_i64, _i64, _i64, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _i32, _i32, _i32, _vp],
     "vc2_select_sharded": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _i32, _vp, _sz, _vp, _vp, _i64, _vp, _vp,
                            _vp, _vp],
     "vc2_multi_scale_gaussian": [_vp, _i64, _i64, _i64, _i32, _vp, _i64, ctypes.POINTER(ctypes.c_double), _i32, _vp, _vp],

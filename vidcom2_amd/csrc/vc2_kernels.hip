@@ -1851,9 +1851,10 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
 //     [64, 128) the x^ values of my last t rows (the beginning of a block the next rank ends)
 //     [128, ..) the sums of my complete blocks (rows added in order)
 // The records are all-gathered (rank order = row order) and k_vc_finish runs the rest of torch's cascade over the
-// whole video: a straddling block is its tail values, then its head values, added one by one; the video's last
-// R_total % B rows (the cascade's tail) are the last rank's tail values.  Needs R_local >= B (a block meets at most
-// two ranks), equal row counts per rank, and the cascade's plain form (column in a full group of 32).
+// whole video: a straddling block is its rows' raw values added one by one in row order -- from as many ranks as it
+// meets (a rank with fewer rows than a block is all head); the video's last R_total % B rows (the cascade's tail) come
+// the same way.  Needs equal row counts per rank and the cascade's plain form (column in a full group of 32).  More
+// flagged columns than a record buffer holds go in further rounds (slot offset j0).
 constexpr int kVcEdge = 64;
 __host__ __device__ inline int64_t vc_rec_floats(int64_t R_local) { return 2 * kVcEdge + R_local / 16 + 1; }
 __host__ __device__ inline int vc_head_rows(int64_t row0, int B) { return int((B - row0 % B) % B); }
@@ -1878,9 +1879,9 @@ template <int DT>
 __global__ __launch_bounds__(64) void k_vc_blocks(const uint8_t* __restrict__ vflag, int C, const void* __restrict__ x,
                                                   int D, const int* __restrict__ cols, const int* __restrict__ spos,
                                                   const float* __restrict__ den, int64_t R_local, int64_t row0, int lp,
-                                                  float* __restrict__ blocks_out) {
-  const int lane = threadIdx.x, j = blockIdx.y;
-  const int cc = nth_flagged_column(vflag, C, j, lane);
+                                                  float* __restrict__ blocks_out, int j0) {
+  const int lane = threadIdx.x, j = blockIdx.y;                  // record j of this round = flagged column number j0 + j
+  const int cc = nth_flagged_column(vflag, C, j0 + j, lane);
   if (cc < 0) return;
   const int col = cols ? cols[cc] : cc;
   const int B = 1 << lp;
@@ -1902,10 +1903,11 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ vflag, int C,
                                                    const int* __restrict__ spos, const float* __restrict__ blocks_all,
                                                    int world, int cap, int64_t R_local, int64_t R_total,
-                                                   float* __restrict__ vc, int* __restrict__ fragile_count) {
+                                                   float* __restrict__ vc, int* __restrict__ fragile_count, int j0) {
   __shared__ float l1[kL1Cap + 4];
-  const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x;
-  const int cc = nth_flagged_column(vflag, C, j, lane);
+  __shared__ float tailv[kVcEdge];
+  const int tid = threadIdx.x, lane = tid & 63, j = blockIdx.x;  // record j of this round = flagged column number j0 + j
+  const int cc = nth_flagged_column(vflag, C, j0 + j, lane);
   if (cc < 0) return;
   const int group = C >= 8 ? 32 : 4;
   const int sp = spos ? spos[cc] : cc;
@@ -1913,18 +1915,25 @@ __global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ v
   const int lp = cascade_lp(R_total), B = 1 << lp;
   const int64_t rec = vc_rec_floats(R_local);
   auto record = [&](int64_t w) { return blocks_all + (w * cap + j) * rec; };
-  // the level-0 sum of the video's block b: a rank's own complete block, or the tail of one rank continued by the head
-  // of the next (row order)
+  // what rank w holds: h head rows (raw, the end of a block begun before it), nb complete blocks, t tail rows (raw)
+  auto head_of = [&](int64_t w) { return int(min<int64_t>(R_local, vc_head_rows(w * R_local, B))); };
+  // the x^ value of video row r: raw in its rank's head or tail section (only asked for rows of straddling blocks)
+  auto row_value = [&](int64_t r) -> float {
+    const int64_t w = r / R_local, off = r - w * R_local;
+    const int h = head_of(w);
+    if (off < h) return record(w)[off];
+    const int64_t nb = (R_local - h) >> lp;
+    return record(w)[kVcEdge + (off - h - (nb << lp))];
+  };
+  // the level-0 sum of the video's block b: a rank's own complete block, or -- a block that meets two OR MORE ranks
+  // (ranks with fewer rows than a block included) -- its rows one by one in row order
   auto block_value = [&](int64_t b) -> float {
     const int64_t g0 = b << lp, w = g0 / R_local, off = g0 - w * R_local;
-    const int hw = vc_head_rows(w * R_local, B);
-    if (off + B <= R_local) return record(w)[2 * kVcEdge + ((off - hw) >> lp)];
-    const int tw = int(R_local - off);                           // rows of the block that rank w holds (its tail)
-    const float* ta = record(w) + kVcEdge;
-    const float* he = record(w + 1);
-    float a = ta[0];
-    for (int u = 1; u < tw; ++u) a += ta[u];
-    for (int u = 0; u < B - tw; ++u) a += he[u];
+    const int h = head_of(w);
+    const int64_t nb = (R_local - h) >> lp;
+    if (off >= h && ((off - h) & (B - 1)) == 0 && ((off - h) >> lp) < nb) return record(w)[2 * kVcEdge + ((off - h) >> lp)];
+    float a = row_value(g0);
+    for (int u = 1; u < B; ++u) a += row_value(g0 + u);
     return a;
   };
   const int64_t nbv = R_total >> lp;
@@ -1939,11 +1948,11 @@ __global__ __launch_bounds__(256) void k_vc_finish(const uint8_t* __restrict__ v
     }
     l1[g] = a;
   }
+  const int ntail = int(R_total - (nbv << lp));                  // the cascade's tail: the video's last R_total % B rows
+  if (tid < ntail) tailv[tid] = row_value((nbv << lp) + tid);
   __syncthreads();
   if (tid < 64) {
-    // the cascade's tail (R_total % B rows): the last rank's tail values
-    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, R_total, lane, lp,
-                                           record(world - 1) + kVcEdge);
+    const float s = wave_cascade_final<DT>(l1, nbv, nullptr, 0, 0, nullptr, 0, 1, R_total, lane, lp, tailv);
     if (lane == 0) {
       vc[cc] = rnT<DT>(s / float(R_total));
       if (fragile_count) atomicSub(fragile_count, 1);            // one flagged column less that kept its exact mean
@@ -3644,7 +3653,8 @@ int vc2_scores_phase1(const void* x, int64_t F, int64_t N, int64_t D, int dtype,
 // can the frame-sharded pass replay its video-centre means (see k_vc_blocks)?
 static bool vc_blocks_ok(const Plan& p, int64_t R_total, int strict) {
   const int64_t B = int64_t(1) << cascade_lp(R_total);      // (a level-0 block meets at most two ranks)
-  return strict != 0 && p.dt != VC2_F32 && p.R >= B && R_total % p.R == 0 && cascade_modelled(R_total);
+  (void)B;                                                    // (a block may meet any number of ranks: k_vc_finish)
+  return strict != 0 && p.dt != VC2_F32 && R_total % p.R == 0 && cascade_modelled(R_total);
 }
 
 int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
@@ -3674,8 +3684,63 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
   const int64_t nb = p.R >> lpv;                               // (at most; one more grid column for the raw edges)
   VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64) + 1), unsigned(cap)), dim3(64), 0,
                                             st, vflag, int(C), x, int(D), cols, spos, wsp<float>(ws, p.o_den), p.R, row0,
-                                            lpv, blocks_out));
+                                            lpv, blocks_out, 0));
   return check_launch("video_centre_blocks");
+}
+
+// Rounds of exchange 2b beyond the first `cap` flagged columns (vc2.h): the records of flagged columns
+// [col_offset, col_offset + cap), the flags being those vc2_video_centre_blocks left in the workspace
+int vc2_video_centre_blocks_round(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
+                                  int64_t C, const int32_t* spos, int64_t R_total, int64_t row0, void* ws, size_t ws_bytes,
+                                  float* blocks_out, int cap, int col_offset, void* stream) {
+  if (!x || !blocks_out || cap <= 0 || col_offset < 0 || row0 < 0 || row0 + F * N > R_total)
+    return fail(VC2_ERR_ARG, "bad video_centre_blocks_round arguments");
+  { int rcc = check_cols(cols, C, D); if (rcc) return rcc; }
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p, R_total / N);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if (!vc_blocks_ok(p, R_total, make_chanset(p, cols, spos, C).strict)) return VC2_OK;
+  const int lpv = cascade_lp(R_total);
+  const int64_t nb = p.R >> lpv;
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_blocks<DT>), dim3(unsigned(cdiv(nb, 64) + 1), unsigned(cap)), dim3(64), 0,
+                                            static_cast<hipStream_t>(stream), wsp<uint8_t>(ws, p.o_mask), int(C), x, int(D),
+                                            cols, spos, wsp<float>(ws, p.o_den), p.R, row0, lpv, blocks_out, col_offset));
+  return check_launch("video_centre_blocks_round");
+}
+
+// how many columns vc2_video_centre_blocks flagged (SYNCHRONISES the stream): the rounds the caller has to go
+int vc2_video_centre_flagged(int64_t F, int64_t N, int64_t D, int dtype, int64_t R_total, const void* ws, size_t ws_bytes,
+                             int32_t* count_host, void* stream) {
+  if (!count_host) return fail(VC2_ERR_ARG, "null pointer");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p, R_total / N);
+  if (rc) return rc;
+  if ((rc = need_ws(p, const_cast<void*>(ws), ws_bytes))) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(count_host, static_cast<const char*>(ws) + p.o_ticket + 5 * sizeof(int), sizeof(int32_t),
+                     hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return fail(VC2_ERR_LAUNCH, "flagged-column read-back failed");
+  return VC2_OK;
+}
+
+// ... and the finish of one round: torch's cascade over the whole video for flagged columns [col_offset, col_offset + cap)
+// from the all-gathered records; the video centre in the workspace is corrected in place (vc2_scores_phase2_blocks with
+// world = -1 then scores with it as it stands)
+int vc2_video_centre_finish_round(int64_t F, int64_t N, int64_t D, int dtype, int64_t C, const int32_t* spos,
+                                  int64_t R_total, void* ws, size_t ws_bytes, const float* blocks_all, int world, int cap,
+                                  int col_offset, void* stream) {
+  if (!blocks_all || world <= 0 || cap <= 0 || col_offset < 0) return fail(VC2_ERR_ARG, "bad video_centre_finish_round arguments");
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p, R_total / N);
+  if (rc) return rc;
+  if ((rc = need_ws(p, ws, ws_bytes))) return rc;
+  if (R_total != int64_t(world) * p.R) return fail(VC2_ERR_ARG, "finish_round: R_total != world * F * N");
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_finish<DT>), dim3(unsigned(cap)), dim3(256), 0,
+                                            static_cast<hipStream_t>(stream), wsp<uint8_t>(ws, p.o_mask), int(C), spos,
+                                            blocks_all, world, cap, p.R, R_total, wsp<float>(ws, p.o_vc),
+                                            wsp<int>(ws, p.o_ticket) + 5, col_offset));
+  return check_launch("video_centre_finish_round");
 }
 
 int vc2_scores_phase2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols, int64_t C,
@@ -3702,7 +3767,8 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
   const bool have_blocks = blocks_all && world > 0 && cap > 0 && vc_blocks_ok(p, R_total, cs0.strict) &&
                            R_total == int64_t(world) * p.R;
-  if (!have_blocks)      // (with blocks: vc2_video_centre_blocks already computed the means, the flags and the count)
+  const bool vc_final = world < 0;   // the caller ran vc2_video_centre_blocks + the finish rounds: the centre is final
+  if (!have_blocks && !vc_final)     // (with blocks: vc2_video_centre_blocks already computed the means, the flags and the count)
     VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
                                               csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                               int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
@@ -3715,7 +3781,7 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
   if (have_blocks)
     VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_vc_finish<DT>), dim3(unsigned(cap)), dim3(256), 0, st,
                                               wsp<uint8_t>(ws, p.o_mask), int(C), spos, blocks_all, world, cap,
-                                              p.R, R_total, wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket) + 5));
+                                              p.R, R_total, wsp<float>(ws, p.o_vc), wsp<int>(ws, p.o_ticket) + 5, 0));
   float* total = total_f32 ? total_f32 : wsp<float>(ws, p.o_total);
   float* s = s_f32 ? s_f32 : wsp<float>(ws, p.o_s);
   return launch_phase2(p, x, make_chanset(p, cols, spos, C), ws, v_T, f_T, total, s, st);

@@ -21,6 +21,7 @@ CPU with gloo (tests inject an oracle-backed stage object); the default stages a
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
@@ -113,15 +114,12 @@ class HipStages:
 
     def vc_blocks(self, x, csum_all, R_total, f0=0):
         """Exchange 2b: this rank's level-0 block sums (and the raw values of the blocks it shares with its neighbours)
-        of the boundary-near video-centre columns, or None when the replay does not apply (fp32, exact mode, fewer rows
-        per rank than the cascade's block -- 16 rows up to 2^19 tokens per video, 32 up to 2^23, 64 beyond --, unequal
-        ranks, more tokens than the replay models) -- a decision every rank takes identically.  f0 = the video index
-        of this rank's first frame."""
-        from .vidcom2 import cascade_level_power, cascade_modelled
-        B = 1 << cascade_level_power(R_total)
+        of the boundary-near video-centre columns, or None when the replay does not apply (fp32, exact mode, more tokens
+        than the replay models) -- a decision every rank takes identically.  f0 = the video index of this rank's first
+        frame.  A block may meet any number of ranks (since round 4: ranks with fewer rows than a block included)."""
+        from .vidcom2 import cascade_modelled
         Rl = self.F * self.N
-        if (not self.vc_replay or _ffi.get_mode() != "torch" or not cascade_modelled(R_total) or Rl < B
-                or R_total % Rl != 0):
+        if not self.vc_replay or _ffi.get_mode() != "torch" or not cascade_modelled(R_total) or R_total % Rl != 0:
             return None
         p = self._p
         parts = csum_all.reshape(-1, csum_all.shape[-1])
@@ -132,10 +130,39 @@ class HipStages:
               "vc2_video_centre_blocks")
         return self.blocks
 
-    def phase2(self, x, csum_all, R_total, blocks_all=None):
+    def flagged_columns(self) -> int:
+        """How many video-centre columns the flag kernel of vc_blocks marked (SYNCHRONISES: one device-to-host read; every
+        rank reads the same number -- the flags come from the all-gathered sums).  Only the modes that can flag more
+        columns than one exchange carries ask (proven margins, debug)."""
+        out = ctypes.c_int32(0)
+        check(self._L.vc2_video_centre_flagged(self.F, self.N, self.D, self.code, self.F_total * self.N, self._p["ws"],
+                                               self._ws_n, ctypes.byref(out), self._st()), "vc2_video_centre_flagged")
+        return int(out.value)
+
+    def needs_rounds(self) -> bool:
+        """Modes whose video-centre margins can flag more than vc_cap columns: 3 (proven) and 2 (debug: all of them)."""
+        return self.vc_replay and int(self._L.vc2_get_mode()) in (2, 3)
+
+    def vc_blocks_round(self, x, R_total, f0, col_offset):
+        p = self._p
+        check(self._L.vc2_video_centre_blocks_round(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
+                                                    R_total, int(f0) * self.N, p["ws"], self._ws_n, p["blocks"], self.vc_cap,
+                                                    int(col_offset), self._st()), "vc2_video_centre_blocks_round")
+        return self.blocks
+
+    def vc_finish_round(self, R_total, blocks_all, col_offset):
+        p = self._p
+        check(self._L.vc2_video_centre_finish_round(self.F, self.N, self.D, self.code, self.C, p["spos"], R_total, p["ws"],
+                                                    self._ws_n, ptr(blocks_all), int(blocks_all.shape[0]), self.vc_cap,
+                                                    int(col_offset), self._st()), "vc2_video_centre_finish_round")
+
+    def phase2(self, x, csum_all, R_total, blocks_all=None, vc_final=False):
+        """vc_final: the video centre in the workspace is final (vc_blocks + vc_finish_round rounds): sweep 3 only."""
         p = self._p
         parts = csum_all.reshape(-1, csum_all.shape[-1])       # [world * groups, C], rank order = frame order
-        world = 0 if blocks_all is None else int(blocks_all.shape[0])
+        world = -1 if vc_final else (0 if blocks_all is None else int(blocks_all.shape[0]))
+        if vc_final:
+            blocks_all = None
         check(self._L.vc2_scores_phase2_blocks(ptr(x), self.F, self.N, self.D, self.code, p["cols"], self.C, p["spos"],
                                                ptr(parts), parts.shape[0], parts.shape[1], self.csum.shape[0], R_total,
                                                p["ws"], self._ws_n, None, None, p["total"], p["s"],
@@ -159,8 +186,8 @@ class HipStages:
         if vc_fragile and _ffi.get_mode() == "torch":
             import warnings
             warnings.warn(f"vidcom2_amd (frame-sharded pass): {vc_fragile} video-centre value(s) lie within the replay margin "
-                          "of a rounding boundary and could not be replayed across ranks (fewer rows per rank than a cascade block, unequal ranks, "
-                          f"more than {self.vc_cap} such columns, or a channel count that is not a multiple of 32); they keep "
+                          "of a rounding boundary and could not be replayed across ranks "
+                          f"(more than {self.vc_cap} such columns in a mode that does not go in rounds, or a channel count that is not a multiple of 32); they keep "
                           "the exactly rounded mean, the reference's fp32 summation order could round the other way.",
                           RuntimeWarning, stacklevel=2)
         li = self.idx[:K]
@@ -191,6 +218,13 @@ class ShardedCompressor:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.F, self.N, self.D = int(F_local), int(N), int(D)
+        if self.world > 1:
+            # every rank must bring the same number of frames (the canonical partials, the exchanges' message sizes and
+            # the replay blocks are cut on that assumption): say so instead of hanging in a mismatched collective
+            fl = [None] * self.world
+            dist.all_gather_object(fl, (self.F, self.N, self.D), group=group)
+            if any(t != fl[0] for t in fl):
+                raise ValueError(f"ShardedCompressor: every rank must hold the same (frames, tokens per frame, width); got {fl}")
         self.F_total = self.F * self.world
         self.f0 = self.rank * self.F
         self.stages = stages if stages is not None else HipStages(self.F, self.N, self.D, dtype, device, base_scale,
@@ -255,7 +289,16 @@ class ShardedCompressor:
         st.select_channels(stats_all, R_total)
         csum_all = self._gather("csum", st.phase1(x_local))                     # exchange 2: [W, D] fp64
         blocks = st.vc_blocks(x_local, csum_all, R_total, self.f0) if hasattr(st, "vc_blocks") else None
-        if blocks is not None:                                                   # exchange 2b: [W, vc_cap, 129 + R_local/16] fp32
+        if blocks is not None and getattr(st, "needs_rounds", lambda: False)():
+            # proven-margin / debug modes: as many rounds of exchange 2b as the flagged columns need (one host sync for
+            # their count -- identical on every rank, so every rank issues the same collectives)
+            n = st.flagged_columns()
+            for j0 in range(0, max(n, 1), st.vc_cap):
+                if j0:
+                    blocks = st.vc_blocks_round(x_local, R_total, self.f0, j0)
+                st.vc_finish_round(R_total, self._gather("blocks", blocks), j0)
+            s_loc = st.phase2(x_local, csum_all, R_total, vc_final=True)
+        elif blocks is not None:                                                 # exchange 2b: [W, vc_cap, 129 + R_local/16] fp32
             s_loc = st.phase2(x_local, csum_all, R_total, self._gather("blocks", blocks))
         else:
             s_loc = st.phase2(x_local, csum_all, R_total)
