@@ -60,7 +60,7 @@ const char* vc2_version(void);
  *   3            "proven": a PROVEN bound decides which centre means are replayed (forward error bound of torch's
  *                cascade relative to sum |x^|, bounded from sweep 1's statistics): flags 50x more means, costs a third
  *                more time; the test-suite runs every fixture in it as well and asserts the same results.
- *   1            "fast" (the default of rounds 1-3, now opt-in): the 16-ulp margin alone for all centre means.  ~3 %
+ *   1            "fast" (the default of rounds 1-3, now opt-in): the 16-ulp margin alone for all centre means.  ~1.6 %
  *                faster than mode 4; NOT bit-exact under cancellation (0.2 % of random `cancel` inputs differ in last-bit
  *                f scores, rarely a kept index) -- no claim of reference parity is made for it.
  *   (2: debug -- every value is replayed.)
@@ -125,7 +125,10 @@ int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int
  * offs int64[F+1] (exclusive prefix of min(ks, N)), idx_out int64[cap] and K_out[0] = number of indices
  * written.  K_out[1] = status bits, all zero on a sound pass: 1 = the count would have exceeded `cap` (nothing past
  * cap is written), 2 = a bounded wait between workgroups of one launch of this pass expired, 4 = a loop bound of the
- * selection replay expired (vc2_selftest_counters has the details); the Python mirror raises on any of them. */
+ * selection replay expired IN THIS PASS (any of its kernels: channel selection, ORDER riders, per-frame selection; the
+ * one-launch pass keeps the bit in its own workspace word, so two passes in flight on two streams cannot report each
+ * other's hits; vc2_selftest_counters has the process-wide details); the Python mirror raises on any of them.  Stage
+ * calls (this function) report their own launch only. */
 int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int64_t tpf, int dtype,
                int map_mode, int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs,
                int64_t* idx_out, int64_t cap, int64_t* K_out, void* stream);

@@ -1,6 +1,8 @@
 """GPU-box soak of the frame-sharded pass: random shapes and world sizes (emulated ranks on one GPU through the stage
-entry points), token-by-token scores against the unsharded pass, in the default mode and in debug mode 2 (every
-video-centre column through exchange 2b)."""
+entry points), token-by-token scores against the unsharded pass, in the default mode, in debug mode 2 (every
+video-centre column through exchange 2b) and in mode 3 (proven margins: hundreds of flagged columns on zero-mean data),
+with record buffers of 8 / 64 / all columns (rounds of exchange 2b) and frames down to 3 tokens (ranks smaller than a
+cascade block)."""
 import os, sys, time, random, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,33 +18,33 @@ for seed in range(lo, hi):
     rng = random.Random(seed)
     P = rng.choice([2, 3, 4, 5, 6, 8])
     Fl = rng.choice([1, 2, 3, 4, 6, 8, 16])
-    N = rng.choice([16, 37, 49, 100, 144, 169, 196, 324])
+    N = rng.choice([3, 5, 7, 16, 37, 49, 100, 144, 169, 196, 324])
     D = rng.choice([64, 128, 256, 512, 1024, 3584])
     dt = rng.choice([torch.float16, torch.bfloat16])
-    dist = rng.choice(["drift", "iid"])
-    mode2 = rng.random() < 0.5 and D <= 1024
+    dist = rng.choice(["drift", "iid", "cancel"])
+    u = rng.random()
+    mode = "debug2" if (u < 0.4 and D <= 1024) else ("torch_proven" if u < 0.7 else "torch")
+    cap = rng.choice([8, 64, max(64, D // 2)]) if mode != "torch" else max(64, D // 2)
     F = P * Fl
     x = synth.make(F, N, D, dt, seed, dist).to(dev)
     try:
-        if mode2:
+        if mode == "debug2":
             _ffi.lib().vc2_set_mode(2)
         else:
-            _ffi.set_mode("torch")
+            _ffi.set_mode(mode)
         whole = vc.compress(x, N, 0.25, want_scores=True)
         total = (whole.v_score + whole.f_score).float().flatten()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            res, st = _emulate_ranks_on_one_gpu(x, F, N, D, dt, 0.25, P, dev, vc_cap=max(64, D // 2))
+            res, st = _emulate_ranks_on_one_gpu(x, F, N, D, dt, 0.25, P, dev, vc_cap=cap)
         replayed = all(s.vc_fragile == 0 for s in st)
         same_idx = torch.equal(torch.cat([r.global_idx for r in res]), whole.global_idx)
         same_tot = torch.equal(torch.cat([s.total for s in st]), total)
-        ok = same_idx and (same_tot or not replayed)
-        if Fl * N >= 64 and not replayed:
-            ok = False                                   # every case with a block's worth of rows per rank must replay
+        ok = same_idx and same_tot and (replayed or D % 64 != 0)      # (C % 32 tail columns are not replayed across ranks)
     finally:
         _ffi.set_mode("torch")
     n += 1
     if not ok:
         bad += 1
-        print("MISMATCH", seed, P, Fl, N, D, dt, dist, "mode2" if mode2 else "torch", "replayed", replayed, same_idx, same_tot, flush=True)
+        print("MISMATCH", seed, P, Fl, N, D, dt, dist, mode, "cap", cap, "replayed", replayed, same_idx, same_tot, flush=True)
 print(f"{n} sharded cases, {bad} mismatches, {time.time() - t0:.0f}s")
