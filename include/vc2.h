@@ -171,6 +171,20 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
                       int64_t* ks, int64_t* K_out, void* v_T, void* f_T, const void* tail, int64_t tail_rows,
                       int flags, void* stream);
 
+/* vc2_compress_ex with a HOST MIRROR of the count: K_host (NULL: none) points at two int64 words of pinned, device-mapped
+ * host memory (hipHostMalloc / torch's pin_memory); the selection launch writes K_host[1] = K_out[1] (status) and then
+ * K_host[0] = K_out[0] there, BEFORE the gather launch runs.  A caller that sets K_host[0] = -1 beforehand and spins in
+ * vc2_wait_host_count has the one number it needs on the host (the reference's `.tolist()`, vidcom2.py:72) ~15 us before
+ * the pass ends and without a device-to-host copy behind it; everything it does with the outputs afterwards is ordered
+ * by the stream.  (The selection-guard bit of the status may still be set on the DEVICE word after the mirror was read.)
+ * vc2_wait_host_count returns the count, or a negative number after timeout_s seconds. */
+int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale,
+                     int map_mode, int64_t grid_h, const void* gather_src, int64_t gather_rows,
+                     void* ws, size_t ws_bytes, void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks,
+                     int64_t* K_out, void* v_T, void* f_T, const void* tail, int64_t tail_rows, int flags,
+                     int64_t* K_host, void* stream);
+int64_t vc2_wait_host_count(const int64_t* K_host, double timeout_s);
+
 /* ---- upstream fusion: LLaVA's get_2dPool (llava/model/llava_arch.py:171-190) + sweep 1 -------
  * xin T[F, H*W, D] (the projector output, token-major) -> x_out T[F, h*w, D] = its 2x2 pool, and the sweep-1
  * channel-statistics partials of x_out in ws (workspace of vc2_workspace_bytes(F, h*w, D)): the pooled tensor is

@@ -21,16 +21,16 @@ def one_shot(n=40):
     return round(statistics.median(lat[5:]), 1)
 
 
-for pre in (False, True):
-    V._PREALLOC = pre
+for pre, early in ((False, False), (True, False), (True, True)):
+    V._PREALLOC, V._EARLY_COUNT = pre, early
     V.clear_plan_cache()
-    print(f"spare outputs {pre!s:5}: one-shot {one_shot()} us")
+    print(f"spare outputs {pre!s:5} early count {early!s:5}: one-shot {one_shot()} us (incl. the final device sync)")
 plan = V._cached_plan(F, N, D, x.dtype, x.device, 0.25, "linear", 0, False, True, 0)
 t = {"cached_plan": [], "enqueue(host)": [], "spare": [], "finish": [], "total": []}
 for _ in range(40):
     torch.cuda.synchronize()
     a = time.perf_counter(); p = V._cached_plan(F, N, D, x.dtype, x.device, 0.25, "linear", 0, False, True, 0)
-    b = time.perf_counter(); p.enqueue(x)
+    b = time.perf_counter(); p.enqueue(x, mirror=True)
     c = time.perf_counter(); p.prepare_spare()
     d = time.perf_counter(); r = p.finish()
     e = time.perf_counter()

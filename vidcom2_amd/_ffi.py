@@ -39,6 +39,9 @@ _SIGNATURES = {
                      _vp, _vp, _vp, _vp],
     "vc2_compress_ex": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
                         _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "vc2_compress_ex2": [_vp, _i64, _i64, _i64, _i32, _dbl, _i32, _i64, _vp, _i64, _vp, _sz, _vp, _vp, _i64, _vp,
+                         _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "vc2_wait_host_count": [_vp, _dbl],
     "vc2_pool_out_tokens": [_i64, _i64, _i32, _vp, _vp],
     "vc2_pool_stats": [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _sz, _vp, _vp],
     "vc2_gather_scatter": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp],
@@ -71,7 +74,7 @@ _SIGNATURES = {
     "vc2_last_error": [],
     "vc2_version": [],
 }
-_RESTYPES = {"vc2_kept_capacity": _i64,  "vc2_last_error": ctypes.c_char_p, "vc2_version": ctypes.c_char_p}
+_RESTYPES = {"vc2_kept_capacity": _i64, "vc2_wait_host_count": _i64,  "vc2_last_error": ctypes.c_char_p, "vc2_version": ctypes.c_char_p}
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2628,7 +2629,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
                                                      const double* __restrict__ vpart, int S2,
                                                      const float* __restrict__ frame_scores, float base,
                                                      float temp, float* __restrict__ scales_out,
-                                                     int* status = nullptr) {
+                                                     int* status = nullptr, long long* khost = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float smf[4];
   __shared__ double smd[4];
@@ -2770,6 +2771,15 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       const long long wv = (Ktot > cap ? 1 : 0) | ((stw & kStatusSpinExpired) ? 2 : 0) | ((stw & kSel2StatusGuard) ? 4 : 0);
       // (one-launch pass: its first kernel zeroed the word and every workgroup ORs -- order-free; stage calls store)
       if (status) atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), (unsigned long long)wv); else K_out[1] = wv;
+      if (khost) {
+        // the host's mirror of (K, status) in pinned memory: the caller only needs K to slice its outputs, so it can go
+        // on while the gather launch is still running (everything after is stream-ordered).  Status first, then the
+        // count the host polls for.  (A selection-guard hit of another workgroup may land after the host has read the
+        // mirror: the device word stays authoritative for that "cannot happen" bit.)
+        __hip_atomic_store(khost + 1, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(khost, (long long)Ktot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   __shared__ int st_local;
@@ -2779,6 +2789,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   __syncthreads();
   if (tid == 0 && st_local) {                                    // (cannot happen; reported, never swallowed)
     if (status) { atomicOr(status, kSel2StatusGuard); atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), 4ull); }
+    if (khost) __hip_atomic_fetch_or(khost + 1, 4ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(809 + (fl ? 50 : 0));
 }
@@ -3471,7 +3482,8 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 // Budgets: vpart (sweep-3 partials, S2 per frame) or frame_scores -> compute_scales in the kernel; else scales_f32[F].
 struct BudgetSrc { const float* scales_f32; const double* vpart; int S2; const float* frame_scores; double base; double temp;
                    float* scales_out; int64_t tpf = 0;         // tpf: the multiplier of vidcom2.py:72 (0: N)
-                   int* status = nullptr; };                   // the pass's kTkStatus word (reported in K_out[1])
+                   int* status = nullptr;                      // the pass's kTkStatus word (reported in K_out[1])
+                   long long* khost = nullptr; };              // pinned host mirror of K_out[0..1] (vc2_compress_ex2)
 int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_sel, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   const BudgetSrc& b, hipStream_t st) {
@@ -3483,7 +3495,7 @@ int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_s
     hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F_sel)), dim3(kFrameNT), smem, st, total, b.scales_f32, int(F),
                        int(f0), int(N), int(b.tpf > 0 ? b.tpf : N), map_mode, int(grid_h), N, cap, ks, offs, idx_out, K_out,
                        b.vpart, b.S2,
-                       b.frame_scores, float(b.base), float(b.temp), b.scales_out, b.status);
+                       b.frame_scores, float(b.base), float(b.temp), b.scales_out, b.status, b.khost);
   });
   return check_launch("select");
 }
@@ -3933,6 +3945,27 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
                       int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
                       void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
                       const void* tail, int64_t tail_rows, int flags, void* stream) {
+  return vc2_compress_ex2(x, F, N, D, dtype, base_scale, map_mode, grid_h, gather_src, gather_rows, ws, ws_bytes, out_rows,
+                          idx_out, cap, ks, K_out, v_T, f_T, tail, tail_rows, flags, nullptr, stream);
+}
+
+int64_t vc2_wait_host_count(const int64_t* K_host, double timeout_s) {
+  // spins on the pinned mirror of K_out[0] (vc2_compress_ex2) until the selection launch has written it; < 0: timed out
+  const volatile int64_t* p = K_host;
+  if (!p) return -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t it = 0;; ++it) {
+    const int64_t v = *p;
+    if (v >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return v; }
+    if ((it & 1023) == 1023 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return -1;
+  }
+}
+
+int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale, int map_mode,
+                     int64_t grid_h, const void* gather_src, int64_t gather_rows, void* ws, size_t ws_bytes,
+                     void* out_rows, int64_t* idx_out, int64_t cap, int64_t* ks, int64_t* K_out, void* v_T, void* f_T,
+                     const void* tail, int64_t tail_rows, int flags, int64_t* K_host, void* stream) {
   if (!x || !idx_out || !ks || !K_out) return fail(VC2_ERR_ARG, "null pointer");
   if (tail_rows < 0 || (tail_rows > 0 && !tail)) return fail(VC2_ERR_ARG, "tail_rows without tail");
   if (N > 8192) return fail(VC2_ERR_UNSUPPORTED, "N=%lld > 8192 tokens per frame", (long long)N);
@@ -3977,11 +4010,12 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
   if (fused_budget) {
     rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
                        BudgetSrc{nullptr, wsp<double>(ws, p.o_vpart), p.S2, nullptr, bs, 0.01, scales, 0,
-                                 wsp<int>(ws, p.o_ticket) + kTkStatus}, st);
+                                 wsp<int>(ws, p.o_ticket) + kTkStatus, reinterpret_cast<long long*>(K_host)}, st);
   } else {
     if ((rc = launch_scales(dtype, s, F, bs, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
     rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
-                       BudgetSrc{scales, nullptr, 0, nullptr, bs, 0.01, nullptr, 0, wsp<int>(ws, p.o_ticket) + kTkStatus}, st);
+                       BudgetSrc{scales, nullptr, 0, nullptr, bs, 0.01, nullptr, 0, wsp<int>(ws, p.o_ticket) + kTkStatus,
+                                 reinterpret_cast<long long*>(K_host)}, st);
   }
   if (rc) return rc;
   if (out_rows && gather_src)

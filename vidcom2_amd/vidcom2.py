@@ -132,6 +132,10 @@ class CompressPlan:
         self.tail_rows = int(tail_rows) if gather else 0
         self._gather, self._want_scores = bool(gather), bool(want_scores)
         self._spare = None
+        # (K, status) mirrored by the selection launch into pinned host memory (vc2_compress_ex2): finish(early=True) gets
+        # the count from there -- ~15 us before the pass ends, no device-to-host copy -- and returns while the gather runs
+        self._khost = None
+        self._khost_armed = False
         self.new_outputs()
 
     def _alloc_outputs(self):
@@ -159,9 +163,10 @@ class CompressPlan:
             self._spare = self._alloc_outputs()
 
     def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None,
-                tail: Optional[torch.Tensor] = None, have_stats: bool = False) -> None:
+                tail: Optional[torch.Tensor] = None, have_stats: bool = False, mirror: bool = False) -> None:
         """have_stats: `self.ws` already holds flat's sweep-1 partials (fused.pool_stats wrote them on this
-        stream), so the pass starts at the variance reduction."""
+        stream), so the pass starts at the variance reduction.  mirror: the count is also written to pinned host
+        memory (finish(early=True))."""
         src = flat if gather_src is None else gather_src
         if have_stats:
             tag = getattr(self.ws, "_vc2_stats_for", None)
@@ -173,18 +178,35 @@ class CompressPlan:
                     or tail.device != self.device:
                 raise RuntimeError(f"tail must be [{self.tail_rows}, {self.D}] {self.dtype} on {self.device}")
             tail = tail.contiguous()
+        khost = None
+        if mirror:
+            if self._khost is None:
+                self._khost = torch.empty(2, dtype=torch.int64).pin_memory()
+                self._khost_addr = ctypes.c_void_p(self._khost.data_ptr())
+                self._khost_word = ctypes.c_int64.from_address(self._khost.data_ptr())
+            self._khost_word.value = -1                  # (host write: the previous pass of this plan was finished)
+            khost = self._khost_addr
+        self._khost_armed = bool(mirror)
         with on_device(self.device):
-            rc = lib().vc2_compress_ex(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
-                                       self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
-                                       src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
-                                       self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
-                                       ptr(tail if self.tail_rows else None), self.tail_rows,
-                                       1 if have_stats else 0, stream_ptr(self.device))
+            rc = lib().vc2_compress_ex2(ptr(flat), self.F, self.N, self.D, DTYPE_CODE[self.dtype], self.base_scale,
+                                        self.map_mode, self.grid_h, ptr(src if self.rows is not None else None),
+                                        src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
+                                        self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
+                                        ptr(tail if self.tail_rows else None), self.tail_rows,
+                                        1 if have_stats else 0, khost, stream_ptr(self.device))
         check(rc, "vc2_compress")
 
     def finish(self) -> CompressionResult:
         # (spinning on an event behind a copy to pinned memory instead of this blocking copy: measured, no gain -- torch's
         #  blocking copy already spins)
+        if self._khost_armed:
+            # the count from the pinned mirror: the caller goes on (slicing, the next launches) while the gather launch is
+            # still running -- everything it does with these tensors is ordered by the stream, like the reference's
+            # tensors after its `.tolist()`.  Falls back to the blocking copy after 50 ms.
+            self._khost_armed = False
+            K = int(lib().vc2_wait_host_count(self._khost_addr, 0.05))
+            if K >= 0:
+                return self._result(self.take(), K, int(self._khost[1]))
         K, status = self.kout.tolist()                   # the single host sync of the path
         return self._result(self.take(), K, status)
 
@@ -219,6 +241,7 @@ _PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _PLAN_CACHE_MAX = int(os.environ.get("VC2_PLAN_CACHE", "8"))       # 0 disables the cache
 _PLAN_CACHE_BYTES = int(os.environ.get("VC2_PLAN_CACHE_MB", "1024")) << 20   # workspaces kept alive by the cache
 _PLAN_LOCK = threading.Lock()
+_EARLY_COUNT = os.environ.get("VC2_EARLY_COUNT", "1") != "0"        # one-shot calls take K from a pinned host mirror (vc2_compress_ex2)
 _PREALLOC = os.environ.get("VC2_PREALLOC", "1") != "0"             # next call's outputs allocated while this pass runs
 
 
@@ -310,7 +333,7 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
                             tail_rows=ntail, ws=stats_ws)
     else:
         plan = _cached_plan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather, ntail)
-    plan.enqueue(x, src, tail, have_stats=stats_ws is not None)
+    plan.enqueue(x, src, tail, have_stats=stats_ws is not None, mirror=_EARLY_COUNT)
     if stats_ws is None and _PREALLOC:
         plan.prepare_spare()              # (the GPU is busy for the next ~190 us: the next call's outputs cost nothing here)
     return plan.finish()
