@@ -105,3 +105,15 @@ def test_fused_ops_have_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="no CPU fallback|CPU fallback"):
         fused.pool_stats(torch.zeros(2, 16, 8, dtype=torch.bfloat16), 4, 4, "average")
     assert set(fused.POOL_MODES) == {"average", "max", "bilinear"}
+
+
+def test_wait_host_count_is_a_plain_host_spin():
+    """vc2_wait_host_count (the host side of vc2_compress_ex2's pinned mirror) touches no device: it returns the word once
+    it is non-negative and a negative number when it stays at the caller's -1 for longer than the timeout."""
+    import numpy as np
+    w = np.array([-1, 0], dtype=np.int64)
+    L = _ffi.lib()
+    assert L.vc2_wait_host_count(ctypes.c_void_p(w.ctypes.data), 0.01) < 0
+    w[0] = 6272
+    assert L.vc2_wait_host_count(ctypes.c_void_p(w.ctypes.data), 0.01) == 6272
+    assert L.vc2_wait_host_count(None, 0.01) < 0

@@ -600,3 +600,65 @@ def test_runs_are_bitwise_repeatable(case):
                 assert sig == first, f"{mode}: run {run} differs from run 0"
         finally:
             _ffi.set_mode("torch")
+
+
+@pytest.mark.gpu
+def test_early_count_mirror_and_spare_outputs_change_nothing():
+    """The one-shot API takes K from the pinned host mirror the selection launch writes (vc2_compress_ex2) and allocates
+    the next call's outputs while the pass runs: same rows / indices / budgets as the blocking copy, call after call,
+    and a result handed out earlier is never overwritten."""
+    import vidcom2_amd as vc
+    from vidcom2_amd import vidcom2 as V
+    dev = torch.device("cuda:0")
+    xs = [synth.make(16, 196, 1024, torch.bfloat16, sd, "drift").to(dev) for sd in (0, 1, 2)]
+    old = (V._EARLY_COUNT, V._PREALLOC)
+    try:
+        V._EARLY_COUNT, V._PREALLOC = False, False
+        V.clear_plan_cache()
+        ref = [vc.compress(x, 196, 0.25) for x in xs]
+        V._EARLY_COUNT, V._PREALLOC = True, True
+        V.clear_plan_cache()
+        got = [vc.compress(x, 196, 0.25) for x in xs for _ in range(2)][::2]
+        torch.cuda.synchronize()
+        for a, b in zip(ref, got):
+            assert a.K == b.K and torch.equal(a.global_idx, b.global_idx) and torch.equal(a.ks, b.ks)
+            assert torch.equal(a.rows, b.rows)
+        assert len({g.rows.data_ptr() for g in got}) == len(got)
+    finally:
+        V._EARLY_COUNT, V._PREALLOC = old
+        V.clear_plan_cache()
+
+
+@pytest.mark.gpu
+def test_plan_cache_is_safe_under_threads():
+    """Several threads through the one-shot API at once, more shapes than the cache holds (evictions while others look
+    up): no KeyError, every result equal to the single-threaded one."""
+    import threading
+    import vidcom2_amd as vc
+    from vidcom2_amd import vidcom2 as V
+    dev = torch.device("cuda:0")
+    shapes = [(4, 49, 64), (6, 49, 128), (8, 16, 256), (5, 100, 64), (3, 196, 128), (7, 37, 64)]
+    xs = [synth.make(F, N, D, torch.bfloat16, 7, "drift").to(dev) for F, N, D in shapes]
+    want = [vc.compress(x, s[1], 0.25).global_idx.cpu() for x, s in zip(xs, shapes)]
+    old_max = V._PLAN_CACHE_MAX
+    errs = []
+
+    def work(t):
+        try:
+            for it in range(30):
+                i = (t + it) % len(shapes)
+                r = vc.compress(xs[i], shapes[i][1], 0.25)
+                if not torch.equal(r.global_idx.cpu(), want[i]):
+                    errs.append(("mismatch", t, i))
+        except Exception as e:  # noqa: BLE001
+            errs.append((repr(e), t))
+    try:
+        V._PLAN_CACHE_MAX = 3
+        V.clear_plan_cache()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        V._PLAN_CACHE_MAX = old_max
+        V.clear_plan_cache()
+    assert not errs, errs[:3]
