@@ -1,7 +1,8 @@
 """Container-only: for FP32 inputs, how often do the oracle's two modes pick the reference's kept indices on random small
 shapes (drift / iid / cancel)?  Round 4: torch-order mode 3 / 160 misses, exact mode 8 / 160 (all but one on `cancel`
 inputs): with fp32 scores there is no rounding to T to hide behind -- near-tied tokens are decided by the last bit of
-torch's fp32 accumulation order AND of its vectorised expf (Sleef), which the oracle does not model.  Not a test."""
+torch's fp32 accumulation order AND of its fp32 exp (MKL VML's vmsExp in this torch build: closed source; 1.1 % of random
+arguments differ in the last bit from the correctly rounded exp the oracle and the kernels compute).  Not a test."""
 import sys, os, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, "/root/reference")
 import torch
