@@ -132,6 +132,8 @@ def cpu_baselines(x_cpu, N, base, budget_s=10.0):
     from oracle import torch_restatement as T
     cores = os.cpu_count() or 1
     counts = sorted({c for c in (8, 16, 32, 64, 128, 256, cores) if c <= cores})
+    if os.environ.get("VC2_BENCH_CPU_THREADS"):         # (the test-suite's subprocess runs: the parity gate, not the sweep)
+        counts = sorted({min(cores, int(c)) for c in os.environ["VC2_BENCH_CPU_THREADS"].split(",")})
 
     def best_of(run, set_threads):
         tried = {}

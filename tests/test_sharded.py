@@ -54,7 +54,7 @@ def test_gloo_world2_matches_unsharded(dtype_name):
     procs = [ctx.Process(target=_worker, args=(r, world, port, dtype_name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=120) for _ in range(world))
+    got = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -257,7 +257,7 @@ def test_two_processes_one_gpu_hip_stages_and_a_real_collective():
     procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=300) for _ in range(world))
+    got = sorted(q.get(timeout=900) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -280,11 +280,11 @@ def test_bench_two_rank_code_path_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VC2_BENCH_ONE_GPU="1", VC2_BENCH_BACKEND="gloo")
+    env = dict(os.environ, VC2_BENCH_ONE_GPU="1", VC2_BENCH_BACKEND="gloo", VC2_BENCH_CPU_THREADS="16,32")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--workload", "cfg2"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints exactly one JSON line
@@ -292,12 +292,12 @@ def test_bench_two_rank_code_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "frame-shard x2"
 
 
-def _run_bench(args, env_extra=None, timeout=900):
+def _run_bench(args, env_extra=None, timeout=1800):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **(env_extra or {}))
+    env = dict(os.environ, VC2_BENCH_CPU_THREADS="16,32", **(env_extra or {}))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, cwd=root, capture_output=True,
                          text=True, timeout=timeout)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -340,11 +340,11 @@ def test_bench_cfg4_strong_scaling_two_ranks_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VC2_BENCH_ONE_GPU="1", VC2_BENCH_BACKEND="gloo")
+    env = dict(os.environ, VC2_BENCH_ONE_GPU="1", VC2_BENCH_BACKEND="gloo", VC2_BENCH_CPU_THREADS="16,32")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--workload", "cfg4"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_gpu"] == 256
