@@ -26,7 +26,8 @@ One JSON line on rank 0 (see the repo prompt for the contract), with extra objec
   "roofline_big"  the same for a > 256 MiB working set (cfg3), where the Infinity Cache cannot hold X
   "cpu_baseline"  the reference CPU path on this box's host cores: kind "port", flavour "torch-restatement" (the same
                   aten ops, oracle/torch_restatement.py) and, nested under "port", the C++/OpenMP oracle -- each at the
-                  best of several thread counts (all 256 hardware threads oversubscribe torch's small ops)
+                  best of several thread counts (all 256 hardware threads oversubscribe torch's small ops;
+                  VC2_BENCH_CPU_THREADS="16,32" restricts the sweep -- the test-suite's subprocess runs do)
   "pass_roofline" the whole pass against 8 TB/s in three states of the input: warm (= value), cold, producer_warm
 """
 from __future__ import annotations
