@@ -41,6 +41,8 @@ for seed in range(lo, hi):
         ok = (torch.equal(r.global_idx.cpu(), o["global_idx"]) and eq(r.v_score.cpu(), o["v"])
               and eq(r.f_score.cpu(), o["f"]) and torch.equal(r.ks.cpu(), o["ks"]))
     n += 1
+    if n % 1000 == 0:                        # (progress: a cut-off run still says how far it got)
+        print(f"[mode {PRIMARY}] seeds {lo}..{seed}: {n} cases, {bad} mismatches so far, {time.time() - t0:.0f}s", flush=True)
     if not ok:
         bad += 1
         proven = None
