@@ -44,6 +44,8 @@ for seed in range(lo, hi):
     finally:
         _ffi.set_mode("torch")
     n += 1
+    if n % 500 == 0:                         # (progress: a cut-off run still says how far it got)
+        print(f"seeds {lo}..{seed}: {n} sharded cases, {bad} mismatches so far, {time.time() - t0:.0f}s", flush=True)
     if not ok:
         bad += 1
         print("MISMATCH", seed, P, Fl, N, D, dt, dist, mode, "cap", cap, "replayed", replayed, same_idx, same_tot, flush=True)
