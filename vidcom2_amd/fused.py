@@ -49,8 +49,9 @@ def gather_scatter(srcs: Sequence[torch.Tensor], idx: Optional[torch.Tensor] = N
     srcs: 2-D tensors [rows_t, D] of one dtype / feature size.  n defaults to len(idx) (or rows of srcs[0]); n_dev
     (device int64[1]) caps it on the device.  dsts default to fresh [n + m, D] (first) / [n, D] tensors.
     A row index outside its tensor is skipped on the device and reported: in `status` (device int32[1], bit 1) when
-    the caller passes one, and -- check=True, what the hooks use -- by an IndexError after one small read-back, like
-    the torch indexing this replaces (an unreported skip would leave an uninitialised row in a fresh destination).
+    the caller passes one, and -- check=True -- by an IndexError after one small read-back, like
+    the torch indexing this replaces (an unreported skip would leave an uninitialised row in a fresh destination).  The
+    model hooks pass lists that keep_positions has just validated, so they skip the second read-back.
     """
     srcs = list(srcs)
     if not 1 <= len(srcs) <= MAX_SOURCES:

@@ -81,7 +81,7 @@ class _LanguageModelShim:
                 vm = st.video_mask[0].to(embeds.device)
                 vpm = kwargs.get("visual_pos_masks")
                 deep = kwargs.get("deepstack_visual_embeds") if torch.is_tensor(vpm) else None
-                fused = _fusable(embeds, kept, st.video_embeds, deep)
+                fused = _fusable(embeds, kept, st.video_embeds, deep) and vm.numel() == embeds.shape[1]
                 vis_rows = None
                 if fused:
                     # device-side keep list + ONE launch for text rows and kept video rows (vc2_keep_positions,
@@ -92,7 +92,9 @@ class _LanguageModelShim:
                     keep, vis_rows = keep_positions(vm, kept, n_video, vpm[0].to(embeds.device) if want_vis else None,
                                                     int(deep[0].shape[0]) if want_vis else None)
                     keep_flags = None
-                    kwargs["inputs_embeds"] = gather_scatter([embeds[0]], keep, check=True)[0][None]
+                    # (no second read-back: keep_positions has just validated the list -- strictly ascending positions of
+                    #  a mask as long as `embeds` -- and raised otherwise; vis_rows likewise against the deep-stack rows)
+                    kwargs["inputs_embeds"] = gather_scatter([embeds[0]], keep, check=False)[0][None]
                 else:
                     video_pos = vm.nonzero(as_tuple=False).squeeze(-1)
                     keep_flags = ~vm
@@ -130,7 +132,7 @@ class _LanguageModelShim:
                 if torch.is_tensor(vpm):
                     if vis_rows is not None:
                         # the deep-stack tensors share ONE index list: one launch for all of them
-                        kwargs["deepstack_visual_embeds"] = gather_scatter(list(deep), vis_rows, check=True)
+                        kwargs["deepstack_visual_embeds"] = gather_scatter(list(deep), vis_rows, check=False)
                     else:
                         if keep_flags is None:
                             keep_flags = torch.zeros(vm.numel(), dtype=torch.bool, device=keep.device)
