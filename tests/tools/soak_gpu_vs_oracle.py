@@ -20,6 +20,8 @@ for (F, N, D), dt, dist, seed in itertools.product(shapes, (torch.float16, torch
     ok = (torch.equal(r.global_idx.cpu(), o["global_idx"]) and torch.equal(r.v_score.cpu(), o["v"])
           and torch.equal(r.f_score.cpu(), o["f"]) and torch.equal(r.ks.cpu(), o["ks"]))
     n += 1
+    if n % 1000 == 0:
+        print(f"{n} cases, {bad} mismatches so far, {time.time() - t0:.0f}s", flush=True)
     if not ok:
         bad += 1
         print("MISMATCH", F, N, D, dt, dist, seed, int((r.v_score.cpu() != o["v"]).sum()), int((r.f_score.cpu() != o["f"]).sum()), flush=True)
