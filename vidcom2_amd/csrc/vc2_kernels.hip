@@ -1404,12 +1404,14 @@ constexpr int kCen2List = 1024;
 struct FrameStatSrc {
   const double* part; int splits; int block_frames; int N; int* diag;
   template <int DT> __device__ __forceinline__ double sumsq(int f, int col, const void* __restrict__ x, int D) const {
+    const float Kf = ldT<DT>(x, int64_t(f / block_frames) * block_frames * N * D + col);   // (issued with the first partials)
     double s1 = 0.0, s2 = 0.0;
     for (int g = f * splits; g < (f + 1) * splits; ++g) {
-      s1 += part[(int64_t(g) * 2 + 0) * D + col];
-      s2 += part[(int64_t(g) * 2 + 1) * D + col];
+      const double a = part[(int64_t(g) * 2 + 0) * D + col], b = part[(int64_t(g) * 2 + 1) * D + col];
+      s1 += a;
+      s2 += b;
     }
-    const double K = double(ldT<DT>(x, int64_t(f / block_frames) * block_frames * N * D + col));
+    const double K = double(Kf);
     return s2 + 2.0 * K * s1 + double(N) * K * K;
   }
 };
@@ -1419,7 +1421,8 @@ struct FrameStatSrc {
 template <int DT>
 __device__ __forceinline__ bool frame_mean_near(float q, bool bounded, bool all, int strict, double kk, double kk_a,
                                                 bool want_bounds, const FrameStatSrc& fs, int f, int col,
-                                                const void* __restrict__ x, int D, int N, float dmin, double& ab) {
+                                                const void* __restrict__ x, int D, int N, float dmin, double& ab,
+                                                const double* ssq_pre = nullptr) {
   if (!bounded) return all || mean_near_T_boundary<DT>(q);       // the empirical margin alone
   // A >= sum_r |x^[r, c]| over the frame (see mean_delta).  |x^| <= 1 gives A <= N: only a mean with a boundary
   // inside that margin fetches sweep 1's partials for the real one (want_bounds: the frame-sharded pass ships
@@ -1428,7 +1431,7 @@ __device__ __forceinline__ bool frame_mean_near(float q, bool bounded, bool all,
                                   : mean_near_T_boundary<DT>(q));
   const bool pre_a = !near && strict != 3 && kk_a > 0.0 && T_boundary_within<DT>(q, mean_delta<DT>(q, double(N), N, kk_a));
   if ((want_bounds || (near && strict == 3) || pre_a) && fs.part) {
-    const double b = abs_sum_bound(fs.sumsq<DT>(f, col, x, D), N, dmin);
+    const double b = abs_sum_bound(ssq_pre ? *ssq_pre : fs.sumsq<DT>(f, col, x, D), N, dmin);
     ab = b < double(N) ? b : double(N);            // (NaN: N)
     if (near && !all && strict == 3) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk));
     if (pre_a) near = T_boundary_within<DT>(q, mean_delta<DT>(q, ab, N, kk_a));
@@ -1519,20 +1522,42 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   // (wave fl reads its frame's N denominators -- in flight with the partial sums below.  A denominator that a rider of
   //  this launch is correcting by an ulp may be read either way: abs_sum_bound allows for that.  Rounds 3 / early 4 had
   //  sweep 2 leave the minimum behind through atomics: +2 us on the sweep.)
+  // Every load this workgroup's results hang on is issued up front -- the channel index (the head of the only
+  // dependent chain), the frame's partial sums, sweep 1's partials for the A-relative margin (18 bytes per lane that
+  // more than half of the waves would otherwise fetch three dependent round trips later, when one of their lanes meets
+  // a candidate), the denominators -- two round trips instead of five.
+  // (UNCONDITIONAL loads at clamped addresses: a load inside a divergent conditional is waited for on the spot)
+  const bool active = c < C && f < F;
+  const int cq = min(c, C - 1), fq = min(f, F - 1);
+  const int col = cols ? cols[cq] : cq;
+  // this frame's segments: one per sweep-2 chunk that meets it (make_plan)
+  const int Sf = int((int64_t(fq + 1) * N - 1) / S_q) - int((int64_t(fq) * N) / S_q) + 1;
+  double v0[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v0[u] = part[(int64_t(fq) * S + min(u, Sf - 1)) * C + cq];
+  float dv[4] = {INFINITY, INFINITY, INFINITY, INFINITY};       // (the frame's first 256 denominators: wave fl = frame f)
+  if (bounded) {                                                // (kernel-uniform)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dv[i] = den[int64_t(fq) * N + min(lane + 64 * i, N - 1)];
+  }
+  const bool pre_stats = bounded && fs.part != nullptr;         // (kernel-uniform)
+  double ssq_pre = 0.0;
+  if (pre_stats) ssq_pre = fs.template sumsq<DT>(fq, col, x, D);  // (the first use of `col`: everything above is in flight)
   float dmin = INFINITY;
   if (bounded && f < F) {
-    for (int r = lane; r < N; r += 64) dmin = fminf(dmin, fabsf(den[int64_t(f) * N + r]));          // (NaN does not enter)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dmin = fminf(dmin, fabsf(dv[i]));                                    // (NaN does not enter)
+    for (int r = lane + 256; r < N; r += 64) dmin = fminf(dmin, fabsf(den[int64_t(f) * N + r]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o, 64));
   }
   __syncthreads();
   double sf = 0.0, ab = 0.0;
   float q = 0.f;
-  const bool active = c < C && f < F;
   if (active) {
-    // this frame's segments: one per sweep-2 chunk that meets it (make_plan)
-    const int Sf = int((int64_t(f + 1) * N - 1) / S_q) - int((int64_t(f) * N) / S_q) + 1;
-    for (int s0 = 0; s0 < Sf; s0 += 8) {                        // (S <= 8: one batch of loads, added in split order)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (u < Sf) sf += v0[u];
+    for (int s0 = 8; s0 < Sf; s0 += 8) {                        // (more than 8 partials: further batches, added in split order)
       double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = part[(int64_t(f) * S + min(s0 + u, Sf - 1)) * C + c];
@@ -1542,7 +1567,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
     const int nc = corr_count ? *corr_count : 0;
     for (int e = 0; e < nc; ++e) {                              // rows whose norm k_norm_fix corrected (normally none)
       if (corr[e].frame == f) {
-        const float v = ldT<DT>(x, int64_t(corr[e].row) * D + (cols ? cols[c] : c));
+        const float v = ldT<DT>(x, int64_t(corr[e].row) * D + col);
         const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_old)));
         const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(corr[e].den_new)));
         sf += double(xn) - double(xo);
@@ -1554,8 +1579,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(501);
   if (replay) {
     if (bounded && dmin_out && blockIdx.x == 0 && cl == 0 && f < F) dmin_out[f] = dmin;     // (k_video_centre's lazy bounds)
-    if (active && frame_mean_near<DT>(q, bounded, all, strict, kk, kk_a, want_bounds != 0, fs, f, cols ? cols[c] : c, x, D, N,
-                                      dmin, ab)) {
+    if (active && frame_mean_near<DT>(q, bounded, all, strict, kk, kk_a, want_bounds != 0, fs, f, col, x, D, N,
+                                      dmin, ab, pre_stats ? &ssq_pre : nullptr)) {
       const int j = atomicAdd(&count, 1);
       if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
     }
@@ -1728,6 +1753,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
   bool flag = false, pre = false;
   const int cl = c < C ? c : C - 1;
   const int my_col = cols ? cols[cl] : cl, my_sp = spos ? spos[cl] : cl;   // (in flight with the partial sums)
+  const int nvc = vcorr_count ? *vcorr_count : 0;                          // (likewise: not a round trip of its own)
   double ab = 0.0;
   float q = 0.f;
   if (c < C) {
@@ -1748,7 +1774,6 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
       }
     }
     // fused centre launch: the group sums were formed before the norm fix-ups -> their corrections are added here
-    const int nvc = vcorr_count ? *vcorr_count : 0;
     for (int e = 0; e < nvc; ++e) {                               // (normally none)
       const float v = ldT<DT>(x, int64_t(vcorr[e].row) * D + my_col);
       const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(vcorr[e].den_old)));
