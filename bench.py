@@ -283,6 +283,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
     args = ap.parse_args()
+    if os.environ.get("VC2_BENCH_WATCHDOG"):
+        # a run that is still going after this many seconds dumps every thread's Python stack to stderr and exits (the
+        # test-suite's subprocess runs set it: a hung rank says where instead of sitting out a 30-minute collective timeout)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["VC2_BENCH_WATCHDOG"]), exit=True)
 
     if args.gpus < 1:
         raise SystemExit("[bench] --gpus must be >= 1")
