@@ -371,11 +371,16 @@ def main():
     # ---- timed region -------------------------------------------------------------------------------
     # (setup, not warm-up: the CPU parity gate above kept the GPU idle for ~20 s and it comes back clocked down; a third
     # of a second of passes brings the clocks up before the W warm-up steps and the K timed steps of the contract)
+    # (More than one rank: a FIXED number of passes.  A loop bounded by each rank's own clock ran 30 passes on one rank
+    #  and 40 on the other every so often -- mismatched all-gathers, both ranks hung until the 30-minute collective
+    #  timeout: the intermittent hang of the two-rank tests, found with VC2_BENCH_WATCHDOG in round 4.)
     t_w = time.perf_counter()
-    while time.perf_counter() - t_w < 0.3:
+    rounds = 0
+    while (rounds < 5) if world > 1 else (time.perf_counter() - t_w < 0.3):
         for _ in range(10):
             step()
         torch.cuda.synchronize()
+        rounds += 1
     for _ in range(args.warmup):
         step()
     elapsed = time_steps(step, args.steps, dist_on)

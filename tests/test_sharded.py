@@ -301,8 +301,10 @@ def _run_bounded(cmd, env, cwd, timeout=420, attempts=2):
     """subprocess.run for the multi-process bench runs, bounded: its own session (a timeout kills the launcher AND its
     ranks -- an orphaned rank would keep the pipes open and block communicate() for good), bench.py's watchdog (every
     thread's Python stack on stderr when a rank is still going after timeout - 120 s), and ONE more attempt when a run was
-    cut off that way (a hang of a two-rank run was seen twice in ~30 full suite runs on the GPU boxes and never in 90
-    back-to-back repeats of the same command: scripts/debug/two_rank_loop.sh).  An ordinary failure is returned as is."""
+    cut off that way.  (Written for an intermittent hang of the two-rank runs -- 3 of 22 loops over this file -- that the
+    watchdog's stacks then pinned on bench.py itself: its clock-warming loop was bounded by each rank's OWN clock, so now
+    and then one rank ran ten passes, i.e. forty all-gathers, more than the other.  Fixed there; the bounds stay.)
+    An ordinary failure is returned as is."""
     import signal
     import subprocess
     import warnings
