@@ -314,7 +314,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         # lazy communicator creation on purpose: with `device_id=` (eager init) every pass measured ~45 us slower on
         # this stack in round 1; with it the numbers match a plain process
-        torch.distributed.init_process_group(os.environ.get("VC2_BENCH_BACKEND", "nccl"))
+        # (a collective that has not completed after 10 minutes is an error, not a 30-minute wait (gloo): the longest
+        #  legitimate wait is the other ranks' for rank 0's CPU parity gate, tens of seconds)
+        import datetime
+        torch.distributed.init_process_group(os.environ.get("VC2_BENCH_BACKEND", "nccl"),
+                                             timeout=datetime.timedelta(seconds=int(os.environ.get("VC2_BENCH_COLL_TIMEOUT", "600"))))
 
     import vidcom2_amd as vc
     from vidcom2_amd import _ffi, synth
