@@ -110,6 +110,21 @@ def time_steps(fn, steps, dist_on):
     return time.perf_counter() - t0
 
 
+def warm_clocks(step, multi_rank, sync=None, seconds=0.3, fixed_rounds=5):
+    """Passes that bring the GPU clocks back up before the warm-up and timed steps; returns how many were issued.
+    One rank: about `seconds` of them.  More than one rank: a CONSTANT number -- every pass of the frame-sharded path
+    issues collectives, and how many a rank issues must not depend on that rank's own clock (tests/test_abi_and_host.py)."""
+    sync = sync or torch.cuda.synchronize
+    t0 = time.perf_counter()
+    rounds = 0
+    while (rounds < fixed_rounds) if multi_rank else (time.perf_counter() - t0 < seconds):
+        for _ in range(10):
+            step()
+        sync()
+        rounds += 1
+    return rounds * 10
+
+
 def median_step_ms(fn, steps):
     """Median over `steps` individually event-timed passes (SURVEY.md §8d asks for the median; the contract's
     ms_per_step above is the mean of the K-step block)."""
@@ -378,13 +393,7 @@ def main():
     # (More than one rank: a FIXED number of passes.  A loop bounded by each rank's own clock ran 30 passes on one rank
     #  and 40 on the other every so often -- mismatched all-gathers, both ranks hung until the 30-minute collective
     #  timeout: the intermittent hang of the two-rank tests, found with VC2_BENCH_WATCHDOG in round 4.)
-    t_w = time.perf_counter()
-    rounds = 0
-    while (rounds < 5) if world > 1 else (time.perf_counter() - t_w < 0.3):
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize()
-        rounds += 1
+    warm_clocks(step, world > 1)
     for _ in range(args.warmup):
         step()
     elapsed = time_steps(step, args.steps, dist_on)

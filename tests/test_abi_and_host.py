@@ -117,3 +117,28 @@ def test_wait_host_count_is_a_plain_host_spin():
     w[0] = 6272
     assert L.vc2_wait_host_count(ctypes.c_void_p(w.ctypes.data), 0.01) == 6272
     assert L.vc2_wait_host_count(None, 0.01) < 0
+
+
+def test_bench_issues_a_constant_number_of_passes_per_rank_before_timing():
+    """bench.py's clock-warming passes: with more than one rank their number must not depend on the rank's own clock
+    (every pass of the frame-sharded path is four all-gathers; round 4: a loop bounded by `perf_counter()` ran ten passes
+    more on one rank than on the other now and then, and both hung)."""
+    import importlib.util
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vc2_bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    counts = []
+    for delay in (0.0, 0.02):                                   # a fast and a slow "rank"
+        n = [0]
+
+        def step():
+            n[0] += 1
+            time.sleep(delay / 10)
+        issued = bench.warm_clocks(step, True, sync=lambda: None)
+        assert issued == n[0]
+        counts.append(issued)
+    assert counts[0] == counts[1] == 50
+    n = [0]
+    assert bench.warm_clocks(lambda: n.__setitem__(0, n[0] + 1), False, sync=lambda: None, seconds=0.01) == n[0] >= 10
