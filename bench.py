@@ -21,6 +21,11 @@ N > 1 : "target": weak scaling -- every rank holds 128 frames of ONE long video 
         reference's document-level data parallelism), two clips in flight per GPU.
         The sharded lines carry "exchanges_us": the mean time of every all-gather with its message size.
 
+Environment knobs: VC2_BENCH_WATCHDOG=<s> (a run still going after s seconds dumps every thread's Python stack and
+exits), VC2_BENCH_COLL_TIMEOUT=<s> (collective timeout, default 600), VC2_BENCH_CPU_THREADS="16,32" (thread counts of
+the CPU-baseline sweep), VC2_BENCH_FORCE_DIST=1 (the sharded path and its collectives at world size 1),
+VC2_BENCH_ONE_GPU=1 + VC2_BENCH_BACKEND=gloo (tests: every rank on cuda:0).
+
 One JSON line on rank 0 (see the repo prompt for the contract), with extra objects:
   "roofline"      the dominant kernel's achieved algorithmic HBM rate (hipEvent-timed inside this run)
   "roofline_big"  the same for a > 256 MiB working set (cfg3), where the Infinity Cache cannot hold X
