@@ -142,3 +142,19 @@ def test_bench_issues_a_constant_number_of_passes_per_rank_before_timing():
     assert counts[0] == counts[1] == 50
     n = [0]
     assert bench.warm_clocks(lambda: n.__setitem__(0, n[0] + 1), False, sync=lambda: None, seconds=0.01) == n[0] >= 10
+
+
+def test_f16_fast_quotient_is_the_ieee_quotient(tmp_path):
+    """The fp16 fast path of sweep 2 (k_norm_colsum2) divides by q = fma(e, r, q0), q0 = x r, e = fma(-dn, q0, x): the
+    exhaustive checker behind it (tests/tools/check_f16_quotient.c; every fp16 x, a strided subset of the denominators
+    here, r off by up to +-4 ulps) must find the IEEE fp32 quotient every time."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = tmp_path / "chk"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", os.path.join(ROOT, "tests", "tools", "check_f16_quotient.c"),
+                           "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe), "61"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    assert out.stdout.count("mismatches 0") == 9, out.stdout

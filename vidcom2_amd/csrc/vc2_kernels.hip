@@ -461,6 +461,7 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   }
 }
 
+#ifndef VC2_DEV_ONLY
 __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict__ var_f32, int D, int k,
                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
                                                         int* __restrict__ perm, uint32_t* __restrict__ wperm,
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   else chan_select_body<uint32_t>(smem, pre, D, k, mask, cols, perm, wperm, wcpos, status);
   if (threadIdx.x == 0) VC2_STAMP(209);
 }
+#endif
 __host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
 
 // torch.topk(sorted=True)'s ORDER of the k kept channels from `perm` (what nth_element / partial_sort left in
@@ -550,6 +552,7 @@ __host__ inline int order_parts(int k, int max_parts) {        // a power of two
   return parts;
 }
 
+#ifndef VC2_DEV_ONLY
 __global__ __launch_bounds__(kOrdNT) void k_chan_order(OrderArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = kOrdNT / 64;
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(kOrdNT) void k_chan_order(OrderArgs a) {
     chan_order_body<uint32_t, NW, 4, 8>(smem, a.var_f32, a.D, a.k, a.perm, a.cols, a.order, a.opos, a.spos,
                                         int(blockIdx.x), int(gridDim.x), a.wperm, a.wcpos, a.status);
 }
+#endif
 
 template <int DT>
 __global__ void k_gather_cols(const void* __restrict__ x, int64_t /*R*/, int D, const int64_t* __restrict__ idx,
@@ -1196,6 +1200,277 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
   }
   seg_a = seg_b;
   if (seg_a < row_b) __syncthreads();                            // (the next segment refills the row buffers)
+  }
+  VC2_WGTIME(1, 1);
+}
+
+// ---- sweep 2, streamlined ("v2") -------------------------------------------------------------------------------
+// The same results as k_norm_colsum<.., ACC = 1>, for the shapes real models have -- 16-bit rows of NCH full 1 KiB
+// chunks (D = 512 NCH), the reference's ratio of one half (C = D / 2 = 64 * 4 NCH: no padded compact positions) -- with
+// the row loop rebuilt around what round 4's profiles showed it spends its time on:
+//   * rows in flight.  The row's 4 NCH selected elements per lane are read from LDS into registers FIRST (bf16:
+//     ds_read_u16_d16_hi -- the element lands in the high half, i.e. as its fp32 value, no unpack), which frees the row buffer at once:
+//     the DMA of row i + 2 is issued into it before row i is computed, so a wave keeps TWO rows on their way from memory
+//     (16 per CU instead of 8) with the same two buffers.  The wait for row i is `s_waitcnt vmcnt(NCH)` -- the younger
+//     row's NCH loads stay outstanding -- which is only sound because nothing else is in the vector-memory queue inside
+//     the loop: the per-row stores (den, rflag) and the "torch order" queue pushes are parked in lanes (lane j keeps the
+//     wave's j-th row) and written once per 64 rows / segment.
+//   * instruction issue.  DMA: NCH global_load_lds with immediate offsets from a scalar row base (the general kernel
+//     runs a 14-instruction loop per chunk); LDS addresses: one register per element, the buffer parity is the
+//     instruction's immediate offset (the general kernel recomputes 4 NCH addresses per row); no padding masks; the
+//     element range test of the bf16 quotient is ONE v_min3_f32 per pair on the products (a nonzero normal bf16 result is
+//     all the midpoint argument above kBf16SpanLo needs; overflow / underflow of the squares shows in the norm itself,
+//     which is tested once per row); the correctly rounded square root in fp32.
+//   * fp16 gets a fast quotient too: q0 = x * r, e = fma(-dn, q0, x), q = fma(e, r, q0) with r = v_rcp_f32(dn) IS the IEEE
+//     fp32 quotient for every nonzero finite fp16 x and dn -- proved by exhaustion (all 1.0e9 pairs, r off by up to +-4
+//     ulps: tests/tools/check_f16_quotient.c) -- so RN_f16 of it is what torch's fp16 division returns; the squares are
+//     exact fp32 fused multiply-adds in two chains (the bound of acc_norm_ulps).
+// Rows the fast path cannot take (norm outside the range where the fp32 sum of squares is safe, a zero / subnormal
+// quotient in bf16, non-finite data) are redone on the spot exactly as the general kernel does them (fp64 sum of squares,
+// exactly rounded division; rflag[row] = 1 tells sweep 3).
+template <int NCH> __device__ __forceinline__ void s2_wait_row(bool younger_in_flight) {
+  if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int J, int NCH>
+__device__ __forceinline__ void s2_issue_chunks(const unsigned char* __restrict__ src_lane, unsigned char* lds_uniform) {
+  if constexpr (J < NCH) {                                        // (the immediate offset applies to BOTH addresses; 13 bits signed)
+    constexpr int hop = (J >> 2) * 4096, off = (J & 3) * 1024;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(src_lane + hop), (lds_void_t*)(lds_uniform + hop), 16, off, 0);
+    s2_issue_chunks<J + 1, NCH>(src_lane, lds_uniform);
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void s2_issue_row(const unsigned char* __restrict__ src_lane, unsigned char* lds_uniform) {
+  s2_issue_chunks<0, NCH>(src_lane, lds_uniform);
+}
+__device__ __forceinline__ f2_t pk_fma_f32(f2_t a, f2_t b, f2_t c) {
+  f2_t r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f2_t pk_fnma_f32(f2_t a, f2_t b, f2_t c) {   // c - a * b
+  f2_t r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ f2_t pk_mul_f32(f2_t a, f2_t b) {
+  f2_t r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+constexpr float kS2NormLoBf16 = 1.8189894035458565e-12f;   // 2^-39 (> 1e-12: clamp_min is the identity above it)
+constexpr float kS2NormHiBf16 = 1.099511627776e12f;        // 2^40
+constexpr float kS2QuotMinBf16 = 2.3509887016445750e-38f;  // 2^-125: products below it may round to a subnormal bf16
+constexpr float kS2NormLoF16 = 6.103515625e-05f;           // 2^-14: dn a normal fp16 number
+constexpr float kS2NormHiF16 = 32768.f;
+
+template <int DT, int NCH, int RIDER>
+__global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __restrict__ x, int N, const int* __restrict__ cols,
+                                                                 int strict, int S, int q, int64_t R,
+                                                                 float* __restrict__ den_out, double* __restrict__ part,
+                                                                 int* __restrict__ tk, unsigned long long* __restrict__ fixq,
+                                                                 int nfix_cap, uint8_t* __restrict__ rflag, OrderArgs rider) {
+  static_assert(DT == VC2_BF16 || DT == VC2_F16, "16-bit inputs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int D = NCH * 512, C = D / 2, NPLB = NCH * 4, NP = NCH * 2, ROWB = NCH * 1024;
+  const int nrider = (RIDER && rider.perm) ? (rider.parts & 0xFF) : 0;
+  VC2_WGTIME(1, 0);
+  if constexpr (RIDER != 0) {
+    if (int(blockIdx.x) < nrider) {
+      chan_order_body<uint32_t, kRowWaves, 4, 4>(smem, rider.var_f32, rider.D, rider.k, rider.perm, rider.cols,
+                                                 rider.order, rider.opos, rider.spos,
+                                                 int(blockIdx.x), nrider, rider.wperm, rider.wcpos, rider.status);
+      VC2_WGTIME(1, 1);
+      return;
+    }
+  }
+  const int bid = int(blockIdx.x) - nrider;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row_a = int64_t(bid) * q, row_b = min(R, row_a + q);
+  unsigned char* wbuf = smem + size_t(2 * wave) * ROWB;           // this wave's two row buffers
+  // LDS byte address (buffer 0) of the lane's elements: pair k = compact positions 128 k + 2 lane, + 1
+  uint32_t addr[NPLB];
+  {
+    const uint32_t base = uint32_t(uintptr_t((lds_void_t*)wbuf));
+    int2 t[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) t[k] = *reinterpret_cast<const int2*>(cols + 128 * k + 2 * lane);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { addr[2 * k] = base + uint32_t(t[k].x) * 2u; addr[2 * k + 1] = base + uint32_t(t[k].y) * 2u; }
+  }
+  const unsigned char* xl = static_cast<const unsigned char*>(x) + size_t(lane) * 16;
+  typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  const int margin_fast = kFragileUlpsNorm + acc_norm_ulps(NPLB);
+
+  for (int64_t seg_a = row_a; seg_a < row_b;) {
+    const int f = int(seg_a / N);
+    const int64_t seg_b = min(row_b, int64_t(f + 1) * N);
+    const int sp = bid - int((int64_t(f) * N) / q);
+    const int64_t r0 = seg_a + wave;                              // this wave's rows: r0 + 4 i, i < cnt
+    const int cnt = r0 < seg_b ? int((seg_b - r0 + kRowWaves - 1) / kRowWaves) : 0;
+    double acc[NPLB];
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
+    // per-row results parked in lanes: lane j keeps row (base + j) of the wave until flush()
+    float pk_dn = 0.f;
+    uint32_t pk_meta = 0u;                                        // bit 0: norm next to a T rounding boundary, bit 1: exact division
+    auto flush = [&](int first, int count) {                      // rows r0 + 4 (first + j), j < count
+      const bool mine = lane < count;
+      const int64_t row = r0 + int64_t(kRowWaves) * (first + lane);
+      if (mine) {
+        den_out[row] = pk_dn;
+        if (rflag) rflag[row] = uint8_t((pk_meta >> 1) & 1u);
+      }
+      const unsigned long long fm = __ballot(mine && (pk_meta & 1u));
+      if (fm) {                                                   // (wave-uniform) one queue reservation for all of them
+        int base = 0;
+        if (lane == 0) base = atomicAdd(tk + kTkFixCount, __popcll(fm));
+        base = __shfl(base, 0, 64);
+        const int j = base + __popcll(fm & ((1ull << lane) - 1ull));
+        if (mine && (pk_meta & 1u) && j < nfix_cap)
+          __hip_atomic_store(fixq + j, fixq_pack(row, pk_dn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
+    auto row_src = [&](int i) -> const unsigned char* { return xl + size_t(r0 + int64_t(kRowWaves) * i) * (size_t(D) * 2); };
+    if (cnt > 0) s2_issue_row<NCH>(row_src(0), wbuf);
+    if (cnt > 1) s2_issue_row<NCH>(row_src(1), wbuf + ROWB);
+
+    auto step = [&](auto par_tag, int i) {
+      constexpr int PAR = decltype(par_tag)::value;
+      s2_wait_row<NCH>(i + 1 < cnt);
+      // (gfx950 runs with SRAM ECC: a d16 load ZEROES the other half of its register instead of keeping it, so a pair
+      // cannot be assembled by two loads -- but a bf16 element loaded into the HIGH half IS its fp32 value: no unpack)
+      float XA[NP], XB[NP];                                       // the lane's pairs as fp32 values
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if constexpr (DT == VC2_BF16) {
+          asm volatile("ds_read_u16_d16_hi %0, %2 offset:%4\n\tds_read_u16_d16_hi %1, %3 offset:%4"
+                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]), "n"(PAR * ROWB) : "memory");
+        } else {
+          asm volatile("ds_read_u16 %0, %2 offset:%4\n\tds_read_u16 %1, %3 offset:%4"
+                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]), "n"(PAR * ROWB) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(XA[k]), "+v"(XB[k]));   // (the loads' results: not before the wait)
+      if (i + 2 < cnt) s2_issue_row<NCH>(row_src(i + 2), wbuf + PAR * ROWB);
+      if constexpr (DT == VC2_F16) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          union { uint16_t u; _Float16 h; } ca, cb;
+          ca.u = uint16_t(__float_as_uint(XA[k])); cb.u = uint16_t(__float_as_uint(XB[k]));
+          XA[k] = float(ca.h); XB[k] = float(cb.h);
+        }
+      }
+      // ---- the fast path: sum of squares as exact products in two fp32 chains (the bound of acc_norm_ulps) ---------
+      f2_t s2 = {0.f, 0.f}, s3 = {0.f, 0.f};                        // (four independent chains of NP / 2 roundings each)
+#pragma unroll
+      for (int k = 0; k < NP; k += 2) {
+        s2 = pk_fma_f32((f2_t){XA[k], XB[k]}, (f2_t){XA[k], XB[k]}, s2);
+        s3 = pk_fma_f32((f2_t){XA[k + 1], XB[k + 1]}, (f2_t){XA[k + 1], XB[k + 1]}, s3);
+      }
+      const float tot = wave_sum_bcast_f32((s2.x + s2.y) + (s3.x + s3.y));
+      const float nrm32 = __builtin_sqrtf(tot);                   // correctly rounded (HIP's default for fp32 sqrt)
+      constexpr float lo = DT == VC2_BF16 ? kS2NormLoBf16 : kS2NormLoF16, hi = DT == VC2_BF16 ? kS2NormHiBf16 : kS2NormHiF16;
+      bool ok = nrm32 >= lo && nrm32 <= hi;                       // (NaN: false)
+      float dn = 0.f;
+      uint32_t Q[NP];
+      if (ok) {
+        const float norm = rnT<DT>(nrm32);
+        dn = rnT<DT>(fmaxf(norm, 1e-12f));
+        const float r = __builtin_amdgcn_rcpf(dn);
+        const f2_t r2 = {r, r};
+        if constexpr (DT == VC2_BF16) {
+          float m = 1.f;
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const f2_t pr = pk_mul_f32((f2_t){XA[k], XB[k]}, r2);
+            m = fminf(fminf(fabsf(pr.x), fabsf(pr.y)), m);
+            union { b2_t b; uint32_t u; } c;
+            c.b = __builtin_convertvector(pr, b2_t);
+            Q[k] = c.u;
+          }
+          ok = !__any(m < kS2QuotMinBf16);
+        } else {
+          const f2_t d2 = {dn, dn};
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            const f2_t xx = {XA[k], XB[k]};
+            const f2_t q0 = pk_mul_f32(xx, r2);
+            const f2_t e = pk_fnma_f32(d2, q0, xx);
+            const f2_t qq = pk_fma_f32(e, r2, q0);
+            union { h2_t h; uint32_t u; } c;
+            c.h = __builtin_convertvector(qq, h2_t);
+            Q[k] = c.u;
+          }
+        }
+      }
+      uint32_t meta;
+      if (ok) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          if constexpr (DT == VC2_BF16) {
+            acc[2 * k] += double(__uint_as_float(Q[k] << 16));
+            acc[2 * k + 1] += double(__uint_as_float(Q[k] & 0xFFFF0000u));
+          } else {
+            union { uint32_t u; h2_t h; } c;
+            c.u = Q[k];
+            const f2_t w = __builtin_convertvector(c.h, f2_t);
+            acc[2 * k] += double(w.x);
+            acc[2 * k + 1] += double(w.y);
+          }
+        }
+        meta = (strict == 2 || near_T_boundary<DT>(nrm32, margin_fast)) ? 1u : 0u;
+      } else {
+        // ---- the row as the general kernel does it (rare) ------------------------------------------------------
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const double a = double(XA[k]), b = double(XB[k]);
+          t = fma(a, a, t);
+          t = fma(b, b, t);
+        }
+        const float n32 = float(sqrt(wave_sum_bcast(t)));
+        const float norm = rnT<DT>(n32);
+        dn = rnT<DT>(fmaxf(norm, 1e-12f));
+        if (norm != norm) dn = norm;
+        const double inv = 1.0 / double(dn);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const double va = double(rnT<DT>(div_via_f64(XA[k], inv)));
+          const double vb = double(rnT<DT>(div_via_f64(XB[k], inv)));
+          asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc[2 * k]) : "v"(va));     // (asm: keeps the two paths' adds apart --
+          asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc[2 * k + 1]) : "v"(vb)); //  merged, they cost 4 NCH register pairs)
+        }
+        meta = ((strict == 2 || near_T_boundary<DT>(n32, kFragileUlpsNorm)) ? 1u : 0u) | 2u;
+      }
+      if (lane == (i & 63)) { pk_dn = dn; pk_meta = meta; }
+      if ((i & 63) == 63) flush(i - 63, 64);
+    };
+    for (int i = 0; i < cnt; i += 2) {
+      step(std::integral_constant<int, 0>{}, i);
+      if (i + 1 < cnt) step(std::integral_constant<int, 1>{}, i + 1);
+    }
+    if (cnt & 63) flush(cnt & ~63, cnt & 63);
+    // combine the 4 waves' column sums in wave order (fixed order) through LDS (the row buffers are free now)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double* sacc = reinterpret_cast<double*>(smem);                // [kRowWaves][C] doubles
+#pragma unroll
+    for (int i = 0; i < NPLB; ++i) sacc[wave * C + compact_pos<1>(i, lane)] = acc[i];
+    __syncthreads();
+    for (int p = tid; p < C; p += kRowWaves * 64) {
+      double t = sacc[p];
+#pragma unroll
+      for (int w = 1; w < kRowWaves; ++w) t += sacc[w * C + p];
+      part[(int64_t(f) * S + sp) * C + p] = t;
+    }
+    seg_a = seg_b;
+    if (seg_a < row_b) __syncthreads();                            // (the next segment refills the row buffers)
   }
   VC2_WGTIME(1, 1);
 }
@@ -2992,6 +3267,7 @@ __global__ void k_kat_round(const float* __restrict__ in, int64_t n, void* __res
 // ======================================================================================
 // host side: workspace plan + launchers
 // ======================================================================================
+#ifndef VC2_DEV_ONLY      // (host side: plans and launches)
 constexpr int64_t kMaxFramesTotal = 65536;   // frames of the WHOLE video in the frame-sharded path
 
 struct Plan {
@@ -3300,8 +3576,44 @@ int launch_norm_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                      wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
   return VC2_OK;
 }
+// the streamlined sweep 2 (k_norm_colsum2): 16-bit rows of NCH full 1 KiB chunks, C = D / 2, "torch order" mode
+#ifndef VC2_S2_V2
+#define VC2_S2_V2 1
+#endif
+std::atomic<int> g_s2v2{-1};            // -1: not read yet (environment VC2_S2_V2, default: on)
+inline bool s2v2_on() {
+  int v = g_s2v2.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("VC2_S2_V2"); v = e ? (atoi(e) != 0) : VC2_S2_V2; g_s2v2.store(v, std::memory_order_relaxed); }
+  return v != 0;
+}
+inline int s2v2_nch(const Plan& p, const ChanSet& cs) {
+  if (!s2v2_on() || p.dt == VC2_F32 || p.VEC == 1 || !cs.cols || !fast_acc(p, cs)) return 0;
+  if (p.D % 512 != 0 || int64_t(cs.C) * 2 != p.D) return 0;
+  const int nch = int(p.D / 512);
+  return (nch == 2 || nch == 7 || nch == 8) ? nch : 0;
+}
+template <int DT, int NCH>
+int launch_norm_v2(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
+  size_t smem = size_t(2) * kRowWaves * NCH * 1024;                                // row buffers, then the combine (same size)
+  if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
+  int rc = allow_big_lds(&k_norm_colsum2<DT, NCH, 1>, smem, "k_norm_colsum2");
+  if (rc) return rc;
+  hipLaunchKernelGGL((k_norm_colsum2<DT, NCH, 1>), dim3(unsigned(p.S_W + (rider.perm ? (rider.parts & 0xFF) : 0))),
+                     dim3(kRowWaves * 64), smem, st, x, int(p.N), cs.cols, cs.strict, p.S, p.S_q, p.R,
+                     wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
+  return VC2_OK;
+}
 template <int DT, int VEC, int NPLB>
 int launch_norm_t(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
+  if constexpr (DT != VC2_F32 && VEC > 1) {
+    switch (s2v2_nch(p, cs)) {
+      case 2: if constexpr (NPLB == 8) return launch_norm_v2<DT, 2>(p, x, cs, ws, rider, st); break;
+      case 7: if constexpr (NPLB == 28) return launch_norm_v2<DT, 7>(p, x, cs, ws, rider, st); break;
+      case 8: if constexpr (NPLB == 32) return launch_norm_v2<DT, 8>(p, x, cs, ws, rider, st); break;
+      default: break;
+    }
+  }
   if constexpr (DT != VC2_F32) {
     if (fast_acc(p, cs)) return launch_norm_acc<DT, VEC, NPLB, 1>(p, x, cs, ws, rider, st);
   }
@@ -3544,11 +3856,13 @@ int launch_gather_rows(const void* src, int64_t src_rows, int64_t D, int ES, con
   return launch_gather(a, 1, st);
 }
 
+#endif   // VC2_DEV_ONLY
 }  // namespace
 
 // ======================================================================================
 // C ABI
 // ======================================================================================
+#ifndef VC2_DEV_ONLY      // (VC2_DEV_ONLY: device-only builds of single kernels for ISA inspection, scripts/dev_isa.sh)
 extern "C" {
 
 const char* vc2_last_error(void) { return g_err; }
@@ -4177,6 +4491,21 @@ int vc2_profile_collect(int max_kernels, const char** names, double* total_ms, i
   return n;
 }
 
+#ifdef VC2_DEBUG_EXPORTS     // (scripts/dev/*: where a plan keeps its arrays, run-time switches of kernel variants)
+int vc2_debug_plan(int64_t F, int64_t N, int64_t D, int dtype, int64_t* out /*[16]*/) {
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  const int64_t v[16] = {int64_t(p.o_den), int64_t(p.o_part_col), int64_t(p.o_rflag), int64_t(p.o_ticket), int64_t(p.o_nfixlist),
+                         p.S, p.S_q, p.S_W, int64_t(p.o_fc), int64_t(p.o_vc), int64_t(p.o_total), int64_t(p.o_cols), p.S2, int64_t(p.o_vpart), 0, 0};
+  for (int i = 0; i < 16; ++i) out[i] = v[i];
+  return VC2_OK;
+}
+int vc2_debug_set(int key, int value) {
+  if (key == 0) g_s2v2.store(value, std::memory_order_relaxed);
+  return VC2_OK;
+}
+#endif
 #ifdef VC2_DEBUG_TIMING
 int vc2_debug_wg(unsigned long long* out /*[4][2][4096]*/) {
   (void)hipDeviceSynchronize();
@@ -4194,3 +4523,8 @@ int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {
 #endif
 
 }  // extern "C"
+#else
+namespace {
+VC2_DEV_ONLY
+}
+#endif
