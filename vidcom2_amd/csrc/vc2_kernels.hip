@@ -62,7 +62,7 @@ __device__ __forceinline__ void dbg_stamp(int tag) {      // (one lane) wall clo
 }
 #define VC2_STAMP(tag) dbg_stamp(tag)
 // per-workgroup begin / end times of the three sweeps (slot 0: k_chan_stats, 1: k_norm_colsum, 2: k_dist)
-namespace vc2 { __device__ unsigned long long g_dbg_wg[4][2][4096]; }
+namespace vc2 { __device__ unsigned long long g_dbg_wg[6][2][4096]; }     // (slots 4, 5: sweep 2's first row landed / row loops over, combine done)
 #define VC2_WGTIME(slot, which) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_wg[slot][which][blockIdx.x] = wall_clock64(); } while (0)
 #else
 #define VC2_STAMP(tag) ((void)0)
@@ -522,8 +522,8 @@ __device__ __forceinline__ void chan_order_body(unsigned char* smem, const float
     __syncthreads();
     for (int q = tid; q < k; q += NT) emit(q, T::idx(S.w[q]));
   } else {
-    // workgroup `part` of `nparts` = 2^L answers for one arrival segment of std::sort(q, q + k - 1) (see introsort2)
-    introsort2<W, NW, SOLO, COOP>(S, Q, k - 1, emit, tid, part, 31 - __clz(nparts));
+    // workgroup `part` of `nparts` answers for one arrival segment of std::sort(q, q + k - 1) (see introsort2)
+    introsort2<W, NW, SOLO, COOP>(S, Q, k - 1, emit, tid, part, nparts);
     if (tid == 0 && part == nparts - 1) emit(k - 1, T::idx(S.w[k - 1]));       // the nth_element pivot stays last
   }
 }
@@ -540,12 +540,25 @@ struct OrderArgs {          // the ORDER job (all null: none), done by `parts` w
 #define VC2_RIDER_PARTS 64     // rider workgroups of sweep 2 (4 waves each); 16 -> 64: the slowest rider (largest
                                // arrival segment) sets the time: cfg2 131 -> 124 us
 #endif
+#ifndef VC2_RIDER_PARTS_LONG
+#define VC2_RIDER_PARTS_LONG 64     // ... when the sweep is expected to last > 30 us (see rider_parts_max)
+#endif
 #ifndef VC2_ORDER_PARTS
 #define VC2_ORDER_PARTS 64     // workgroups of the stand-alone k_chan_order
 #endif
 #ifndef VC2_ORDER_MINSEG
 #define VC2_ORDER_MINSEG 16
 #endif
+// How many rider workgroups a sweep-2 launch carries: every rider takes one of the 512 resident workgroup slots from the
+// streaming workgroups (and the one it shares a CU with streams 40 % faster than the others: imbalance), while FEWER riders
+// take longer (16: ~26 us, 32: ~22, 64: ~20, whatever the clip) -- so a long sweep carries few, a short one many.
+// Environment VC2_RIDERS overrides (experiments).
+inline int rider_parts_max(int64_t rows, int64_t row_bytes) {
+  static const int env = [] { const char* e = getenv("VC2_RIDERS"); return e ? atoi(e) : 0; }();
+  if (env > 0) return env;
+  const double sweep_us = double(rows) * double(row_bytes) / 6.5e6 + 4.0;      // ~6.5 TB/s + launch ramp
+  return sweep_us > 30.0 ? VC2_RIDER_PARTS_LONG : VC2_RIDER_PARTS;
+}
 __host__ inline int order_parts(int k, int max_parts) {        // a power of two
   int parts = 1;
   while (parts * 2 <= max_parts && parts * 2 <= (k - 1) / VC2_ORDER_MINSEG) parts *= 2;
@@ -1265,8 +1278,16 @@ constexpr float kS2QuotMinBf16 = 2.3509887016445750e-38f;  // 2^-125: products b
 constexpr float kS2NormLoF16 = 6.103515625e-05f;           // 2^-14: dn a normal fp16 number
 constexpr float kS2NormHiF16 = 32768.f;
 
+#ifndef VC2_S2_PROBE
+#define VC2_S2_PROBE 0       // timing probes (results invalid): 1 memory side only (DMA + LDS reads), 2 compute only (no DMA), 3 DMA only
+#endif
+#ifndef VC2_S2_WAVES
+#define VC2_S2_WAVES 2      // waves per SIMD the register allocation aims at (3: three workgroups per CU)
+#endif
+constexpr int kS2CombineRounds = VC2_S2_WAVES >= 3 ? 4 : 2;      // (3 workgroups per CU: 4 NCH + 2 NCH KiB of LDS each)
+__host__ inline size_t s2v2_lds(int nch) { return size_t(kRowWaves) * nch * 1024 + size_t(kRowWaves) * (4 * nch / kS2CombineRounds) * 64 * 8; }
 template <int DT, int NCH, int RIDER>
-__global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __restrict__ x, int N, const int* __restrict__ cols,
+__global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(const void* __restrict__ x, int N, const int* __restrict__ cols,
                                                                  int strict, int S, int q, int64_t R,
                                                                  float* __restrict__ den_out, double* __restrict__ part,
                                                                  int* __restrict__ tk, unsigned long long* __restrict__ fixq,
@@ -1288,9 +1309,32 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
   const int bid = int(blockIdx.x) - nrider;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t row_a = int64_t(bid) * q, row_b = min(R, row_a + q);
-  unsigned char* wbuf = smem + size_t(2 * wave) * ROWB;           // this wave's two row buffers
-  // LDS byte address (buffer 0) of the lane's elements: pair k = compact positions 128 k + 2 lane, + 1
+  // (rows fit 31 bits: the launch checks R < 2^31; 32-bit uniform arithmetic keeps the index math in a few SALU instructions)
+  const int Rr = int(R);
+  const int row_a = bid * q, row_b = min(Rr, row_a + q);
+  // LDS: [kRowWaves] row buffers (ONE per wave: the row is in registers before the next one is asked for), then the
+  // scratch of the cross-wave combine, [kRowWaves][NPLB / 2][64] doubles (= kRowWaves * ROWB bytes), used in two rounds
+  unsigned char* wbuf = smem + size_t(wave) * ROWB;
+  double* scratch = reinterpret_cast<double*>(smem + size_t(kRowWaves) * ROWB);        // [kRowWaves][NPLB / rounds][64]
+  const unsigned char* xl = static_cast<const unsigned char*>(x) + size_t(lane) * 16;
+  auto row_src = [&](int row) -> const unsigned char* { return xl + size_t(uint32_t(row)) * (size_t(D) * 2); };
+  // this wave's first row at or behind `sa`, the start of a segment of frame `fr` (the wave's rows in a segment [sa, sb)
+  // are sa + wave, + 4, ...); -1: none
+  auto first_row_from = [&](int sa, int fr) -> int {
+    while (sa < row_b) {
+      const int sb = min(row_b, (fr + 1) * N);
+      if (sa + wave < sb) return sa + wave;
+      sa = sb; ++fr;
+    }
+    return -1;
+  };
+  const int f_a = row_a / N;                                      // the chunk's first frame
+  // the wave's first row is on its way before anything else is fetched
+  {
+    const int first = first_row_from(row_a, f_a);
+    if (VC2_S2_PROBE != 2 && first >= 0) s2_issue_row<NCH>(row_src(first), wbuf);
+  }
+  // LDS byte address of the lane's elements: pair k = compact positions 128 k + 2 lane, + 1
   uint32_t addr[NPLB];
   {
     const uint32_t base = uint32_t(uintptr_t((lds_void_t*)wbuf));
@@ -1300,17 +1344,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
 #pragma unroll
     for (int k = 0; k < NP; ++k) { addr[2 * k] = base + uint32_t(t[k].x) * 2u; addr[2 * k + 1] = base + uint32_t(t[k].y) * 2u; }
   }
-  const unsigned char* xl = static_cast<const unsigned char*>(x) + size_t(lane) * 16;
   typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   const int margin_fast = kFragileUlpsNorm + acc_norm_ulps(NPLB);
 
-  for (int64_t seg_a = row_a; seg_a < row_b;) {
-    const int f = int(seg_a / N);
-    const int64_t seg_b = min(row_b, int64_t(f + 1) * N);
-    const int sp = bid - int((int64_t(f) * N) / q);
-    const int64_t r0 = seg_a + wave;                              // this wave's rows: r0 + 4 i, i < cnt
-    const int cnt = r0 < seg_b ? int((seg_b - r0 + kRowWaves - 1) / kRowWaves) : 0;
+  int f = f_a;
+  for (int seg_a = row_a; seg_a < row_b; ++f) {
+    const int seg_b = min(row_b, (f + 1) * N);
+    const int sp = bid - (f * N) / q;
+    const int r0 = seg_a + wave;                                  // this wave's rows: r0 + 4 i, i < cnt
+    const int cnt = r0 < seg_b ? (seg_b - r0 + kRowWaves - 1) / kRowWaves : 0;
     double acc[NPLB];
 #pragma unroll
     for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
@@ -1319,7 +1362,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
     uint32_t pk_meta = 0u;                                        // bit 0: norm next to a T rounding boundary, bit 1: exact division
     auto flush = [&](int first, int count) {                      // rows r0 + 4 (first + j), j < count
       const bool mine = lane < count;
-      const int64_t row = r0 + int64_t(kRowWaves) * (first + lane);
+      const int row = r0 + kRowWaves * (first + lane);
       if (mine) {
         den_out[row] = pk_dn;
         if (rflag) rflag[row] = uint8_t((pk_meta >> 1) & 1u);
@@ -1334,30 +1377,40 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
           __hip_atomic_store(fixq + j, fixq_pack(row, pk_dn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     };
-    auto row_src = [&](int i) -> const unsigned char* { return xl + size_t(r0 + int64_t(kRowWaves) * i) * (size_t(D) * 2); };
-    if (cnt > 0) s2_issue_row<NCH>(row_src(0), wbuf);
-    if (cnt > 1) s2_issue_row<NCH>(row_src(1), wbuf + ROWB);
-
-    auto step = [&](auto par_tag, int i) {
-      constexpr int PAR = decltype(par_tag)::value;
-      s2_wait_row<NCH>(i + 1 < cnt);
+    for (int i = 0; i < cnt; ++i) {
+      if (VC2_S2_PROBE != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VC2_DEBUG_TIMING
+      if (i == 0 && seg_a == row_a) VC2_WGTIME(4, 0);
+#endif
       // (gfx950 runs with SRAM ECC: a d16 load ZEROES the other half of its register instead of keeping it, so a pair
       // cannot be assembled by two loads -- but a bf16 element loaded into the HIGH half IS its fp32 value: no unpack)
       float XA[NP], XB[NP];                                       // the lane's pairs as fp32 values
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
+        if (VC2_S2_PROBE == 3) { XA[k] = 1.f; XB[k] = 1.f; continue; }
         if constexpr (DT == VC2_BF16) {
-          asm volatile("ds_read_u16_d16_hi %0, %2 offset:%4\n\tds_read_u16_d16_hi %1, %3 offset:%4"
-                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]), "n"(PAR * ROWB) : "memory");
+          asm volatile("ds_read_u16_d16_hi %0, %2\n\tds_read_u16_d16_hi %1, %3"
+                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]) : "memory");
         } else {
-          asm volatile("ds_read_u16 %0, %2 offset:%4\n\tds_read_u16 %1, %3 offset:%4"
-                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]), "n"(PAR * ROWB) : "memory");
+          asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3"
+                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]) : "memory");
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(XA[k]), "+v"(XB[k]));   // (the loads' results: not before the wait)
-      if (i + 2 < cnt) s2_issue_row<NCH>(row_src(i + 2), wbuf + PAR * ROWB);
+      // the row is in registers: its buffer takes the wave's NEXT row (of this segment, else of a later one) right away
+      if (VC2_S2_PROBE != 2) {
+        const int nr = i + 1 < cnt ? r0 + kRowWaves * (i + 1) : first_row_from(seg_b, f + 1);
+        if (nr >= 0) s2_issue_row<NCH>(row_src(nr), wbuf);
+      }
+      if (VC2_S2_PROBE == 1 || VC2_S2_PROBE == 3) {               // (keep the loads alive, skip the arithmetic)
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) t += XA[k] + XB[k];
+        if (t == 12345.678f) pk_dn = t;
+        continue;
+      }
       if constexpr (DT == VC2_F16) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -1366,8 +1419,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
           XA[k] = float(ca.h); XB[k] = float(cb.h);
         }
       }
-      // ---- the fast path: sum of squares as exact products in two fp32 chains (the bound of acc_norm_ulps) ---------
-      f2_t s2 = {0.f, 0.f}, s3 = {0.f, 0.f};                        // (four independent chains of NP / 2 roundings each)
+      // ---- the fast path: sum of squares as exact products in four fp32 chains (the bound of acc_norm_ulps) --------
+      f2_t s2 = {0.f, 0.f}, s3 = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < NP; k += 2) {
         s2 = pk_fma_f32((f2_t){XA[k], XB[k]}, (f2_t){XA[k], XB[k]}, s2);
@@ -1427,12 +1480,15 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
         meta = (strict == 2 || near_T_boundary<DT>(nrm32, margin_fast)) ? 1u : 0u;
       } else {
         // ---- the row as the general kernel does it (rare) ------------------------------------------------------
+        // (one pair at a time -- the empty asm statements pin the order: left to its own devices the scheduler starts all
+        // 4 NCH conversions at once and this rare path becomes the kernel's register peak)
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
           const double a = double(XA[k]), b = double(XB[k]);
           t = fma(a, a, t);
           t = fma(b, b, t);
+          if (k + 1 < NP) asm volatile("" : "+v"(XA[k + 1]), "+v"(XB[k + 1]), "+v"(t));
         }
         const float n32 = float(sqrt(wave_sum_bcast(t)));
         const float norm = rnT<DT>(n32);
@@ -1445,32 +1501,38 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum2(const void* __r
           const double vb = double(rnT<DT>(div_via_f64(XB[k], inv)));
           asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc[2 * k]) : "v"(va));     // (asm: keeps the two paths' adds apart --
           asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc[2 * k + 1]) : "v"(vb)); //  merged, they cost 4 NCH register pairs)
+          if (k + 1 < NP) asm volatile("" : "+v"(XA[k + 1]), "+v"(XB[k + 1]));
         }
         meta = ((strict == 2 || near_T_boundary<DT>(n32, kFragileUlpsNorm)) ? 1u : 0u) | 2u;
       }
       if (lane == (i & 63)) { pk_dn = dn; pk_meta = meta; }
       if ((i & 63) == 63) flush(i - 63, 64);
-    };
-    for (int i = 0; i < cnt; i += 2) {
-      step(std::integral_constant<int, 0>{}, i);
-      if (i + 1 < cnt) step(std::integral_constant<int, 1>{}, i + 1);
     }
     if (cnt & 63) flush(cnt & ~63, cnt & 63);
-    // combine the 4 waves' column sums in wave order (fixed order) through LDS (the row buffers are free now)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    double* sacc = reinterpret_cast<double*>(smem);                // [kRowWaves][C] doubles
+#ifdef VC2_DEBUG_TIMING
+    if (seg_b == row_b) VC2_WGTIME(4, 1);
+#endif
+    // Combine the 4 waves' column sums in wave order (fixed order) through the scratch area, 1 / NR of the lane's sums per
+    // round; the row buffers are not touched -- the waves' next rows (of the next segment) are landing in them meanwhile.
+    constexpr int NR = kS2CombineRounds, PER = NPLB / NR;
+    static_assert(NPLB % NR == 0, "combine rounds");
 #pragma unroll
-    for (int i = 0; i < NPLB; ++i) sacc[wave * C + compact_pos<1>(i, lane)] = acc[i];
-    __syncthreads();
-    for (int p = tid; p < C; p += kRowWaves * 64) {
-      double t = sacc[p];
+    for (int h = 0; h < NR; ++h) {
+      if (h) __syncthreads();
 #pragma unroll
-      for (int w = 1; w < kRowWaves; ++w) t += sacc[w * C + p];
-      part[(int64_t(f) * S + sp) * C + p] = t;
+      for (int i = 0; i < PER; ++i) scratch[(wave * PER + i) * 64 + lane] = acc[h * PER + i];
+      __syncthreads();
+      // scratch[w][i][l] = wave w's sum of the lane-l compact position of slot h PER + i
+      for (int t = tid; t < PER * 64; t += kRowWaves * 64) {
+        const int i = t >> 6, l = t & 63;
+        double v = scratch[t];
+#pragma unroll
+        for (int w = 1; w < kRowWaves; ++w) v += scratch[w * PER * 64 + t];
+        part[size_t(uint32_t(f * S + sp)) * C + compact_pos<1>(h * PER + i, l)] = v;
+      }
     }
     seg_a = seg_b;
-    if (seg_a < row_b) __syncthreads();                            // (the next segment refills the row buffers)
+    if (seg_a < row_b) __syncthreads();                            // (the next segment's combine reuses the scratch)
   }
   VC2_WGTIME(1, 1);
 }
@@ -3323,7 +3385,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   // workgroup lives for the whole sweep.  The ORDER riders ("torch order" mode, 16-bit inputs) are workgroups of the
   // same launch, so the splits are chosen to leave them slots -- with 512 + 16 workgroups the last 16 start when the
   // riders end and the sweep takes 51 instead of 36 us; with 384 + 16 it takes 41.
-  const int64_t riders = (cur_mode() && dt != VC2_F32) ? VC2_RIDER_PARTS : 0;
+  const int64_t riders = (cur_mode() && dt != VC2_F32) ? rider_parts_max(p->R, D * p->ES) : 0;
   // S is chosen from THIS rank's frames (occupancy), not from the whole video's: the frame sums are fp64 sums of
   // T-rounded x^ in [-1, 1] -- exact (so independent of how the rows are cut) for fp16 by range (2^-24 .. 1, <= 8192
   // rows: 48 bits), and for bf16 unless a nonzero |x^| < 2^-39 meets a frame sum > 2^6
@@ -3332,7 +3394,11 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
     // frame-aligned cut was 4 x 49 rows for half of the frames and 3 x 66 for the others -- the sweep took as long as
     // the 66-row workgroups (36 us against 25 for the others: scripts/dbg_wg.py).  A chunk that contains a frame
     // boundary is swept segment by segment (one flush of the column sums per segment).
-    const int64_t budget = 512 - riders;
+    // (the streamlined sweep built for three workgroups per CU -- VC2_S2_WAVES = 3 -- has 768 slots: 512 streaming
+    // workgroups AND the riders are resident together; decided from what the plan knows, shape and mode)
+    static const int env_budget = [] { const char* e = getenv("VC2_S2_BUDGET"); return e ? atoi(e) : 0; }();
+    const bool three = VC2_S2_WAVES >= 3 && cur_mode() != 0 && dt != VC2_F32 && (D == 1024 || D == 3584 || D == 4096);
+    const int64_t budget = env_budget > 0 ? env_budget : (three ? 512 : 512 - riders);
     int64_t W = std::max<int64_t>(1, std::min<int64_t>(budget, p->R / (8 * kRowWaves)));   // >= 32 rows a chunk
     int64_t q = std::max<int64_t>(cdiv(p->R, W), cdiv(N, 6));          // (a frame meets at most (N - 1) / q + 2 <= 8 chunks)
     p->S_q = int(q);
@@ -3588,13 +3654,13 @@ inline bool s2v2_on() {
 }
 inline int s2v2_nch(const Plan& p, const ChanSet& cs) {
   if (!s2v2_on() || p.dt == VC2_F32 || p.VEC == 1 || !cs.cols || !fast_acc(p, cs)) return 0;
-  if (p.D % 512 != 0 || int64_t(cs.C) * 2 != p.D) return 0;
+  if (p.D % 512 != 0 || int64_t(cs.C) * 2 != p.D || p.R >= (int64_t(1) << 31) || p.F * int64_t(p.S) >= (int64_t(1) << 31) / 8) return 0;
   const int nch = int(p.D / 512);
   return (nch == 2 || nch == 7 || nch == 8) ? nch : 0;
 }
 template <int DT, int NCH>
 int launch_norm_v2(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
-  size_t smem = size_t(2) * kRowWaves * NCH * 1024;                                // row buffers, then the combine (same size)
+  size_t smem = s2v2_lds(NCH);                                                     // row buffers + the combine's scratch
   if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
   int rc = allow_big_lds(&k_norm_colsum2<DT, NCH, 1>, smem, "k_norm_colsum2");
   if (rc) return rc;
@@ -3690,7 +3756,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
     if (rc) return rc;
     ride = OrderArgs{};
   }
-  if (ride.perm) ride.parts = order_parts(ride.k, VC2_RIDER_PARTS);
+  if (ride.perm) ride.parts = order_parts(ride.k, rider_parts_max(p.R, p.D * p.ES));
 #ifdef VC2_RIDER_PROBE
   if (ride.perm) { const char* e = getenv("VC2_RIDER_PROBE_MODE"); if (e) ride.parts |= atoi(e) << 8; }
 #endif
@@ -4507,9 +4573,9 @@ int vc2_debug_set(int key, int value) {
 }
 #endif
 #ifdef VC2_DEBUG_TIMING
-int vc2_debug_wg(unsigned long long* out /*[4][2][4096]*/) {
+int vc2_debug_wg(unsigned long long* out /*[6][2][4096]*/) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 4 * 2 * 4096);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 6 * 2 * 4096);
   return 0;
 }
 int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {

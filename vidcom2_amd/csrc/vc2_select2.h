@@ -546,12 +546,12 @@ __device__ __forceinline__ void topk_smallest2(const Sel2<W>& S, int n, int k, i
 // and the insertion uses a strict compare); because everything left of a leaf is <= and everything right of it is
 // >= its elements, the final position of element p is p + #{q in (p, p+16): key_q < key_p} - #{q in (p-16, p):
 // key_q > key_p} -- no leaf bookkeeping at all.
-// Slices: a partition's two sides are independent, so R = 2^L workgroups replay the same sort side by side.
-// Workgroup r first walks L levels down the partition tree -- at level l it partitions the segment it stands on
-// (the same input as everybody else on that segment, so the same result) and steps to the left or right part by
-// bit L-1-l of r -- and then sorts, ranks and stores the segment it arrived at.  The 2^L arrival segments tile
-// [0, n): no position is answered twice, none is left out.  (A segment that is already a leaf above level L goes to
-// the workgroup whose remaining bits are zero.)
+// Slices: a partition's two sides are independent, so R workgroups replay the same sort side by side.  The workgroups
+// [lo, hi) that stand on a segment all partition it (the same input as everybody else on that segment, so the same
+// result) and then split in proportion to the two sides' lengths -- the first round(g * left / total) of them (at least
+// one, at most g - 1) step left, the others right -- until a workgroup stands alone: that is the segment it sorts, ranks
+// and stores.  The R arrival segments tile [0, n): no position is answered twice, none is left out.  (A segment that is
+// already a leaf while several workgroups stand on it goes to the first of them.)
 // out(p, i): original index i stands at sorted position p (called for the positions of the arrival segment).
 constexpr int kSortOwnCap = 512;         // a wave's own segments (every segment > 16: at most n / 17 = 481 in all)
 struct SortScratch2 {
@@ -569,7 +569,7 @@ __device__ __forceinline__ uint32_t seg_pack(int first, int last, int depth) {
 
 template <typename W, int NW, int SOLO, int COOP, typename OUT>
 __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2& Q, int n, OUT out, int tid,
-                                           int part = 0, int levels = 0) {
+                                           int part = 0, int nparts = 1) {
   using T = WordTr<W>;
   constexpr int NT = 64 * NW;
   constexpr int kCoopMin = NW > 1 ? 64 : 0x7FFFFFFF;            // longer segments: all waves together
@@ -605,18 +605,24 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
       deal(sg);
     }
   };
-  // walk down to my arrival segment [ta, tb)
+  // Walk down to my arrival segment [ta, tb).  Workgroups [lo, hi) are on the segment [first, last) together; after its
+  // partition (repeated by all of them: same input, same cut) they split IN PROPORTION to the two sides -- round 5; with
+  // one bit of `part` per level (rounds 3-4) the arrival segments were products of six random split ratios, 3 .. 200
+  // positions where the mean is 28, and the slowest rider took twice the median's time.
   int ta = 0, tb = n;
   {
     int first = 0, last = n, depth = n > 1 ? 2 * (31 - __clz(n)) : 0;
+    int lo = 0, hi = nparts > 1 ? nparts : 1;
     bool mine_ = true;
-    for (int l = 0; l < levels && mine_; ++l) {
-      const int rest = part & ((1 << (levels - l)) - 1);          // my bits from this level on
-      if (last - first <= 16 || depth == 0) { mine_ = rest == 0; break; }   // a leaf (or a heapsort segment): one owner
+    while (hi - lo > 1) {
+      if (last - first <= 16 || depth == 0) { mine_ = part == lo; break; }   // a leaf (or a heapsort segment): one owner
       int cut;
       if constexpr (NW > 1) cut = sel2_partition<W, NW, 0, COOP>(S, first, last, S.la + first, S.lb + first, tid);
       else cut = sel2_partition<W, 1, 0, SOLO>(S, first, last, S.la + first, S.lb + first, lane);
-      if ((rest >> (levels - l - 1)) & 1) first = cut; else last = cut;
+      const int g = hi - lo, nl = cut - first, nt = last - first;
+      int m = (2 * g * nl + nt) / (2 * nt);                       // round(g * nl / nt), at least one owner per side
+      m = m < 1 ? 1 : (m > g - 1 ? g - 1 : m);
+      if (part < lo + m) { hi = lo + m; last = cut; } else { lo += m; first = cut; }
       --depth;
     }
     if (mine_) { ta = first; tb = last; if (last - first > 16) push_uniform(first, last, depth); }
