@@ -12,11 +12,11 @@ F, N, D = 128, 196, 3584
 x = synth.make(F, N, D, torch.bfloat16, 0, sys.argv[2] if len(sys.argv) > 2 else "drift").cuda()
 plan = vc.vidcom2.CompressPlan(F, N, D, torch.bfloat16, x.device, 0.25)
 L = ctypes.CDLL(_ffi.LIB_PATH)
-buf = (ctypes.c_ulonglong * (4 * 2 * 4096))()
+buf = (ctypes.c_ulonglong * (8 * 2 * 4096))()
 for it in range(5):
     plan.enqueue(x); plan.finish()
 L.vc2_debug_wg(buf)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(4, 2, 4096).astype(np.float64) / 100.0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(8, 2, 4096).astype(np.float64) / 100.0
 for slot, name in ((1, "k_norm_colsum"), (2, "k_dist")):
     b, e = a[slot, 0], a[slot, 1]
     m = e > 0

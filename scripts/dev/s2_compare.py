@@ -21,7 +21,7 @@ o_den, o_part, o_rflag, o_tk, o_fixq, S, S_q, S_W, o_fc, o_vc, o_total = [int(v)
 C = D // 2
 res = {}
 for v2 in (0, 1):
-    L.vc2_debug_set(0, v2)
+    L.vc2_debug_set(0, v2); L.vc2_debug_set(1, v2)
     plan = vc.vidcom2.CompressPlan(F, N, D, dt, x.device, 0.25)
     plan.enqueue(x); plan.finish(); torch.cuda.synchronize()
     ws = plan.ws.view(torch.uint8)

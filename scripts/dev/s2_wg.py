@@ -12,12 +12,12 @@ F, N, D = int(sys.argv[2]) if len(sys.argv) > 2 else 128, 196, 3584
 x = synth.make(F, N, D, torch.bfloat16, 0, "drift").cuda()
 plan = vc.vidcom2.CompressPlan(F, N, D, torch.bfloat16, x.device, 0.25)
 L = ctypes.CDLL(_ffi.LIB_PATH)
-buf = (ctypes.c_ulonglong * (6 * 2 * 4096))()
+buf = (ctypes.c_ulonglong * (8 * 2 * 4096))()
 for it in range(8):
     plan.enqueue(x); plan.finish()
 torch.cuda.synchronize()
 L.vc2_debug_wg(buf)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(6, 2, 4096).astype(np.float64) / 100.0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(8, 2, 4096).astype(np.float64) / 100.0
 b, e, first, loop = a[1, 0], a[1, 1], a[4, 0], a[4, 1]
 m = e > 0
 t0 = b[m].min()

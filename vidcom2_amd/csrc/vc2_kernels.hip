@@ -62,7 +62,7 @@ __device__ __forceinline__ void dbg_stamp(int tag) {      // (one lane) wall clo
 }
 #define VC2_STAMP(tag) dbg_stamp(tag)
 // per-workgroup begin / end times of the three sweeps (slot 0: k_chan_stats, 1: k_norm_colsum, 2: k_dist)
-namespace vc2 { __device__ unsigned long long g_dbg_wg[6][2][4096]; }     // (slots 4, 5: sweep 2's first row landed / row loops over, combine done)
+namespace vc2 { __device__ unsigned long long g_dbg_wg[8][2][4096]; }     // (slots 4, 5: sweep 2's first row landed / row loops over, combine done)
 #define VC2_WGTIME(slot, which) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_wg[slot][which][blockIdx.x] = wall_clock64(); } while (0)
 #else
 #define VC2_STAMP(tag) ((void)0)
@@ -1788,12 +1788,16 @@ __device__ __forceinline__ bool frame_mean_near(float q, bool bounded, bool all,
 // workgroup's acquire empties its XCD's L2.)
 struct FixRiders {
   int fy;                                   // grid rows of rider workgroups (0: none -- k_norm_fix ran before this launch)
+  int waves;                                // waves of a rider workgroup that take queue entries (the others leave at once)
   int CV, max_entries;
   const int* nfix_count; const unsigned long long* fixq;
   int* corr_count; NormCorr* corr; float* den;
   FixPush push;
 };
-constexpr int kFixWaves = 4;
+#ifndef VC2_FIX_WAVES_DEFAULT
+#define VC2_FIX_WAVES_DEFAULT 8      // (8 = two chains per SIMD: a fp16 norm replay is ONE sequential 2048-step chain)
+#endif
+constexpr int kFixWaves = VC2_FIX_WAVES_DEFAULT;               // (default; FixRiders::waves)
 constexpr int kTkFixEntries = 8;             // ticket word: correction entries of the pass (FixPush)
 
 template <int DT, int VEC, int NPLB>        // NPLB = 0: no rider code compiled in
@@ -1822,11 +1826,14 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       constexpr int ES = Tr<DT>::ES;
       const size_t rowb = row_lds_bytes(D, ES);
       const size_t stride = (std::max(rowb, size_t(C) * 4 + 16) + 15) / 16 * 16;
-      if (wave >= kFixWaves) return;
+      if (wave >= fr.waves) return;
       const int cnt = min(*fr.nfix_count, fr.max_entries);
-      const int nslots = fy * int(gridDim.x) * kFixWaves;
-      const int first = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kFixWaves + wave;
+      const int nslots = fy * int(gridDim.x) * fr.waves;
+      const int first = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * fr.waves + wave;
       if (first >= cnt) return;
+#ifdef VC2_DEBUG_TIMING
+      if (lane == 0 && first < 4096) g_dbg_wg[5][0][first] = wall_clock64();
+#endif
       unsigned char* buf0 = fix_rows + size_t(wave) * stride;
       if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
       unsigned long long q = fr.fixq[first];
@@ -1838,9 +1845,15 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
         fx.row(buf0, rowb, int64_t(uint32_t(q)) - 1, __uint_as_float(uint32_t(q >> 32)), C, N, fr.den, fr.corr_count, fr.corr,
                fr.max_entries, lane, fr.push);
       }
+#ifdef VC2_DEBUG_TIMING
+      if (lane == 0 && first < 4096) g_dbg_wg[5][1][first] = wall_clock64();
+#endif
       return;
     }
   }
+#ifdef VC2_DEBUG_TIMING
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == fy) g_dbg_wg[5][0][4095] = wall_clock64();     // (a frame workgroup's begin: the launch's clock zero)
+#endif
   const int c = blockIdx.x * 64 + cl;
   const int g = int(blockIdx.y) - fy;
   const int FGn = int(gridDim.y) - fy;                           // frame groups of this launch
@@ -2062,6 +2075,15 @@ __global__ __launch_bounds__(64) void k_frame_replay(FrameReplay r, const void* 
 // strided column at ~50 GB/s, 25088 rows would take it ~35 us -- which leave them in l1g[column][group]; the last
 // wave to arrive (agent-scope release / acquire around the block's ticket) finishes the cascade and stores the
 // replayed mean.  replay_rows = 0 (frame-sharded pass): the flagged columns are only counted (fragile_count).
+__host__ __device__ inline int64_t cascade_l1_groups(int64_t n) {
+  const int lp = cascade_lp(n);
+  return (((n >> lp) + (int64_t(1) << lp) - 1) >> lp);
+}
+__host__ inline size_t vc_lds_bytes(int64_t R, int64_t N) {      // k_video_centre: main waves hold a column's level-1 groups,
+  const int64_t main_f = std::min<int64_t>(kL1Cap, std::max(cascade_l1_groups(R), cascade_l1_groups(R >> 2)));   // riders a frame's
+  const int64_t rider_f = N <= kCFixSolo ? N : std::max(cascade_l1_groups(N), cascade_l1_groups(N >> 2));           // values / groups
+  return size_t(std::max<int64_t>(std::max(main_f, rider_f), 64) + 4) * 4;
+}
 template <int DT>
 __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ parts, int NP, int64_t stride, int C,
                                                       int64_t R, float* __restrict__ vc, const void* __restrict__ x,
@@ -2074,15 +2096,29 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
                                                       FrameReplay frp = FrameReplay{}, int Ymain = 0,
                                                       const int* __restrict__ vcorr_count = nullptr,
                                                       const NormCorr* __restrict__ vcorr = nullptr) {
-  __shared__ float l1s[kL1Cap + 4];                  // level-1 groups of one column
+  // level-1 groups of one column / a rider's frame chain: vc_lds_bytes(R, N) of dynamic LDS.  (Round 5: this was a static
+  // float[kL1Cap + 4] -- 32 KiB for every 64-thread workgroup, i.e. FIVE waves per CU: with 700 main + 1024 rider waves
+  // in the launch the riders only started when main waves ended, and fp16's ~4000 replays queued for 30 us.)
+  extern __shared__ __attribute__((aligned(16))) float l1s[];
   // grid rows [Ymain, gridDim.y) (Ymain > 0) are RIDER waves: they replay the boundary-near frame means k_frame_centres
   // listed -- work that is independent of the video centre and hides under this kernel's own latency chain
   const int lane = threadIdx.x, bx = blockIdx.x, y = blockIdx.y, Y = Ymain > 0 ? Ymain : int(gridDim.y);
   if (y >= Y) {
+#ifdef VC2_DEBUG_TIMING
+    const int rid_ = (y - Y) * int(gridDim.x) + bx;
+    if (lane == 0 && rid_ < 4096) g_dbg_wg[6][0][rid_] = wall_clock64();
+#endif
     frame_replay_wave<DT>(frp, (y - Y) * int(gridDim.x) + bx, (int(gridDim.y) - Y) * int(gridDim.x), l1s, x, D, C, cols, spos,
                           den, lane);
+#ifdef VC2_DEBUG_TIMING
+    if (lane == 0 && rid_ < 4096) g_dbg_wg[6][1][rid_] = wall_clock64();
+#endif
     return;
   }
+#ifdef VC2_DEBUG_TIMING
+  struct EndStamp { int i; __device__ ~EndStamp() { if (threadIdx.x == 0 && i < 4096) g_dbg_wg[7][1][i] = wall_clock64(); } } end_stamp_{bx * Y + y};
+  if (lane == 0 && bx * Y + y < 4096) g_dbg_wg[7][0][bx * Y + y] = wall_clock64();
+#endif
   const bool replay = strict != 0 && DT != VC2_F32;
   const bool all = strict == 2;
   const int c = bx * 64 + lane;
@@ -2442,8 +2478,17 @@ __host__ __device__ inline int dist_split_cut(int j, int S, int N, int skew_q10)
   return int((num + den / 2) / den);
 }
 
-template <int DT, int VEC, int NPLB, int ACC, int QUAD = 0>
-__global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
+// V2 = 1 ("streamlined", round 5; 16-bit rows of full 1 KiB chunks, C = 64 NPLB = D / 2, ACC = 1, QUAD tables): the row
+// loop of k_norm_colsum2 -- the row's elements are read into registers first (bf16 with ds_read_u16_d16_hi: the element
+// arrives as its fp32 value), the wave's NEXT row is DMA'd into the same buffer at once and lands while this one is
+// computed; LDS addresses are per-lane constants; the rows' denominators / exact-division flags are parked in lanes (no LDS
+// access in the loop: the compiler would put a vmcnt(0) in front of it); the first row's DMA is issued before the tables
+// are fetched.  fp16 divides by the fused-multiply-add quotient proved in tests/tools/check_f16_quotient.c.
+#ifndef VC2_S3_WAVES
+#define VC2_S3_WAVES 3      // (at 4 the streamlined loop spills inside the row loop)
+#endif
+template <int DT, int VEC, int NPLB, int ACC, int QUAD = 0, int V2 = 0>
+__global__ __launch_bounds__(kRowWaves * 64, V2 ? VC2_S3_WAVES : 1) void k_dist(const void* __restrict__ x, int N, int D, int CV, int C,
                                                          const int* __restrict__ cols,
                                                          const int* __restrict__ spos, int strict, int S,
                                                          int rows_per_split, int skew_q10, const float* __restrict__ den,
@@ -2481,12 +2526,30 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   int n = n0 + wave;
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) VC2_STAMP(700);
   VC2_WGTIME(2, 0);
+  static_assert(V2 == 0 || (QUAD != 0 && ACC == 1 && VEC > 1 && DT != VC2_F32 && NPLB % 4 == 0), "streamlined sweep 3");
+  constexpr int NCH2 = NPLB / 4;                                    // (V2) 1 KiB chunks per row
+  const unsigned char* xl2 = static_cast<const unsigned char*>(x) + (size_t(f) * N + n) * (size_t(D) * ES) + size_t(lane) * 16;   // (V2) the wave's first row, this lane's 16 bytes
+  const int cnt2 = wave < nrows ? (nrows - wave + kRowWaves - 1) / kRowWaves : 0;                    // (V2) the wave's rows
+  float my_dn = 1.f;                                                // (V2) lane j: the wave's row j
+  uint32_t my_rf = 1u;
+  if constexpr (V2 != 0) {
+    if (cnt2 > 0) s2_issue_row<NCH2>(xl2, buf0);
+    if (lane < cnt2) {
+      const int64_t row = int64_t(f) * N + n + kRowWaves * lane;
+      my_dn = den[row];
+      my_rf = rflag ? uint32_t(rflag[row]) : 1u;
+    }
+  }
+  if constexpr (V2 == 0) {
   if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
   if (tid < 2) lcount[tid] = 0;
   for (int r = tid; r < nrows; r += kRowWaves * 64) {
     dens[r] = den[int64_t(f) * N + n0 + r];
     rfl[r] = (kFast && rflag) ? rflag[int64_t(f) * N + n0 + r] : 1;
   }
+  }
+  float den_mine = 0.f;                                             // (V2) dens[tid], stored to LDS behind the table loads
+  if constexpr (V2 != 0) { if (tid < nrows) den_mine = den[int64_t(f) * N + n0 + tid]; }
   int coff[NPLB];
   float cv[NPLB], cf[NPLB];                                       // video / frame centre of the lane's compact positions
   // QUAD (ACC = 1 only: any ownership of the compact positions gives the same bits there -- the accumulation is bounded,
@@ -2559,7 +2622,12 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   }
   // (plain loads first: behind an in-flight global_load_lds the compiler waits for EVERY load separately)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (V2 != 0) {
+    if (tid < 2) lcount[tid] = 0;
+    if (tid < nrows) dens[tid] = den_mine;                          // (phase 2 reads them; nrows <= kDistMaxRows <= 256)
+  } else {
   if (n < n1) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
+  }
   __syncthreads();
   // ---- phase 1 ---------------------------------------------------------------------------------------
   // The rows' results stay in registers (lane `it` holds row it of this wave) until the loop is over: the compiler
@@ -2578,6 +2646,110 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
   };
   float held_v = 0.f, held_f = 0.f;                               // (fast path) the previous row's lane partials
   int it = 0;
+  if constexpr (V2 != 0) {
+    constexpr int NP = NPLB / 2;
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    uint32_t addr[NPLB];                                            // LDS byte address of the lane's elements
+    {
+      const uint32_t base = uint32_t(uintptr_t((lds_void_t*)buf0));
+#pragma unroll
+      for (int i = 0; i < NPLB; ++i) addr[i] = base + uint32_t(coff[i]) * uint32_t(ES);
+    }
+    // fp16: the centres as packed pairs
+    uint32_t cvp[DT == VC2_F16 ? NP : 1], cfp[DT == VC2_F16 ? NP : 1];
+    if constexpr (DT == VC2_F16) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        union { h2_t h; uint32_t u; } a, b;
+        a.h = __builtin_convertvector((f2_t){cv[2 * k], cv[2 * k + 1]}, h2_t);
+        b.h = __builtin_convertvector((f2_t){cf[2 * k], cf[2 * k + 1]}, h2_t);
+        cvp[k] = a.u; cfp[k] = b.u;
+      }
+    }
+    const size_t row_step = size_t(kRowWaves) * size_t(D) * ES;
+    for (; it < cnt2; ++it) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      float XA[NP], XB[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if constexpr (DT == VC2_BF16)
+          asm volatile("ds_read_u16_d16_hi %0, %2\n\tds_read_u16_d16_hi %1, %3"
+                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]) : "memory");
+        else
+          asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3"
+                       : "=&v"(XA[k]), "=&v"(XB[k]) : "v"(addr[2 * k]), "v"(addr[2 * k + 1]) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(XA[k]), "+v"(XB[k]));
+      if (it + 1 < cnt2) s2_issue_row<NCH2>(xl2 + size_t(it + 1) * row_step, buf0);
+      const float dn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dn), it));
+      const bool exact_div = __builtin_amdgcn_readlane(int(my_rf), it) != 0;
+      float pv = 0.f, pf = 0.f;
+      if constexpr (DT == VC2_BF16) {
+        using AR = DistArith<VC2_BF16, 1>;
+        auto body = [&](auto exact_tag) {
+          constexpr bool kExact = decltype(exact_tag)::value;
+          const double inv = kExact ? 1.0 / double(dn) : 0.0;
+          const float r = kExact ? 0.f : __builtin_amdgcn_rcpf(dn);
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            uint32_t xh;
+            if constexpr (kExact) xh = AR::pk(div_via_f64(XA[k], inv), div_via_f64(XB[k], inv));
+            else { const f2_t pr = pk_mul_f32((f2_t){XA[k], XB[k]}, (f2_t){r, r}); xh = AR::pk(pr.x, pr.y); }
+            const float xa = __uint_as_float(xh << 16), xb = __uint_as_float(xh & 0xFFFF0000u);
+            const uint32_t dv = AR::pk(xa - cv[2 * k], xb - cv[2 * k + 1]);
+            const uint32_t df = AR::pk(xa - cf[2 * k], xb - cf[2 * k + 1]);
+            const float va = __uint_as_float(dv << 16), vb = __uint_as_float(dv & 0xFFFF0000u);
+            const float fa = __uint_as_float(df << 16), fb = __uint_as_float(df & 0xFFFF0000u);
+            pv = AR::dot_ones(AR::pk(va * va, vb * vb), pv);
+            pf = AR::dot_ones(AR::pk(fa * fa, fb * fb), pf);
+          }
+        };
+        if (exact_div) body(std::true_type{}); else body(std::false_type{});
+      } else {
+        const h2_t ones = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
+        auto body = [&](auto exact_tag) {
+          constexpr bool kExact = decltype(exact_tag)::value;
+          const double inv = kExact ? 1.0 / double(dn) : 0.0;
+          const float r = kExact ? 0.f : __builtin_amdgcn_rcpf(dn);
+          const f2_t r2 = {r, r}, d2 = {dn, dn};
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            union { uint16_t u; _Float16 h; } ca, cb;
+            ca.u = uint16_t(__float_as_uint(XA[k])); cb.u = uint16_t(__float_as_uint(XB[k]));
+            const f2_t xx = {float(ca.h), float(cb.h)};
+            h2_t xh;
+            if constexpr (kExact) xh = __builtin_convertvector((f2_t){div_via_f64(xx.x, inv), div_via_f64(xx.y, inv)}, h2_t);
+            else {
+              const f2_t q0 = pk_mul_f32(xx, r2);
+              const f2_t e = pk_fnma_f32(d2, q0, xx);
+              xh = __builtin_convertvector(pk_fma_f32(e, r2, q0), h2_t);
+            }
+            union { uint32_t u; h2_t h; } a, b;
+            a.u = cvp[k]; b.u = cfp[k];
+            const h2_t dv = xh - a.h, df = xh - b.h;
+            pv = __builtin_amdgcn_fdot2(dv * dv, ones, pv, false);
+            pf = __builtin_amdgcn_fdot2(df * df, ones, pf, false);
+          }
+        };
+        if (exact_div) body(std::true_type{}); else body(std::false_type{});
+      }
+      // two rows' lane partials are reduced together (four values: one permlane32 / permlane16 fold each)
+      if (it & 1) {
+        float q[4] = {held_v, held_f, pv, pf};
+        wave_totals_f32<4>(q);
+        auto at = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[0]), l)); };
+        const float t0 = at(0), t2 = at(16), t1 = at(32), t3 = at(48);
+        settle(t0, t1, it - 1);
+        settle(t2, t3, it);
+      } else {
+        held_v = pv; held_f = pf;
+      }
+    }
+    if (it & 1) settle(wave_sum_bcast_f32(held_v), wave_sum_bcast_f32(held_f), it - 1);   // the odd row out
+  } else
   for (; n < n1; n += kRowWaves, ++it) {
     // issue the row's DMA, wait, compute straight from LDS
     if (it) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
@@ -2656,7 +2828,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_dist(const void* __restrict_
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // LDS reads done before the buffer is refilled
   }
-  if constexpr (kFast) {
+  if constexpr (kFast && V2 == 0) {
     if (it & 1) settle(wave_sum_bcast_f32(held_v), wave_sum_bcast_f32(held_f), it - 1);   // the odd row out
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3415,6 +3587,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
 #define VC2_DIST_RPS_MIN 16
 #endif
     int64_t rps = std::max<int64_t>(VC2_DIST_RPS_MIN, std::min<int64_t>(25, cdiv(p->R, VC2_DIST_WGS)));
+    static const int env_rps = [] { const char* e = getenv("VC2_DIST_RPS"); return e ? atoi(e) : 0; }();   // (experiments)
+    if (env_rps > 0) rps = std::min<int64_t>(env_rps, kDistMaxRows);
     rps = std::min<int64_t>(rps, N);
     p->S2 = int(cdiv(N, rps));
 #ifndef VC2_DIST_SKEW
@@ -3422,7 +3596,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
 #endif
     // the skew pays when the launch is ONE wave of workgroups with several of them per CU (4 at 1024 on 256 CUs)
     const int64_t wgs = F * p->S2;
-    p->skew2_q10 = (p->S2 >= 4 && wgs > 512 && wgs <= 1024) ? int(VC2_DIST_SKEW * (wgs - 256) / 768) : 0;
+    static const int env_skew = [] { const char* e = getenv("VC2_DIST_SKEW_Q10"); return e ? atoi(e) : -1; }();
+    p->skew2_q10 = env_skew >= 0 ? env_skew : (p->S2 >= 4 && wgs > 512 && wgs <= 1024) ? int(VC2_DIST_SKEW * (wgs - 256) / 768) : 0;
     p->rows_per_split2 = dist_split_cut(1, p->S2, int(N), p->skew2_q10);          // the longest split
   }
   size_t o = 0;
@@ -3652,6 +3827,13 @@ inline bool s2v2_on() {
   if (v < 0) { const char* e = getenv("VC2_S2_V2"); v = e ? (atoi(e) != 0) : VC2_S2_V2; g_s2v2.store(v, std::memory_order_relaxed); }
   return v != 0;
 }
+std::atomic<int> g_s3v2{-1};            // the streamlined sweep 3 (k_dist<.., V2 = 1>): environment VC2_S3_V2; default OFF -- measured
+                                        // no faster than the general form (35.4 vs 34.6 us bf16, 47 vs 45 fp16: NOTES_r05.md)
+inline bool s3v2_on() {
+  int v = g_s3v2.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("VC2_S3_V2"); v = e ? (atoi(e) != 0) : 0; g_s3v2.store(v, std::memory_order_relaxed); }
+  return v != 0;
+}
 inline int s2v2_nch(const Plan& p, const ChanSet& cs) {
   if (!s2v2_on() || p.dt == VC2_F32 || p.VEC == 1 || !cs.cols || !fast_acc(p, cs)) return 0;
   if (p.D % 512 != 0 || int64_t(cs.C) * 2 != p.D || p.R >= (int64_t(1) << 31) || p.F * int64_t(p.S) >= (int64_t(1) << 31) / 8) return 0;
@@ -3715,6 +3897,9 @@ int launch_dist_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
                        wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total, wsp<double>(ws, p.o_vpart));
     return VC2_OK;
   };
+  if constexpr (ACC == 1 && NPLB % 4 == 0 && DT != VC2_F32 && VEC > 1 && (NPLB == 8 || NPLB == 28 || NPLB == 32)) {
+    if (s3v2_on() && s2v2_nch(p, cs) * 4 == NPLB) return launch(k_dist<DT, VEC, NPLB, ACC, 1, 1>);   // streamlined (sweep 2 wrote rflag)
+  }
   if constexpr (ACC == 1 && NPLB % 4 == 0) {
     if (cols && (C & 3) == 0) return launch(k_dist<DT, VEC, NPLB, ACC, 1>);      // tables in 16-byte loads
   }
@@ -3787,11 +3972,20 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   const int FG = int(cdiv(p.F, kCentreFL));
   // rider rows: fp16 queues ~3 % of the rows (its T ulp is 2^13 fp32 ulps), bf16 ~0.4 %; debug mode 2 all of them
   const int bxn = int(cdiv(C, 64));
-  const int fy = !fused ? 0 : int(cdiv(cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 1024 : 256), bxn * kFixWaves));
-  const FixRiders fr{fy, p.CV, int(p.R), wsp<int>(ws, p.o_ticket) + kTkFixCount, wsp<unsigned long long>(ws, p.o_nfixlist),
+  // (a rider workgroup is as large as a frame workgroup -- 16 waves -- and with ~120 VGPRs only ONE workgroup fits a CU:
+  // every rider workgroup takes a whole CU for the length of its rows' chains.  So few of them with many busy waves.)
+  static const int env_fw = [] { const char* e = getenv("VC2_FIX_WAVES"); return e ? atoi(e) : 0; }();
+  const size_t fix_row = (std::max(row_lds_bytes(int(p.D), p.ES), size_t(C) * 4 + 16) + 15) / 16 * 16;
+  int fwaves = env_fw > 0 ? env_fw : VC2_FIX_WAVES_DEFAULT;
+  fwaves = int(std::max<int64_t>(1, std::min<int64_t>(std::min(fwaves, kCentreFL), int64_t(160 * 1024 - 256 - 24 * 1024) / int64_t(fix_row))));
+  // rider slots ~ the rows sweep 2 queues: bf16 ~0.4 % of them, fp16 ~3.7 % (its T ulp is 2^13 fp32 ulps); a rider wave
+  // that finds more entries than slots takes several in turn
+  const int64_t want_slots = cs.strict == 2 ? 8192 : std::max<int64_t>(64, p.dt == VC2_F16 ? p.R / 24 : p.R / 128);
+  const int fy = !fused ? 0 : int(std::min<int64_t>(cdiv(want_slots, int64_t(bxn) * fwaves), cdiv(cs.strict == 2 ? 8192 : 1024, int64_t(bxn) * fwaves)));
+  const FixRiders fr{fy, fwaves, p.CV, int(p.R), wsp<int>(ws, p.o_ticket) + kTkFixCount, wsp<unsigned long long>(ws, p.o_nfixlist),
                      wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr), wsp<float>(ws, p.o_den),
                      FixPush{wsp<uint32_t>(ws, p.o_rlist) + rcap, wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2, wsp<int>(ws, p.o_fmark)}};
-  const size_t fix_lds = !fused ? 0 : kFixWaves * ((std::max(row_lds_bytes(int(p.D), p.ES), size_t(C) * 4 + 16) + 15) / 16 * 16);
+  const size_t fix_lds = !fused ? 0 : size_t(fwaves) * fix_row;
   int rcl = VC2_OK;
   auto launch_fc = [&](auto kernel) {
     if ((rcl = allow_big_lds(kernel, fix_lds, "k_frame_centres", 24 * 1024))) return;
@@ -3824,14 +4018,15 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                  wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr)},
                         fused ? wsp<uint32_t>(ws, p.o_rlist) + rcap : (const uint32_t*)nullptr,
                         wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2};
-  const int rwaves = cs.strict == 2 ? 8192 : 1024;             // rider waves (debug mode 2 replays every mean)
+  static const int env_rw = [] { const char* e = getenv("VC2_REPLAY_WAVES"); return e ? atoi(e) : 0; }();
+  const int rwaves = env_rw > 0 ? env_rw : cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 4096 : 1024);   // rider waves (debug mode 2 replays every mean; fp16 lists ~8x bf16's)
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
     const int G1v = int(cdiv(p.R >> lpv, int64_t(1) << lpv));
     const int Y = int(std::max<int64_t>(1, std::min<int64_t>(32, cdiv(G1v, 64 >> std::min(lpv, 6)))));
     const int RY = replays ? int(cdiv(rwaves, cdiv(C, 64))) : 0;
-    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y + RY)), dim3(64), 0,
-                                             st, cpart, FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
+    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64)), unsigned(Y + RY)), dim3(64),
+                                             vc_lds_bytes(p.R, p.N), st, cpart, FG, int64_t(C), C, p.R, wsp<float>(ws, p.o_vc), x, int(p.D),
                                              cs.cols, cs.spos, wsp<float>(ws, p.o_den), cs.strict, 1,
                                              wsp<int>(ws, p.o_ticket) + kTkVcFragile,
                                              wsp<float>(ws, p.o_vscratch), p.vstride, wsp<int>(ws, p.o_vticket),
@@ -4091,7 +4286,7 @@ int vc2_video_centre_blocks(const void* x, int64_t F, int64_t N, int64_t D, int 
   const ChanSet cs0 = make_chanset(p, cols, spos, C);
   if (!vc_blocks_ok(p, R_total, cs0.strict)) return VC2_OK;      // nothing to exchange: phase 2 keeps the exact means
   uint8_t* vflag = wsp<uint8_t>(ws, p.o_mask);
-  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
+  VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 512 /* (replay_rows = 0: no LDS use) */, st,
                                             csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                             int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
                                             wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr, vflag,
@@ -4186,7 +4381,7 @@ int vc2_scores_phase2_blocks(const void* x, int64_t F, int64_t N, int64_t D, int
                            R_total == int64_t(world) * p.R;
   const bool vc_final = world < 0;   // the caller ran vc2_video_centre_blocks + the finish rounds: the centre is final
   if (!have_blocks && !vc_final)     // (with blocks: vc2_video_centre_blocks already computed the means, the flags and the count)
-    VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 0, st,
+    VC2_DISPATCH_DT(dtype, hipLaunchKernelGGL((k_video_centre<DT>), dim3(unsigned(cdiv(C, 64))), dim3(64), 512 /* (replay_rows = 0: no LDS use) */, st,
                                               csum_all, int(P), csum_stride, int(C), R_total, wsp<float>(ws, p.o_vc), x,
                                               int(D), cols, spos, wsp<float>(ws, p.o_den), cs0.strict, 0,
                                               wsp<int>(ws, p.o_ticket) + 5, (float*)nullptr, 0, (int*)nullptr,
@@ -4569,13 +4764,14 @@ int vc2_debug_plan(int64_t F, int64_t N, int64_t D, int dtype, int64_t* out /*[1
 }
 int vc2_debug_set(int key, int value) {
   if (key == 0) g_s2v2.store(value, std::memory_order_relaxed);
+  if (key == 1) g_s3v2.store(value, std::memory_order_relaxed);
   return VC2_OK;
 }
 #endif
 #ifdef VC2_DEBUG_TIMING
-int vc2_debug_wg(unsigned long long* out /*[6][2][4096]*/) {
+int vc2_debug_wg(unsigned long long* out /*[8][2][4096]*/) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 6 * 2 * 4096);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 8 * 2 * 4096);
   return 0;
 }
 int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {
