@@ -128,7 +128,8 @@ int vc2_compute_scales(const void* s_T, int64_t F, double base, double temp, int
  * selection replay expired IN THIS PASS (any of its kernels: channel selection, ORDER riders, per-frame selection; the
  * one-launch pass keeps the bit in its own workspace word, so two passes in flight on two streams cannot report each
  * other's hits; vc2_selftest_counters has the process-wide details); the Python mirror raises on any of them.  Stage
- * calls (this function) report their own launch only. */
+ * calls (this function) report their own launch only: K_out[1] is zeroed before the launch and every workgroup that
+ * sees a hit ORs it in (a hit of ANY frame's selection is reported, whichever workgroup wrote the count). */
 int vc2_select(const void* scores_T, const void* scales_T, int64_t F, int64_t N, int64_t tpf, int dtype,
                int map_mode, int64_t grid_h, void* ws, size_t ws_bytes, int64_t* ks, int64_t* offs,
                int64_t* idx_out, int64_t cap, int64_t* K_out, void* stream);
@@ -171,12 +172,15 @@ int vc2_compress_ex(const void* x, int64_t F, int64_t N, int64_t D, int dtype, d
                       int64_t* ks, int64_t* K_out, void* v_T, void* f_T, const void* tail, int64_t tail_rows,
                       int flags, void* stream);
 
-/* vc2_compress_ex with a HOST MIRROR of the count: K_host (NULL: none) points at two int64 words of pinned, device-mapped
- * host memory (hipHostMalloc / torch's pin_memory); the selection launch writes K_host[1] = K_out[1] (status) and then
- * K_host[0] = K_out[0] there, BEFORE the gather launch runs.  A caller that sets K_host[0] = -1 beforehand and spins in
- * vc2_wait_host_count has the one number it needs on the host (the reference's `.tolist()`, vidcom2.py:72) ~15 us before
- * the pass ends and without a device-to-host copy behind it; everything it does with the outputs afterwards is ordered
- * by the stream.  (The selection-guard bit of the status may still be set on the DEVICE word after the mirror was read.)
+/* vc2_compress_ex with a HOST MIRROR of the count: K_host (NULL: none) points at FOUR int64 words of pinned, device-mapped
+ * host memory (hipHostMalloc / torch's pin_memory).  The selection launch writes K_host[1] = the status known so far and
+ * then K_host[0] = K_out[0] there, BEFORE the gather launch runs: a caller that sets K_host[0] = -1 beforehand and spins
+ * in vc2_wait_host_count has the one number it needs on the host (the reference's `.tolist()`, vidcom2.py:72) ~15 us
+ * before the pass ends and without a device-to-host copy behind it; everything it does with the outputs afterwards is
+ * ordered by the stream.  K_host[1] is the EARLY status (capacity, expired waits, guard hits of the earlier kernels); the
+ * last selection workgroup to finish writes K_host[2] = the launch's final status | 2^62 (set K_host[2] = 0 beforehand):
+ * a caller that went on with the early words must look at K_host[2] before it relies on the kept set being what the
+ * reference keeps (bit 4, a loop bound of the selection replay expired: "cannot happen", never swallowed).
  * vc2_wait_host_count returns the count, or a negative number after timeout_s seconds. */
 int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, double base_scale,
                      int map_mode, int64_t grid_h, const void* gather_src, int64_t gather_rows,
@@ -336,6 +340,10 @@ int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws
 /* Diagnostic (SYNCHRONISES): every loop of the selection replay is bounded; out8 = how often each bound actually
  * expired since the last reset (all zero on a healthy run; the test-suite asserts it). */
 int vc2_selftest_counters(int32_t* out8_host, int reset);
+/* Test hook: the selection launches that follow report a loop-bound hit (status bit 4) from the workgroup of local frame
+ * `frame` (-1: off) -- how the test-suite checks that a hit in ANY workgroup of the launch reaches K_out[1] and the host
+ * mirror's final word.  Process-wide; nothing is computed differently. */
+int vc2_selftest_force_guard(int frame);
 
 #ifdef __cplusplus
 }

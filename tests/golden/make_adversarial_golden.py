@@ -4,6 +4,8 @@ half-positive half-negative tokens, scored channels whose frame / video means ar
 through the REFERENCE itself (build container only: needs /root/reference):
 
     python tests/golden/make_adversarial_golden.py      ->  tests/golden/adversarial_cases.json
+    python tests/golden/make_adversarial_golden.py big  ->  tests/golden/adversarial_big_cases.json (round 5: the same inputs at
+                                                            the target shape and at cfg3, bf16 and fp16 -- VERDICT r4 item 4)
 
 Data only (seeds, shapes, digests, index lists).  Also records, per case, how often the reference's centre values
 differ from the exactly rounded means -- i.e. how often torch's fp32 cascade decided a rounding -- and the largest
@@ -33,15 +35,21 @@ torch.set_num_threads(8)
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 CASES = [("adv", 16, 196, 512, "bf16", 0), ("adv", 16, 196, 512, "f16", 0), ("adv", 32, 100, 1024, "bf16", 1),
          ("adv", 8, 324, 768, "f16", 2), ("adv", 64, 196, 256, "bf16", 3)]
+# (name, F, N, D, dtype, seed, base)
+BIG_CASES = [("adv_target", 128, 196, 3584, "bf16", 4, 0.25), ("adv_target", 128, 196, 3584, "f16", 5, 0.25),
+             ("adv_cfg3", 64, 324, 3584, "bf16", 6, 0.125), ("adv_cfg3", 64, 324, 3584, "f16", 7, 0.125)]
 
 
 def main():
+    big = len(sys.argv) > 1 and sys.argv[1] == "big"
     out = []
-    for name, Fr, N, D, dn, seed in CASES:
+    for case in (BIG_CASES if big else CASES):
+        name, Fr, N, D, dn, seed = case[:6]
+        base = case[6] if len(case) > 6 else 0.25
         x = synth.make(Fr, N, D, DT[dn], seed, "cancel")
         sel = R.select_low_var_channels(x)
         v, f = R.compute_gaussian_scores(sel, N)
-        scales = R.compute_scales(-v.mean(dim=-1), 0.25)
+        scales = R.compute_scales(-v.mean(dim=-1), base)
         ks = (scales * N).round().long().clamp(min=1).tolist()
         idx = R.select_outlier_indices(v + f, scales, N)
         g = R._map_linear_offset(idx, N)
@@ -53,7 +61,7 @@ def main():
         fc_exact = (fd.sum(dim=1).float() / float(N)).to(DT[dn])
         vc_exact = (fd.sum(dim=(0, 1)).float() / float(Fr * N)).to(DT[dn])
         cancel = float((fd.abs().mean(dim=1) / fd.mean(dim=1).abs().clamp_min(1e-30)).median())
-        out.append({"name": name, "F": Fr, "N": N, "D": D, "dtype": dn, "seed": seed, "dist": "cancel", "base": 0.25,
+        out.append({"name": name, "F": Fr, "N": N, "D": D, "dtype": dn, "seed": seed, "dist": "cancel", "base": base,
                     "x_sha256": synth.sha256_tensor(x), "ks": ks, "global_idx": g.tolist(),
                     "v_sha256": synth.sha256_tensor(v), "f_sha256": synth.sha256_tensor(f),
                     "frame_centres_decided_by_order": int((fc_ref != fc_exact).sum()),
@@ -62,7 +70,8 @@ def main():
         print(out[-1]["dtype"], Fr, N, D, "ks", ks[:6], "frame centres decided by torch's order:",
               out[-1]["frame_centres_decided_by_order"], "of", fc_ref.numel(), "| video:",
               out[-1]["video_centre_decided_by_order"], "of", vc_ref.numel(), "| cancellation x", cancel)
-    json.dump({"cases": out}, open(os.path.join(HERE, "adversarial_cases.json"), "w"), indent=1)
+    json.dump({"cases": out}, open(os.path.join(HERE, "adversarial_big_cases.json" if big else "adversarial_cases.json"), "w"),
+              indent=None if big else 1)
 
 
 if __name__ == "__main__":

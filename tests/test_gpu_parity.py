@@ -526,7 +526,7 @@ def test_mode_is_process_wide_with_a_per_thread_override():
         _ffi.set_thread_mode(None)
 
 
-ADV = load_json("adversarial_cases.json")["cases"]
+ADV = load_json("adversarial_cases.json")["cases"] + load_json("adversarial_big_cases.json")["cases"]   # (round 5: + target / cfg3 size)
 
 
 @pytest.mark.parametrize("mode", ["torch", "torch_proven"])
@@ -627,6 +627,54 @@ def test_early_count_mirror_and_spare_outputs_change_nothing():
     finally:
         V._EARLY_COUNT, V._PREALLOC = old
         V.clear_plan_cache()
+
+
+@pytest.mark.gpu
+def test_a_guard_hit_of_any_frame_reaches_the_caller():
+    """Status bit 4 (a loop bound of the selection replay expired) raised from the workgroup of a NON-last frame -- the
+    last frame's workgroup writes the count and the early status words before the other selections end.  With the host
+    mirror armed the hit arrives in the mirror's FINAL word (K_host[2]): taken by finish() if it is already there, else
+    raised when the plan's next pass is enqueued (_settle).  Without the mirror the blocking copy sees it.  The stage
+    call (vc2_select: no pass-wide status word) reports it in K_out[1] as well."""
+    import vidcom2_amd as vc
+    from vidcom2_amd import vidcom2 as V
+    dev = torch.device("cuda:0")
+    F, N, D = 16, 196, 1024
+    x = synth.make(F, N, D, torch.bfloat16, 3, "drift").to(dev)
+    L = _ffi.lib()
+    try:
+        for mirror in (False, True):
+            plan = V.CompressPlan(F, N, D, torch.bfloat16, dev, 0.25)
+            plan.enqueue(x, mirror=mirror); good = plan.finish(); plan._settle()
+            L.vc2_selftest_force_guard(3)                      # frame 3 of 16: not the workgroup that writes the count
+            plan.new_outputs(); plan.enqueue(x, mirror=mirror)
+            raised = False
+            try:
+                plan.finish()
+            except RuntimeError as e:
+                raised = "selection replay" in str(e)
+            if not raised:                                     # the early words were clean: the final word must not be
+                assert mirror
+                torch.cuda.synchronize()
+                with pytest.raises(RuntimeError, match="PREVIOUS pass.*selection replay"):
+                    plan.new_outputs(); plan.enqueue(x, mirror=mirror)
+            L.vc2_selftest_force_guard(-1)
+            torch.cuda.synchronize()
+            plan._late = None
+            plan.new_outputs(); plan.enqueue(x, mirror=mirror); again = plan.finish(); plan._settle()
+            assert again.K == good.K and torch.equal(again.global_idx, good.global_idx)
+        # the stage call: K_out[1] carries the bit whichever workgroup stored the count
+        scores = torch.rand(F, N, device=dev).to(torch.bfloat16)
+        scales = torch.full((F,), 0.25, device=dev).to(torch.bfloat16)
+        L.vc2_selftest_force_guard(5)
+        with pytest.raises(RuntimeError, match="selection replay"):
+            vc.select_outlier_indices(scores, scales, N)
+        L.vc2_selftest_force_guard(-1)
+        assert [int(t.numel()) for t in vc.select_outlier_indices(scores, scales, N)] == [49] * F
+    finally:
+        L.vc2_selftest_force_guard(-1)
+        c = (ctypes.c_int32 * 8)()
+        L.vc2_selftest_counters(c, 1)
 
 
 @pytest.mark.gpu

@@ -159,7 +159,11 @@ def test_oracle_matches_the_reference_on_adversarial_centre_means():
     import json
     import os
     cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "adversarial_cases.json")))["cases"]
+    # (round 5) the same construction at the target shape and at cfg3, bf16 and fp16: 38 .. 335 frame centres per case
+    # are decided by torch's summation order there
+    cases += json.load(open(os.path.join(os.path.dirname(__file__), "golden", "adversarial_big_cases.json")))["cases"]
     assert sum(c["frame_centres_decided_by_order"] + c["video_centre_decided_by_order"] for c in cases) > 10
+    assert sum(c["F"] * c["N"] * c["D"] >= 64 * 324 * 3584 for c in cases) >= 4
     O.set_mode("torch")
     try:
         for c in cases:

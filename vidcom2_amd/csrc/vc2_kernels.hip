@@ -1799,6 +1799,7 @@ struct FixRiders {
 #endif
 constexpr int kFixWaves = VC2_FIX_WAVES_DEFAULT;               // (default; FixRiders::waves)
 constexpr int kTkFixEntries = 8;             // ticket word: correction entries of the pass (FixPush)
+constexpr int kTkSelArrive = 9;              // ticket word: k_select workgroups that have finished their selection (host mirror)
 
 template <int DT, int VEC, int NPLB>        // NPLB = 0: no rider code compiled in
 __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* __restrict__ part, int F, int S, int S_q, int N,
@@ -3163,7 +3164,8 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
                                                      const double* __restrict__ vpart, int S2,
                                                      const float* __restrict__ frame_scores, float base,
                                                      float temp, float* __restrict__ scales_out,
-                                                     int* status = nullptr, long long* khost = nullptr) {
+                                                     int* status = nullptr, long long* khost = nullptr,
+                                                     int* arrive = nullptr, int force_guard = -1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float smf[4];
   __shared__ double smd[4];
@@ -3303,13 +3305,14 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       //  inside this launch's own replays is ORed in by the workgroup that sees it, below)
       const int stw = status ? __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       const long long wv = (Ktot > cap ? 1 : 0) | ((stw & kStatusSpinExpired) ? 2 : 0) | ((stw & kSel2StatusGuard) ? 4 : 0);
-      // (one-launch pass: its first kernel zeroed the word and every workgroup ORs -- order-free; stage calls store)
-      if (status) atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), (unsigned long long)wv); else K_out[1] = wv;
+      // (the word is zero when the launch begins -- the pass's first kernel or launch_select's memset -- and every
+      // workgroup ORs its bits in: order-free)
+      atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), (unsigned long long)wv);
       if (khost) {
         // the host's mirror of (K, status) in pinned memory: the caller only needs K to slice its outputs, so it can go
         // on while the gather launch is still running (everything after is stream-ordered).  Status first, then the
-        // count the host polls for.  (A selection-guard hit of another workgroup may land after the host has read the
-        // mirror: the device word stays authoritative for that "cannot happen" bit.)
+        // count the host polls for.  This is the EARLY status: a selection-guard hit of another workgroup may land
+        // later -- khost[2], written by the last workgroup to finish its selection (below), is the final word.
         __hip_atomic_store(khost + 1, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
         __hip_atomic_store(khost, (long long)Ktot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3321,9 +3324,21 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   if constexpr (DT == VC2_F32) select_frame_body<DT, uint64_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out, &st_local);
   else select_frame_body<DT, uint32_t>(smem, total, fl, N, k, o0, map_mode, grid_h, stride, cap, idx_out, &st_local);
   __syncthreads();
+  if (tid == 0 && fl == force_guard) st_local = 1;               // (test hook: vc2_selftest_force_guard)
   if (tid == 0 && st_local) {                                    // (cannot happen; reported, never swallowed)
-    if (status) { atomicOr(status, kSel2StatusGuard); atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), 4ull); }
-    if (khost) __hip_atomic_fetch_or(khost + 1, 4ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (status) atomicOr(status, kSel2StatusGuard);
+    atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), 4ull);
+  }
+  // The FINAL status for the host mirror: the last workgroup to get here (all selections of the launch are over, their
+  // bits are in K_out[1]) publishes khost[2] = status | 2^62.  A host that returned on the early words re-reads it
+  // before it trusts the next pass of the plan (CompressPlan._settle): a late guard hit is raised, never lost.
+  if (tid == 0 && khost && arrive) {
+    __threadfence();                                             // release my bits ...
+    if (atomicAdd(arrive, 1) == FS - 1) {
+      __threadfence();                                           // ... acquire everybody's
+      const unsigned long long fin = atomicOr(reinterpret_cast<unsigned long long*>(K_out + 1), 0ull);
+      __hip_atomic_store(khost + 2, (long long)(fin | (1ull << 62)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(809 + (fl ? 50 : 0));
 }
@@ -4081,11 +4096,16 @@ int launch_scales(int dt, const float* s, int64_t F, double base, double temp, f
 struct BudgetSrc { const float* scales_f32; const double* vpart; int S2; const float* frame_scores; double base; double temp;
                    float* scales_out; int64_t tpf = 0;         // tpf: the multiplier of vidcom2.py:72 (0: N)
                    int* status = nullptr;                      // the pass's kTkStatus word (reported in K_out[1])
-                   long long* khost = nullptr; };              // pinned host mirror of K_out[0..1] (vc2_compress_ex2)
+                   long long* khost = nullptr;                 // pinned host mirror: K, early status, final status (vc2_compress_ex2)
+                   int* arrive = nullptr; };                   // ... and the arrival ticket behind the final word (zero on entry)
+std::atomic<int> g_force_guard{-1};       // test hook (vc2_selftest_force_guard): this local frame's selection reports a guard hit
 int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_sel, int64_t N, int map_mode,
                   int64_t grid_h, int64_t* ks, int64_t* offs, int64_t* idx_out, int64_t cap, int64_t* K_out,
                   const BudgetSrc& b, hipStream_t st) {
   const size_t smem = sel2_bytes(int(N), dt == VC2_F32 ? 8 : 4);
+  // K_out[1] collects the launch's status bits by atomic OR: it starts at zero -- the one-launch pass's first kernel
+  // zeroed it (b.status != nullptr); a stage call zeroes it here
+  if (!b.status && hipMemsetAsync(K_out + 1, 0, 8, st) != hipSuccess) return fail(VC2_ERR_LAUNCH, "status memset failed");
   ProfScope ps_(KID_SELECT, st);
   VC2_DISPATCH_DT(dt, {
     int rca = allow_big_lds(&k_select<DT>, smem, "k_select");
@@ -4093,7 +4113,8 @@ int launch_select(int dt, const float* total, int64_t F, int64_t f0, int64_t F_s
     hipLaunchKernelGGL((k_select<DT>), dim3(unsigned(F_sel)), dim3(kFrameNT), smem, st, total, b.scales_f32, int(F),
                        int(f0), int(N), int(b.tpf > 0 ? b.tpf : N), map_mode, int(grid_h), N, cap, ks, offs, idx_out, K_out,
                        b.vpart, b.S2,
-                       b.frame_scores, float(b.base), float(b.temp), b.scales_out, b.status, b.khost);
+                       b.frame_scores, float(b.base), float(b.temp), b.scales_out, b.status, b.khost, b.arrive,
+                       g_force_guard.load(std::memory_order_relaxed));
   });
   return check_launch("select");
 }
@@ -4577,6 +4598,20 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   if ((rc = need_ws(p, ws, ws_bytes))) return rc;
   if (D > 8192) return fail(VC2_ERR_UNSUPPORTED, "D=%lld > 8192 channels", (long long)D);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (K_host) {       // the kernels store through this pointer: it must be pinned, device-mapped host memory -- translated
+    //                    (not assumed equal: unified addressing is the common case, not a guarantee), once per pointer
+    thread_local int64_t* seen_host = nullptr;
+    thread_local int64_t* seen_dev = nullptr;
+    if (seen_host != K_host) {
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, K_host, 0) != hipSuccess || !dp) {
+        (void)hipGetLastError();
+        return fail(VC2_ERR_ARG, "K_host is not pinned, device-mapped host memory (hipHostMalloc / pin_memory)");
+      }
+      seen_host = K_host; seen_dev = static_cast<int64_t*>(dp);
+    }
+    K_host = seen_dev;
+  }
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
   int* cols = wsp<int>(ws, p.o_cols);
   if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true,
@@ -4610,12 +4645,13 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   if (fused_budget) {
     rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
                        BudgetSrc{nullptr, wsp<double>(ws, p.o_vpart), p.S2, nullptr, bs, 0.01, scales, 0,
-                                 wsp<int>(ws, p.o_ticket) + kTkStatus, reinterpret_cast<long long*>(K_host)}, st);
+                                 wsp<int>(ws, p.o_ticket) + kTkStatus, reinterpret_cast<long long*>(K_host),
+                                 wsp<int>(ws, p.o_ticket) + kTkSelArrive}, st);
   } else {
     if ((rc = launch_scales(dtype, s, F, bs, 0.01, wsp<float>(ws, p.o_zbuf), scales, nullptr, st))) return rc;
     rc = launch_select(dtype, total, F, 0, F, N, map_mode, grid_h, ks, wsp<int64_t>(ws, p.o_offs), idx_out, cap, K_out,
                        BudgetSrc{scales, nullptr, 0, nullptr, bs, 0.01, nullptr, 0, wsp<int>(ws, p.o_ticket) + kTkStatus,
-                                 reinterpret_cast<long long*>(K_host)}, st);
+                                 reinterpret_cast<long long*>(K_host), wsp<int>(ws, p.o_ticket) + kTkSelArrive}, st);
   }
   if (rc) return rc;
   if (out_rows && gather_src)
@@ -4712,6 +4748,10 @@ int vc2_pass_counters(int64_t F, int64_t N, int64_t D, int dtype, const void* ws
   return VC2_OK;
 }
 
+int vc2_selftest_force_guard(int frame) {
+  g_force_guard.store(frame, std::memory_order_relaxed);
+  return VC2_OK;
+}
 int vc2_selftest_counters(int32_t* out8_host, int reset) {
   // diagnostic (SYNCHRONISES): how often a loop bound of the selection engine expired (must be all zero)
   if (!out8_host) return fail(VC2_ERR_ARG, "null pointer");

@@ -136,6 +136,7 @@ class CompressPlan:
         # the count from there -- ~15 us before the pass ends, no device-to-host copy -- and returns while the gather runs
         self._khost = None
         self._khost_armed = False
+        self._late = None                                # a pass that returned on its early status words (see _settle)
         self.new_outputs()
 
     def _alloc_outputs(self):
@@ -180,11 +181,13 @@ class CompressPlan:
             tail = tail.contiguous()
         khost = None
         if mirror:
+            self._settle()                               # (a previous pass that returned on its early status words)
             if self._khost is None:
-                self._khost = torch.empty(2, dtype=torch.int64).pin_memory()
-                self._khost_addr = ctypes.c_void_p(self._khost.data_ptr())
-                self._khost_word = ctypes.c_int64.from_address(self._khost.data_ptr())
+                self._khost = _khost_get()               # (pinned words from the process-wide pool: never freed)
+                self._khost_addr, self._khost_word, self._khost_final = self._khost.addr, self._khost.word, self._khost.final
             self._khost_word.value = -1                  # (host write: the previous pass of this plan was finished)
+            self._khost_final.value = 0
+            self._khost.in_flight = True
             khost = self._khost_addr
         self._khost_armed = bool(mirror)
         with on_device(self.device):
@@ -196,6 +199,14 @@ class CompressPlan:
                                         1 if have_stats else 0, khost, stream_ptr(self.device))
         check(rc, "vc2_compress")
 
+    def __del__(self):
+        kh = getattr(self, "_khost", None)
+        if kh is not None:
+            try:
+                _khost_put(kh)
+            except Exception:                            # (interpreter shutdown)
+                pass
+
     def finish(self) -> CompressionResult:
         # (spinning on an event behind a copy to pinned memory instead of this blocking copy: measured, no gain -- torch's
         #  blocking copy already spins)
@@ -206,9 +217,33 @@ class CompressPlan:
             self._khost_armed = False
             K = int(lib().vc2_wait_host_count(self._khost_addr, 0.05))
             if K >= 0:
-                return self._result(self.take(), K, int(self._khost[1]))
+                # the launch's FINAL status word arrives when its last selection ends (~10 us after K): taken if it is
+                # there already, else this pass is settled before the plan's next one starts (_settle) -- a late
+                # selection-guard hit is raised there, never lost
+                fin = int(self._khost_final.value)
+                if fin & _STATUS_FINAL:
+                    status = fin & ~_STATUS_FINAL
+                else:
+                    status = int(self._khost.t[1])
+                    self._late = (self.kout, self.cap, K)
+                return self._result(self.take(), K, status)
         K, status = self.kout.tolist()                   # the single host sync of the path
         return self._result(self.take(), K, status)
+
+    def _settle(self) -> None:
+        """A pass that returned on the early status words of the host mirror: read its final status now (the device word,
+        one blocking copy -- by now the launch is long over) and raise what it reports."""
+        late, self._late = getattr(self, "_late", None), None
+        if late is None:
+            return
+        kout, cap, K = late
+        fin = int(self._khost_final.value) if self._khost is not None else 0
+        status = (fin & ~_STATUS_FINAL) if fin & _STATUS_FINAL else int(kout[1].item())
+        if status:
+            try:
+                _raise_status(status, cap, K)
+            except RuntimeError as e:
+                raise RuntimeError(f"the PREVIOUS pass of this plan (its result was already returned): {e}") from None
 
     def take(self):
         """The enqueued pass's output tensors, detached from the plan: the plan can take new outputs and the next clip
@@ -274,6 +309,46 @@ def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores
 def clear_plan_cache() -> None:
     with _PLAN_LOCK:
         _PLAN_CACHE.clear()
+
+
+class _KHost:
+    """Four pinned int64 words for vc2_compress_ex2's host mirror (K, early status, final status | 2^62, spare).  Pooled
+    and never freed: the selection launch writes the final word ~10 us after the count, possibly after the plan that
+    enqueued the pass is gone -- a block handed back to the allocator could be somebody else's memory by then."""
+    __slots__ = ("t", "addr", "word", "final", "in_flight")
+
+    def __init__(self):
+        self.t = torch.zeros(4, dtype=torch.int64).pin_memory()
+        self.addr = ctypes.c_void_p(self.t.data_ptr())
+        self.word = ctypes.c_int64.from_address(self.t.data_ptr())
+        self.final = ctypes.c_int64.from_address(self.t.data_ptr() + 16)
+        self.in_flight = False
+
+
+_KHOST_LOCK = threading.Lock()
+_KHOST_FREE: list = []
+_KHOST_QUARANTINE: list = []         # returned while their pass may still write the final word
+
+
+def _khost_get() -> _KHost:
+    with _KHOST_LOCK:
+        still = []
+        for b in _KHOST_QUARANTINE:
+            (_KHOST_FREE if b.final.value & _STATUS_FINAL else still).append(b)
+        _KHOST_QUARANTINE[:] = still
+        b = _KHOST_FREE.pop() if _KHOST_FREE else None
+    if b is None:
+        b = _KHost()
+    b.in_flight = False
+    return b
+
+
+def _khost_put(b: _KHost) -> None:
+    with _KHOST_LOCK:
+        (_KHOST_QUARANTINE if b.in_flight and not (b.final.value & _STATUS_FINAL) else _KHOST_FREE).append(b)
+
+
+_STATUS_FINAL = 1 << 62          # K_host[2] of vc2_compress_ex2: "this is the launch's final status word"
 
 
 def _raise_status(status: int, cap: int, K: int) -> None:
@@ -543,7 +618,10 @@ def select_outlier_indices(scores: torch.Tensor, scales: torch.Tensor, tpf: int)
     """Reference: vidcom2.py:70-78.  Returns F ascending int64 index tensors (one host sync, as the
     reference's ``.tolist()``)."""
     idx, ks, _, kout = _select(scores, scales, _as_int(tpf), MAP_LOCAL)
-    ks_host = ks.tolist()
+    host = torch.cat((ks, kout)).tolist()     # budgets + (count, status): still ONE host sync
+    ks_host, (K, status) = host[:-2], host[-2:]
+    if status:
+        _raise_status(int(status), int(idx.numel()), int(K))
     N = scores.shape[1]
     if any(k > N for k in ks_host):          # ks = round(scales * tpf) with tpf > N: torch.topk's own error (vidcom2.py:76)
         raise RuntimeError("selected index k out of range")
