@@ -3430,25 +3430,82 @@ __global__ __launch_bounds__(256) void k_gather_rows(GSArgs a) {
 // not a video token, plus the video tokens whose ordinal is in `kept` (ascending).  keep_out = those positions in
 // order; vis_rows_out (optional) = for the positions flagged in visual_mask, the ordinals (among them) that are
 // kept -- the rows Qwen3-VL's deep-stack tensors keep (qwen3_vl.py:141-149).  counts_out = {n_keep, n_vis_rows}.
-// One workgroup of 1024 threads, thread-contiguous chunks, two block scans.
+// One workgroup of 1024 threads, thread-contiguous chunks of positions.  Round 5: the kept ordinals go into an LDS
+// BITMAP first (one coalesced sweep of kept[], which also checks that it ascends), so that "is video token number o
+// kept" is an LDS bit test -- rounds 2-4 walked kept[] with a binary search and a merge per thread, a chain of dependent
+// global loads per position (54.8 us for 20 832 positions); the mask bytes of a chunk are fetched sixteen at a time.
+// counts_out may be pinned host memory (vc2_keep_positions translates it): its words are stored system-scope, the error
+// word LAST, so that a host spinning on it (vc2_wait_host_count on counts_out + 2, preset to -1) needs no copy.
 constexpr int kKeepNT = 1024;
+constexpr int64_t kKeepBitmapMaxS = int64_t(120) * 1024 * 8;      // positions whose bitmap fits the workgroup's LDS
+// V > 0: a thread owns 16 V consecutive positions and keeps their mask bytes in REGISTERS (one round of 16-byte loads,
+// S <= 1024 * 16 V); V = 0: thread-contiguous chunks of any length, re-read sixteen bytes at a time in every pass.
+template <typename F>
+__device__ __forceinline__ void keep_walk(const uint8_t* __restrict__ m0, const uint8_t* __restrict__ m1, int64_t b, int64_t e, F f) {
+  for (int64_t p0 = b; p0 < e; p0 += 16) {                        // sixteen mask bytes (of each mask) in flight
+    uint8_t a[16], v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int64_t p = p0 + u < e ? p0 + u : e - 1; a[u] = m0[p]; v[u] = m1 ? m1[p] : uint8_t(0); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (p0 + u < e) f(p0 + u, a[u] != 0, v[u] != 0);
+  }
+}
+template <int V>
 __global__ __launch_bounds__(kKeepNT) void k_keep_positions(const uint8_t* __restrict__ video_mask, int64_t S,
                                                             const int64_t* __restrict__ kept,
                                                             const int64_t* __restrict__ K_dev, int64_t K_max,
                                                             const uint8_t* __restrict__ visual_mask,
                                                             int64_t* __restrict__ keep_out, int64_t keep_cap,
                                                             int64_t* __restrict__ vis_rows_out, int64_t vis_cap,
-                                                            int64_t* __restrict__ counts_out) {
+                                                            int64_t* __restrict__ counts_out, int use_bitmap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t bitmap[];     // [ceil(S / 32)] when use_bitmap
   __shared__ uint32_t xch[16];
   __shared__ int err_s;
   constexpr int NW = kKeepNT / 64;
+  constexpr int PB = V > 0 ? 16 * V : 1;                           // positions (mask bytes) a thread holds in registers
   const int tid = threadIdx.x;
   const int64_t K = K_dev ? min(K_dev[0], K_max) : K_max;
   if (tid == 0) err_s = 0;
-  const int64_t E = (S + kKeepNT - 1) / kKeepNT;
+  const int64_t E = V > 0 ? PB : (S + kKeepNT - 1) / kKeepNT;
   const int64_t b = min(S, tid * E), e = min(S, b + E);
+  union Bytes { uint4 q[V > 0 ? V : 1]; uint8_t c[PB]; };
+  Bytes vm, vs;
+  if constexpr (V > 0) {
+    // (the masks are torch tensors: 16-byte aligned; a vector that crosses the end is fetched byte by byte)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int64_t p0 = b + 16 * j;
+      if (p0 + 16 <= S && (reinterpret_cast<uintptr_t>(video_mask + p0) & 15) == 0 &&
+          (!visual_mask || (reinterpret_cast<uintptr_t>(visual_mask + p0) & 15) == 0)) {
+        vm.q[j] = *reinterpret_cast<const uint4*>(video_mask + p0);
+        vs.q[j] = visual_mask ? *reinterpret_cast<const uint4*>(visual_mask + p0) : make_uint4(0u, 0u, 0u, 0u);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const bool in = p0 + u < S;
+          vm.c[16 * j + u] = in ? video_mask[p0 + u] : uint8_t(0);
+          vs.c[16 * j + u] = (in && visual_mask) ? visual_mask[p0 + u] : uint8_t(0);
+        }
+      }
+    }
+  }
+  // f(position, is video, is visual) over my positions in order
+  auto walk = [&](auto f) {
+    if constexpr (V > 0) {                                         // (bytes picked out of the packed words: 8 V registers, not 32 V)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const uint32_t wm[4] = {vm.q[j].x, vm.q[j].y, vm.q[j].z, vm.q[j].w}, wv[4] = {vs.q[j].x, vs.q[j].y, vs.q[j].z, vs.q[j].w};
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (b + 16 * j + u < e) f(b + 16 * j + u, ((wm[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0u, ((wv[u >> 2] >> (8 * (u & 3))) & 0xFFu) != 0u);
+      }
+    } else {
+      keep_walk(video_mask, visual_mask, b, e, f);
+    }
+  };
   uint32_t nv = 0;
-  for (int64_t p = b; p < e; ++p) nv += video_mask[p] ? 1u : 0u;
+  walk([&](int64_t, bool vid, bool) { nv += vid ? 1u : 0u; });
+  if (use_bitmap) for (int64_t w = tid; w < (S + 31) / 32; w += kKeepNT) bitmap[w] = 0u;
   uint32_t tot;
   const int64_t ord0 = block_excl_scan<NW>(nv, xch, tot);        // video ordinal of my first video token
   __syncthreads();
@@ -3457,47 +3514,69 @@ __global__ __launch_bounds__(kKeepNT) void k_keep_positions(const uint8_t* __res
     for (int64_t i = tid; i < K; i += kKeepNT) {
       const int64_t v = kept[i];
       if (v < 0 || v >= int64_t(tot) || (i + 1 < K && kept[i + 1] <= v)) bad = 1;
+      else if (use_bitmap) atomicOr(&bitmap[v >> 5], 1u << (v & 31));
     }
     if (bad) atomicOr(&err_s, 4);
   }
-  int64_t q;                                                     // first entry of kept[] that is >= ord0
-  { int64_t lo = 0, hi = K; while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (kept[m] < ord0) lo = m + 1; else hi = m; } q = lo; }
-  // pass 1: how many positions / visual rows do I keep, how many visual positions precede mine
+  __syncthreads();
+  int64_t q = 0;                                                 // (no bitmap) first entry of kept[] that is >= ord0
+  if (!use_bitmap) { int64_t lo = 0, hi = K; while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (kept[m] < ord0) lo = m + 1; else hi = m; } q = lo; }
+  // is video token number o kept?  (qq: the thread's cursor into kept[] when there is no bitmap)
+  auto kept_has = [&](int64_t o, int64_t& qq) -> bool {
+    if (use_bitmap) return (bitmap[o >> 5] >> (o & 31)) & 1u;
+    while (qq < K && kept[qq] < o) ++qq;
+    return qq < K && kept[qq] == o;
+  };
+  // pass 1: how many positions / visual rows do I keep, how many visual positions precede mine; the decisions stay in a
+  // register mask when the positions do
   uint32_t nk = 0, nvis = 0, nvk = 0;
+  unsigned long long keepbits[(PB + 63) / 64] = {};
   {
     int64_t o = ord0, qq = q;
-    for (int64_t p = b; p < e; ++p) {
+    int u = 0;
+    walk([&](int64_t, bool vid, bool vis) {
       bool keep = true;
-      if (video_mask[p]) { while (qq < K && kept[qq] < o) ++qq; keep = qq < K && kept[qq] == o; ++o; }
+      if (vid) { keep = kept_has(o, qq); ++o; }
+      if (V > 0) { if (keep) keepbits[u >> 6] |= 1ull << (u & 63); ++u; }
       nk += keep ? 1u : 0u;
-      if (visual_mask && visual_mask[p]) { ++nvis; nvk += keep ? 1u : 0u; }
-    }
+      if (vis) { ++nvis; nvk += keep ? 1u : 0u; }
+    });
   }
   const int64_t k0 = block_excl_scan<NW>(nk, xch, tot);
   const uint32_t tot_k = tot;
   __syncthreads();
-  const int64_t v0 = block_excl_scan<NW>(nvis, xch, tot);
-  __syncthreads();
-  const int64_t vk0 = block_excl_scan<NW>(nvk, xch, tot);
-  const uint32_t tot_vk = tot;
-  __syncthreads();
-  if (tid == 0 && counts_out) {
-    // counts_out[2]: 1 = more kept positions than keep_cap, 2 = more visual rows than vis_cap (neither is written
-    // past its capacity), 4 = kept[] not strictly ascending inside [0, video positions), 8 = fewer positions than
-    // keep_cap (the caller's count of video positions was wrong: the rest of keep_out is filled with -1)
-    counts_out[0] = tot_k; counts_out[1] = tot_vk;
-    counts_out[2] = err_s | (int64_t(tot_k) > keep_cap ? 1 : 0) | ((vis_rows_out && int64_t(tot_vk) > vis_cap) ? 2 : 0) |
-                    ((keep_out && int64_t(tot_k) < keep_cap) ? 8 : 0);
+  int64_t v0 = 0, vk0 = 0;
+  uint32_t tot_vk = 0;
+  if (visual_mask) {                                             // (uniform)
+    v0 = block_excl_scan<NW>(nvis, xch, tot);
+    __syncthreads();
+    vk0 = block_excl_scan<NW>(nvk, xch, tot);
+    tot_vk = tot;
+    __syncthreads();
   }
   if (keep_out) for (int64_t i = int64_t(tot_k) + tid; i < keep_cap; i += kKeepNT) keep_out[i] = -1;
   {
     int64_t o = ord0, qq = q, kk = k0, vv = v0, vk = vk0;
-    for (int64_t p = b; p < e; ++p) {
+    int u = 0;
+    walk([&](int64_t p, bool vid, bool vis) {
       bool keep = true;
-      if (video_mask[p]) { while (qq < K && kept[qq] < o) ++qq; keep = qq < K && kept[qq] == o; ++o; }
+      if (V > 0) { keep = (keepbits[u >> 6] >> (u & 63)) & 1ull; ++u; }
+      else if (vid) { keep = kept_has(o, qq); ++o; }
       if (keep && keep_out) { if (kk < keep_cap) keep_out[kk] = p; ++kk; }
-      if (visual_mask && visual_mask[p]) { if (keep && vis_rows_out) { if (vk < vis_cap) vis_rows_out[vk] = vv; ++vk; } ++vv; }
-    }
+      if (vis) { if (keep && vis_rows_out) { if (vk < vis_cap) vis_rows_out[vk] = vv; ++vk; } ++vv; }
+    });
+  }
+  if (tid == 0 && counts_out) {
+    // counts_out[2]: 1 = more kept positions than keep_cap, 2 = more visual rows than vis_cap (neither is written
+    // past its capacity), 4 = kept[] not strictly ascending inside [0, video positions), 8 = fewer positions than
+    // keep_cap (the caller's count of video positions was wrong: the rest of keep_out is filled with -1)
+    const long long err = err_s | (int64_t(tot_k) > keep_cap ? 1 : 0) | ((vis_rows_out && int64_t(tot_vk) > vis_cap) ? 2 : 0) |
+                          ((keep_out && int64_t(tot_k) < keep_cap) ? 8 : 0);
+    long long* co = reinterpret_cast<long long*>(counts_out);
+    __hip_atomic_store(co, (long long)tot_k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(co + 1, (long long)tot_vk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(co + 2, err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);    // (last: what a spinning host waits for)
   }
 }
 
@@ -4541,9 +4620,29 @@ int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept
   if (!video_mask || S <= 0 || K_max < 0 || (K_max > 0 && !kept) || keep_cap < 0 || vis_cap < 0)
     return fail(VC2_ERR_ARG, "bad keep_positions arguments");          // (keep_out may be null when nothing is kept)
   if (S > (int64_t(1) << 31) - 1) return fail(VC2_ERR_UNSUPPORTED, "S=%lld positions", (long long)S);
-  hipLaunchKernelGGL(k_keep_positions, dim3(1), dim3(kKeepNT), 0, static_cast<hipStream_t>(stream), video_mask, S, kept,
-                     K_dev, K_max, visual_mask, keep_out, keep_out ? keep_cap : 0, vis_rows_out,
-                     vis_rows_out ? vis_cap : 0, counts_out);
+  if (counts_out) {       // pinned host memory (a caller that spins on counts_out[2] instead of copying)? then its device alias
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, counts_out) == hipSuccess) {
+      if (at.type == hipMemoryTypeHost && at.devicePointer) counts_out = static_cast<int64_t*>(at.devicePointer);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  const int use_bitmap = S <= kKeepBitmapMaxS ? 1 : 0;
+  const size_t smem = use_bitmap ? size_t((S + 31) / 32) * 4 + 16 : 16;
+  auto go = [&](auto kernel) -> int {
+    int rca = allow_big_lds(kernel, smem, "k_keep_positions", 128);
+    if (rca) return rca;
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(kKeepNT), smem, static_cast<hipStream_t>(stream), video_mask, S, kept,
+                       K_dev, K_max, visual_mask, keep_out, keep_out ? keep_cap : 0, vis_rows_out,
+                       vis_rows_out ? vis_cap : 0, counts_out, use_bitmap);
+    return VC2_OK;
+  };
+  // positions per thread held in registers: 16 / 32 / 64 (prompts up to 65 536 positions); longer ones re-read their chunks
+  const int64_t per = cdiv(S, kKeepNT);
+  int rcg = per <= 16 ? go(k_keep_positions<1>) : per <= 32 ? go(k_keep_positions<2>) : per <= 64 ? go(k_keep_positions<4>)
+                                                                                                 : go(k_keep_positions<0>);
+  if (rcg) return rcg;
   return check_launch("keep_positions");
 }
 

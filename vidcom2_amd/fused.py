@@ -17,6 +17,7 @@ Device tensors only: there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -112,6 +113,18 @@ def gather_scatter(srcs: Sequence[torch.Tensor], idx: Optional[torch.Tensor] = N
     return dsts
 
 
+_PINNED = threading.local()
+
+
+def _pinned_counts() -> torch.Tensor:
+    """Four pinned int64 words per thread for vc2_keep_positions' counts (used synchronously: the call spins until the
+    kernel has written them; never freed -- see vidcom2._KHost)."""
+    t = getattr(_PINNED, "counts", None)
+    if t is None:
+        t = _PINNED.counts = torch.zeros(4, dtype=torch.int64).pin_memory()
+    return t
+
+
 def keep_positions(video_mask: torch.Tensor, kept: torch.Tensor, n_video: Optional[int] = None,
                    visual_mask: Optional[torch.Tensor] = None,
                    n_visual: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
@@ -139,14 +152,19 @@ def keep_positions(video_mask: torch.Tensor, kept: torch.Tensor, n_video: Option
         if vis.numel() != S or vis.device != vm.device:
             raise RuntimeError("visual_mask must cover the same positions as video_mask")
         vis_rows = torch.empty(S, dtype=torch.int64, device=vm.device)
-    counts = torch.empty(3, dtype=torch.int64, device=vm.device)
+    # The counts / error word come back through pinned host memory the kernel stores to (no device-to-host copy: the
+    # host spins on the error word, which the kernel writes last) -- what the index lists are worth: torch indexing,
+    # which this replaces, raises on a bad index; an unchecked list would gather rows from wherever it points.
+    counts = _pinned_counts()
+    counts[2] = -1
     with on_device(vm.device):
         rc = lib().vc2_keep_positions(ptr(vm), S, ptr(kept), None, K, ptr(vis), ptr(keep), n_keep, ptr(vis_rows),
-                                      S if vis_rows is not None else 0, ptr(counts), stream_ptr(vm.device))
+                                      S if vis_rows is not None else 0, ctypes.c_void_p(counts.data_ptr()),
+                                      stream_ptr(vm.device))
     check(rc, "vc2_keep_positions")
-    # One small read-back (the kernel is a single workgroup): what the index lists are worth.  torch indexing -- what
-    # this replaces -- raises on a bad index; an unchecked list would gather rows from wherever it points.
-    found, found_vis, err = (int(v) for v in counts.tolist())
+    if int(lib().vc2_wait_host_count(ctypes.c_void_p(counts.data_ptr() + 16), 0.05)) < 0:
+        torch.cuda.current_stream(vm.device).synchronize()       # (a busy stream: the plain wait)
+    found, found_vis, err = (int(v) for v in counts[:3].tolist())
     if err:
         why = []
         if err & 1 or err & 8:

@@ -164,7 +164,8 @@ class CompressPlan:
             self._spare = self._alloc_outputs()
 
     def enqueue(self, flat: torch.Tensor, gather_src: Optional[torch.Tensor] = None,
-                tail: Optional[torch.Tensor] = None, have_stats: bool = False, mirror: bool = False) -> None:
+                tail: Optional[torch.Tensor] = None, have_stats: bool = False, mirror: bool = False,
+                stream: Optional["torch.cuda.Stream"] = None) -> None:
         """have_stats: `self.ws` already holds flat's sweep-1 partials (fused.pool_stats wrote them on this
         stream), so the pass starts at the variance reduction.  mirror: the count is also written to pinned host
         memory (finish(early=True))."""
@@ -196,7 +197,8 @@ class CompressPlan:
                                         src.shape[0], ptr(self.ws), self.ws.numel(), ptr(self.rows), ptr(self.idx),
                                         self.cap, ptr(self.ks), ptr(self.kout), ptr(self.v), ptr(self.f),
                                         ptr(tail if self.tail_rows else None), self.tail_rows,
-                                        1 if have_stats else 0, khost, stream_ptr(self.device))
+                                        1 if have_stats else 0, khost,
+                                        stream_ptr(self.device) if stream is None else ctypes.c_void_p(stream.cuda_stream))
         check(rc, "vc2_compress")
 
     def __del__(self):
@@ -424,17 +426,60 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2
     if not clips:
         return []
     dev = clips[0].device
-    cur = torch.cuda.current_stream(dev)
-    lanes = [cur] + [torch.cuda.Stream(dev) for _ in range(max(1, int(in_flight)) - 1)]
-    for st in lanes[1:]:
-        st.wait_stream(cur)                               # inputs were produced on the current stream
-    # Every clip's pass is enqueued without waiting for an earlier one: a lane's plan keeps its workspace (work on one
-    # stream is ordered) and takes fresh output tensors per clip, so the host never syncs inside the loop -- a sync
-    # per clip left the GPU idle for ~50 us per clip.  One copy at the end brings all the kept-token counts.
-    taken = []
     for i, x in enumerate(clips):
         if x.dim() != 2 or tpf <= 0 or x.shape[0] % int(tpf) != 0:
             raise RuntimeError(f"clip {i}: shape {tuple(x.shape)} is not [frames * {tpf}, dim]")
+    cur = torch.cuda.current_stream(dev)
+    lanes = [cur] + [torch.cuda.Stream(dev) for _ in range(max(1, min(int(in_flight), len(clips))) - 1)]
+    same = all(c.shape == clips[0].shape and c.dtype == clips[0].dtype and c.device == dev for c in clips)
+    if not same:
+        return _compress_batch_mixed(clips, int(tpf), base_scale, lanes, gather)
+    # Clips of one shape (the batched-eval case, BASELINE config 5): ONE plan per lane (workspace; work on a stream is
+    # ordered), ONE allocation per output kind for the whole batch -- each clip's pass writes its slice --, one
+    # device-to-host copy for all the counts at the end.  Round 4 looked a plan up, allocated six tensors and recorded
+    # them on the caller's stream PER CLIP: ~100 us of host work per clip, more than the 75 us a lane's share of the GPU
+    # time leaves -- 16 clips took 5.8 ms, slower than one at a time.
+    n, x0 = len(clips), clips[0]
+    F_, D_ = x0.shape[0] // int(tpf), x0.shape[1]
+    plans = []
+    for st in lanes:
+        with torch.cuda.stream(st):
+            plans.append(_cached_plan(F_, int(tpf), D_, x0.dtype, dev, base_scale, "linear", 0, False, gather, 0))
+    p0 = plans[0]
+    idx_all = torch.empty((n, p0.cap), dtype=torch.int64, device=dev)
+    ks_all = torch.empty((n, F_), dtype=torch.int64, device=dev)
+    rows_all = torch.empty((n, p0.cap, D_), dtype=x0.dtype, device=dev) if gather else None
+    kout_all = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    for st in lanes[1:]:
+        st.wait_stream(cur)               # inputs and these buffers belong to the caller's stream
+        for t in (idx_all, ks_all, rows_all, kout_all):
+            if t is not None:
+                t.record_stream(st)
+    for i, x in enumerate(clips):
+        plan = plans[i % len(lanes)]
+        plan.idx, plan.ks, plan.rows, plan.v, plan.f, plan.kout = idx_all[i], ks_all[i], (rows_all[i] if gather else None), None, None, kout_all[i]
+        plan.enqueue(x, stream=lanes[i % len(lanes)])
+    for st in lanes[1:]:
+        cur.wait_stream(st)               # results are safe to use on the current stream
+    for plan in plans:
+        plan.new_outputs()                # (the cached plans must not keep pointing into the batch's buffers)
+    words = kout_all.tolist()             # the single host sync of the batch
+    out = []
+    for i, (K, status) in enumerate(words):
+        if status:
+            _raise_status(int(status), p0.cap, int(K))
+        out.append(CompressionResult(rows_all[i, :K] if gather else None, idx_all[i, :K], ks_all[i], int(K), None, None))
+    return out
+
+
+def _compress_batch_mixed(clips, tpf: int, base_scale: float, lanes, gather: bool):
+    """compress_batch for clips of different shapes: a plan lookup and fresh outputs per clip."""
+    dev = clips[0].device
+    cur = lanes[0]
+    for st in lanes[1:]:
+        st.wait_stream(cur)                               # inputs were produced on the current stream
+    taken = []
+    for i, x in enumerate(clips):
         st = lanes[i % len(lanes)]
         with torch.cuda.stream(st):       # the plan's buffers are allocated (and owned) on the lane's stream
             plan = _cached_plan(x.shape[0] // int(tpf), int(tpf), x.shape[1], x.dtype, dev, base_scale, "linear", 0,
