@@ -58,10 +58,11 @@ const char* vc2_version(void);
  *                Reproduces the reference on every fixture (incl. the adversarial `cancel` ones) and every soak case.
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
  *   3            "proven": a PROVEN bound decides which centre means are replayed (forward error bound of torch's
- *                cascade relative to sum |x^|, bounded from sweep 1's statistics): flags 50x more means, costs a third
- *                more time; the test-suite runs every fixture in it as well and asserts the same results.
- *   1            "fast" (the default of rounds 1-3, now opt-in): the 16-ulp margin alone for all centre means.  ~1.6 %
- *                faster than mode 4; NOT bit-exact under cancellation (0.2 % of random `cancel` inputs differ in last-bit
+ *                cascade relative to sum |x^|, bounded from sweep 1's statistics): flags 50x more means, costs ~45 %
+ *                more time (256 against 178 us per pass at the target shape, round 5); the test-suite runs every fixture
+ *                in it as well and asserts the same results.
+ *   1            "fast" (the default of rounds 1-3, now opt-in): the 16-ulp margin alone for all centre means.  ~1 %
+ *                faster than mode 4 (176 against 178 us, round 5); NOT bit-exact under cancellation (0.2 % of random `cancel` inputs differ in last-bit
  *                f scores, rarely a kept index) -- no claim of reference parity is made for it.
  *   (2: debug -- every value is replayed.)
  * fp32 inputs are unaffected.  vc2_set_mode is PROCESS-WIDE (default 4) and also drops the calling thread's own
@@ -108,7 +109,11 @@ int vc2_gather_cols(const void* x, int64_t R, int64_t D, int dtype, const int64_
  * (cols NULL = all channels, C == D, i.e. x already holds the selected features, already in torch.topk
  * order).  spos = vc2_chan_select's output (needed for mode 1 when cols != NULL).  Sweeps 2 and 3 of X.
  * Outputs: v_T, f_T  T[F,N] (may be NULL), total_f32 fp32-widened RN_T(v+f) [F,N] (vidcom2.py:33),
- * s_f32[F] = -mean(v, -1) widened (vidcom2.py:32). */
+ * s_f32[F] = -mean(v, -1) widened (vidcom2.py:32).
+ * Cost note: in modes 3 and 4 (4 is the default) the frame-mean replay margins are bounded from the channel statistics
+ * of x, so this stage call runs the statistics sweep (sweep 1) over x itself before sweeps 2 and 3 -- three sweeps, where
+ * modes 0 / 1 take two.  The one-launch pass (vc2_compress*) and vc2_scores_phase1 behind vc2_chan_stats reuse sweep 1's
+ * partials instead. */
 int vc2_scores(const void* x, int64_t F, int64_t N, int64_t D, int dtype, const int32_t* cols,
                int64_t C, const int32_t* spos, void* ws, size_t ws_bytes, void* v_T, void* f_T,
                float* total_f32, float* s_f32, void* stream);

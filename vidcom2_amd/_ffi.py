@@ -188,8 +188,9 @@ def profile_collect() -> dict:
 
 # 'torch' = the library default (C mode 4): bit-exact to the CPU reference; the frame-mean replay margin has a term relative
 # to sum |x^| so that it grows under cancellation.  'torch_proven' (mode 3): a PROVEN error bound decides which centre
-# means are replayed -- same results (the parity suite asserts that on every fixture) at a third more time per pass.
-# 'torch_fast' (mode 1, the default of rounds 1-3): the 16-ulp empirical margin alone, ~3 % faster, NOT bit-exact on
+# means are replayed -- same results (the parity suite asserts that on every fixture) at ~45 % more time per pass (round 5:
+# 256 against 178 us at the target shape).
+# 'torch_fast' (mode 1, the default of rounds 1-3): the 16-ulp empirical margin alone, ~1 % faster, NOT bit-exact on
 # adversarial cancellation inputs -- opt-in, no parity claim.  ('torch_robust': the name mode 4 had while it was opt-in.)
 MODE_CODE = {"exact": 0, "torch": 4, "torch_fast": 1, "torch_proven": 3, "torch_robust": 4}
 

@@ -1979,7 +1979,9 @@ struct FrameReplay {
   float* fc; int N;
   FrameFix fix;
   const uint32_t* list2; const int* count2; int cap2;   // correction entries frame * nbx + column block: taken FIRST (the
-};                                                      // longest items -- a block's sums, margins, then its replays one by one)
+                                                        // longest items -- a block's sums, margins, then its replays one by one)
+  const int* fmark;    // per frame: non-zero = the frame has correction entries, which redo ALL of its means (with the corrected
+};                     //   sums) -- its regular entries are skipped: two waves would otherwise store the same fc word in either order
 template <int DT>
 __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid, int nrid, float* xs,
                                                   const void* __restrict__ x, int D, int C,
@@ -2013,6 +2015,7 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
     if (e >= cnt2) {
       const uint32_t ent = r.list[e - cnt2];
       const int ff = int(ent / uint32_t(C));
+      if (r.fmark && cnt2 > 0 && r.fmark[ff] != 0) continue;      // (its correction entries answer for the whole frame)
       replay_one(ff, int(ent - uint32_t(ff) * uint32_t(C)));
       continue;
     }
@@ -2043,12 +2046,20 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
       }
       const int col = cols ? cols[c] : c;
       const int nc = *m.corr_count;
-      for (int e2 = 0; e2 < nc; ++e2) {
-        if (m.corr[e2].frame == f) {
-          const float v = ldT<DT>(x, int64_t(m.corr[e2].row) * D + col);
-          const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(m.corr[e2].den_old)));
-          const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(m.corr[e2].den_new)));
-          sf += double(xn) - double(xo);
+      for (int e0 = 0; e0 < nc; e0 += 8) {                        // (eight entries' loads in flight; added in entry order)
+        NormCorr nc8[8];
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nc8[u] = m.corr[min(e0 + u, nc - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = ldT<DT>(x, int64_t(nc8[u].row) * D + col);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (e0 + u < nc && nc8[u].frame == f) {
+            const float xo = rnT<DT>(div_via_f64(v8[u], 1.0 / double(nc8[u].den_old)));
+            const float xn = rnT<DT>(div_via_f64(v8[u], 1.0 / double(nc8[u].den_new)));
+            sf += double(xn) - double(xo);
+          }
         }
       }
       r.fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
@@ -2148,11 +2159,21 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
       }
     }
     // fused centre launch: the group sums were formed before the norm fix-ups -> their corrections are added here
-    for (int e = 0; e < nvc; ++e) {                               // (normally none)
-      const float v = ldT<DT>(x, int64_t(vcorr[e].row) * D + my_col);
-      const float xo = rnT<DT>(div_via_f64(v, 1.0 / double(vcorr[e].den_old)));
-      const float xn = rnT<DT>(div_via_f64(v, 1.0 / double(vcorr[e].den_new)));
-      t += double(xn) - double(xo);
+    for (int e0 = 0; e0 < nvc; e0 += 8) {                         // (bf16: normally none; fp16: ~16 at the cfg5 shape -- eight
+      NormCorr nc8[8];                                            //  entries' loads in flight: one by one they cost 0.5 us each)
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nc8[u] = vcorr[min(e0 + u, nvc - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = ldT<DT>(x, int64_t(nc8[u].row) * D + my_col);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (e0 + u < nvc) {
+          const float xo = rnT<DT>(div_via_f64(v8[u], 1.0 / double(nc8[u].den_old)));
+          const float xn = rnT<DT>(div_via_f64(v8[u], 1.0 / double(nc8[u].den_new)));
+          t += double(xn) - double(xo);
+        }
+      }
     }
     if (y == 0) vc[c] = mean_T<DT>(t, R);
     q = float(t) / float(R);
@@ -4111,7 +4132,8 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                  (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, fs,
                                  wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr)},
                         fused ? wsp<uint32_t>(ws, p.o_rlist) + rcap : (const uint32_t*)nullptr,
-                        wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2};
+                        wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2,
+                        fused ? wsp<int>(ws, p.o_fmark) : (const int*)nullptr};
   static const int env_rw = [] { const char* e = getenv("VC2_REPLAY_WAVES"); return e ? atoi(e) : 0; }();
   const int rwaves = env_rw > 0 ? env_rw : cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 4096 : 1024);   // rider waves (debug mode 2 replays every mean; fp16 lists ~8x bf16's)
   if (single_rank) {

@@ -156,6 +156,20 @@ class CompressPlan:
         spare, self._spare = self._spare, None
         self.idx, self.ks, self.rows, self.v, self.f, self.kout = spare if spare is not None else self._alloc_outputs()
 
+    def output_bytes(self) -> int:
+        """Bytes of ONE output set (kept rows, indices, budgets, scores, status words)."""
+        es = torch.empty(0, dtype=self.dtype).element_size()
+        n = self.cap * 8 + self.F * 8 + 16
+        if self._gather:
+            n += (self.cap + self.tail_rows) * self.D * es
+        if self._want_scores:
+            n += 2 * self.F * self.N * es
+        return n
+
+    def cached_bytes(self) -> int:
+        """What a cached plan keeps alive: workspace, the last output set, the spare one."""
+        return int(self.ws.numel()) + self.output_bytes() * (2 if self._spare is not None else 1)
+
     def prepare_spare(self) -> None:
         """Allocate the NEXT call's output tensors now -- called by the one-shot API between enqueue and finish, i.e.
         while the GPU is busy with this pass -- so that the next call launches its first kernel ~25 us earlier (five
@@ -276,7 +290,8 @@ class CompressPlan:
 # another stream or thread gets its own plan.  Outputs are NOT cached (CompressPlan.new_outputs).
 _PLAN_CACHE: "collections.OrderedDict" = collections.OrderedDict()
 _PLAN_CACHE_MAX = int(os.environ.get("VC2_PLAN_CACHE", "8"))       # 0 disables the cache
-_PLAN_CACHE_BYTES = int(os.environ.get("VC2_PLAN_CACHE_MB", "1024")) << 20   # workspaces kept alive by the cache
+_PLAN_CACHE_BYTES = int(os.environ.get("VC2_PLAN_CACHE_MB", "1024")) << 20   # workspaces + output sets kept alive by the cache
+_SPARE_MAX_BYTES = int(os.environ.get("VC2_SPARE_MAX_MB", "256")) << 20      # no spare output set beyond this size
 _PLAN_LOCK = threading.Lock()
 _EARLY_COUNT = os.environ.get("VC2_EARLY_COUNT", "1") != "0"        # one-shot calls take K from a pinned host mirror (vc2_compress_ex2)
 _PREALLOC = os.environ.get("VC2_PREALLOC", "1") != "0"             # next call's outputs allocated while this pass runs
@@ -300,8 +315,9 @@ def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores
             with _PLAN_LOCK:
                 _PLAN_CACHE[key] = plan
                 # bounded by entries AND by bytes (a long clip's workspace is hundreds of MB): oldest first
+                # (a cached plan keeps its workspace AND its last output set, plus a spare one: all counted)
                 while len(_PLAN_CACHE) > _PLAN_CACHE_MAX or \
-                        (len(_PLAN_CACHE) > 1 and sum(p.ws.numel() for p in _PLAN_CACHE.values()) > _PLAN_CACHE_BYTES):
+                        (len(_PLAN_CACHE) > 1 and sum(p.cached_bytes() for p in _PLAN_CACHE.values()) > _PLAN_CACHE_BYTES):
                     _PLAN_CACHE.popitem(last=False)
     else:
         plan.new_outputs()
@@ -411,7 +427,7 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
     else:
         plan = _cached_plan(R // tpf, tpf, D, x.dtype, x.device, base_scale, mapper, grid_h, want_scores, gather, ntail)
     plan.enqueue(x, src, tail, have_stats=stats_ws is not None, mirror=_EARLY_COUNT)
-    if stats_ws is None and _PREALLOC:
+    if stats_ws is None and _PREALLOC and _PLAN_CACHE_MAX > 0 and plan.output_bytes() <= _SPARE_MAX_BYTES:
         plan.prepare_spare()              # (the GPU is busy for the next ~190 us: the next call's outputs cost nothing here)
     return plan.finish()
 
