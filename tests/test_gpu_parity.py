@@ -549,6 +549,57 @@ def test_adversarial_centre_means(c, mode):
     assert synth.sha256_tensor(got.v_score) == c["v_sha256"] and synth.sha256_tensor(got.f_score) == c["f_sha256"]
 
 
+@pytest.mark.parametrize("c", [c for c in ADV if c["D"] in (1024, 3584)], ids=lambda c: f"ord-{c['F']}x{c['N']}x{c['D']}-{c['dtype']}")
+def test_torch_ordered_frame_sums_reproduce_the_reference(c):
+    """VC2_S2_ORD=1 (opt-in): sweep 2 adds every frame's x^ in torch's own order (16-row blocks, k_norm_colsum2<.., ORD>)
+    and k_frame_centres combines the block sums the way torch's cascade does -- no margin, no replay for any frame
+    mean.  A completely different route to the same bits: on the adversarial `cancel` inputs (the reference's own centres
+    are decided by the summation order in up to 335 places) it must reproduce the reference exactly, like the default
+    form with its margins and replays does."""
+    import os
+    x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
+    old = os.environ.get("VC2_S2_ORD")
+    try:
+        os.environ["VC2_S2_ORD"] = "1"
+        got = vc.compress(x.to(dev()), c["N"], c["base"], want_scores=True)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["VC2_S2_ORD"]
+        else:
+            os.environ["VC2_S2_ORD"] = old
+    assert got.ks.cpu().tolist() == c["ks"]
+    assert got.global_idx.cpu().tolist() == c["global_idx"]
+    assert synth.sha256_tensor(got.v_score) == c["v_sha256"] and synth.sha256_tensor(got.f_score) == c["f_sha256"]
+
+
+@pytest.mark.parametrize("shape", [(5, 169, 1024, "bf16", "drift"), (3, 100, 1024, "f16", "cancel"), (9, 324, 1024, "bf16", "iid"),
+                                   (4, 16, 1024, "f16", "drift"), (6, 7, 1024, "bf16", "cancel"), (2, 512, 1024, "f16", "iid"),
+                                   (40, 33, 1024, "bf16", "cancel"), (130, 48, 1024, "f16", "drift")],
+                         ids=lambda s_: "x".join(map(str, s_)))
+def test_torch_ordered_frame_sums_on_odd_frame_lengths(shape):
+    """The ORD form against the oracle where its geometry has corners: frames of 9 / 4 leftover rows, none, fewer than one
+    block, 32 blocks, more blocks than a workgroup's waves, several blocks per wave (many frames)."""
+    import os
+    F, N, D, dn, dist = shape
+    x = make_input(F, N, D, dn, 11, dist)
+    O.set_mode("torch")
+    ref = O.compress_indices(x, N, 0.25)
+    old = os.environ.get("VC2_S2_ORD")
+    try:
+        os.environ["VC2_S2_ORD"] = "1"
+        got = vc.compress(x.to(dev()), N, 0.25, want_scores=True)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["VC2_S2_ORD"]
+        else:
+            os.environ["VC2_S2_ORD"] = old
+    assert nan_eq(got.v_score, ref["v"]) and nan_eq(got.f_score, ref["f"])
+    assert got.ks.cpu().tolist() == ref["ks"].tolist()
+    assert torch.equal(got.global_idx.cpu(), ref["global_idx"])
+
+
 @pytest.mark.parametrize("shape", [(1024, 16, 256, "bf16"), (300, 7, 128, "f16"), (640, 40, 512, "bf16"), (97, 33, 192, "f16"),
                                    (2000, 4, 64, "bf16")], ids=lambda s_: "x".join(map(str, s_)))
 def test_many_short_frames(shape):

@@ -1267,6 +1267,11 @@ __device__ __forceinline__ f2_t pk_fnma_f32(f2_t a, f2_t b, f2_t c) {   // c - a
   asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+__device__ __forceinline__ f2_t pk_add_f32(f2_t a, f2_t b) {
+  f2_t r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ f2_t pk_mul_f32(f2_t a, f2_t b) {
   f2_t r;
   asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -1286,12 +1291,13 @@ constexpr float kS2NormHiF16 = 32768.f;
 #endif
 constexpr int kS2CombineRounds = VC2_S2_WAVES >= 3 ? 4 : 2;      // (3 workgroups per CU: 4 NCH + 2 NCH KiB of LDS each)
 __host__ inline size_t s2v2_lds(int nch) { return size_t(kRowWaves) * nch * 1024 + size_t(kRowWaves) * (4 * nch / kS2CombineRounds) * 64 * 8; }
-template <int DT, int NCH, int RIDER>
+template <int DT, int NCH, int RIDER, int ORD>
 __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(const void* __restrict__ x, int N, const int* __restrict__ cols,
                                                                  int strict, int S, int q, int64_t R,
                                                                  float* __restrict__ den_out, double* __restrict__ part,
                                                                  int* __restrict__ tk, unsigned long long* __restrict__ fixq,
-                                                                 int nfix_cap, uint8_t* __restrict__ rflag, OrderArgs rider) {
+                                                                 int nfix_cap, uint8_t* __restrict__ rflag, OrderArgs rider,
+                                                                 float* __restrict__ bsum, int ord_m) {
   static_assert(DT == VC2_BF16 || DT == VC2_F16, "16-bit inputs");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int D = NCH * 512, C = D / 2, NPLB = NCH * 4, NP = NCH * 2, ROWB = NCH * 1024;
@@ -1311,7 +1317,29 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // (rows fit 31 bits: the launch checks R < 2^31; 32-bit uniform arithmetic keeps the index math in a few SALU instructions)
   const int Rr = int(R);
-  const int row_a = bid * q, row_b = min(Rr, row_a + q);
+  // ORD (round 5, frames of N <= 512 tokens): the frame means in TORCH'S OWN ORDER, natively.  Workgroup `bid` = piece
+  // bid % S of frame bid / S; a wave takes ord_m CONSECUTIVE 16-row blocks of the frame (torch's outer-sum cascade adds
+  // a frame's rows in blocks of 16: SumKernel.cpp, level_power 4) and sweeps their rows in order, adding every x^ to a
+  // second, fp32, accumulator per column -- sequentially, as torch does -- that is stored per block (bsum[f][block][c];
+  // index N / 16: the chain of the N % 16 leftover rows, taken by the wave that owns the last block).
+  // k_frame_centres combines the block sums the way torch combines them: EVERY frame mean is torch's bit pattern by
+  // construction -- no margins, no list of boundary-near means, no replays (bf16 replayed ~400 of them per pass, fp16
+  // ~3300: k_video_centre 39 us at the cfg5 shape).  The fp64 column sums stay: the video centre is formed from them.
+  const int nblk = N >> 4, ntail = N & 15;
+  int row_a, row_b, ord_f = 0, ord_b0 = 0, ord_b1 = 0, ord_r0 = 0, ord_cnt = 0;
+  if constexpr (ORD != 0) {
+    ord_f = bid / S;
+    const int j = bid - ord_f * S;
+    ord_b0 = min(nblk, (kRowWaves * j + wave) * ord_m);
+    ord_b1 = min(nblk, ord_b0 + ord_m);
+    const bool owns_tail = ntail != 0 && (nblk == 0 ? (j == 0 && wave == 0) : (ord_b0 < nblk && ord_b1 == nblk));
+    ord_r0 = ord_f * N + 16 * ord_b0;
+    ord_cnt = 16 * (ord_b1 - ord_b0) + (owns_tail ? ntail : 0);
+    if (nblk == 0 && owns_tail) ord_r0 = ord_f * N;
+    row_a = ord_f * N; row_b = min(Rr, row_a + N);
+  } else {
+    row_a = bid * q; row_b = min(Rr, row_a + q);
+  }
   // LDS: [kRowWaves] row buffers (ONE per wave: the row is in registers before the next one is asked for), then the
   // scratch of the cross-wave combine, [kRowWaves][NPLB / 2][64] doubles (= kRowWaves * ROWB bytes), used in two rounds
   unsigned char* wbuf = smem + size_t(wave) * ROWB;
@@ -1328,10 +1356,10 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
     }
     return -1;
   };
-  const int f_a = row_a / N;                                      // the chunk's first frame
+  const int f_a = ORD ? ord_f : row_a / N;                        // the chunk's first frame
   // the wave's first row is on its way before anything else is fetched
   {
-    const int first = first_row_from(row_a, f_a);
+    const int first = ORD ? (ord_cnt > 0 ? ord_r0 : -1) : first_row_from(row_a, f_a);
     if (VC2_S2_PROBE != 2 && first >= 0) s2_issue_row<NCH>(row_src(first), wbuf);
   }
   // LDS byte address of the lane's elements: pair k = compact positions 128 k + 2 lane, + 1
@@ -1348,12 +1376,14 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   const int margin_fast = kFragileUlpsNorm + acc_norm_ulps(NPLB);
 
+  constexpr int RS = ORD ? 1 : kRowWaves;                          // the wave's rows: r0 + RS i, i < cnt
+  f2_t chain[ORD ? NP : 1];                                       // (ORD) the fp32 chains of the block under way
   int f = f_a;
   for (int seg_a = row_a; seg_a < row_b; ++f) {
     const int seg_b = min(row_b, (f + 1) * N);
-    const int sp = bid - (f * N) / q;
-    const int r0 = seg_a + wave;                                  // this wave's rows: r0 + 4 i, i < cnt
-    const int cnt = r0 < seg_b ? (seg_b - r0 + kRowWaves - 1) / kRowWaves : 0;
+    const int sp = ORD ? bid - f * S : bid - (f * N) / q;
+    const int r0 = ORD ? ord_r0 : seg_a + wave;
+    const int cnt = ORD ? ord_cnt : (r0 < seg_b ? (seg_b - r0 + kRowWaves - 1) / kRowWaves : 0);
     double acc[NPLB];
 #pragma unroll
     for (int i = 0; i < NPLB; ++i) acc[i] = 0.0;
@@ -1362,7 +1392,7 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
     uint32_t pk_meta = 0u;                                        // bit 0: norm next to a T rounding boundary, bit 1: exact division
     auto flush = [&](int first, int count) {                      // rows r0 + 4 (first + j), j < count
       const bool mine = lane < count;
-      const int row = r0 + kRowWaves * (first + lane);
+      const int row = r0 + RS * (first + lane);
       if (mine) {
         den_out[row] = pk_dn;
         if (rflag) rflag[row] = uint8_t((pk_meta >> 1) & 1u);
@@ -1401,7 +1431,7 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
       for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(XA[k]), "+v"(XB[k]));   // (the loads' results: not before the wait)
       // the row is in registers: its buffer takes the wave's NEXT row (of this segment, else of a later one) right away
       if (VC2_S2_PROBE != 2) {
-        const int nr = i + 1 < cnt ? r0 + kRowWaves * (i + 1) : first_row_from(seg_b, f + 1);
+        const int nr = i + 1 < cnt ? r0 + RS * (i + 1) : (ORD ? -1 : first_row_from(seg_b, f + 1));
         if (nr >= 0) s2_issue_row<NCH>(row_src(nr), wbuf);
       }
       if (VC2_S2_PROBE == 1 || VC2_S2_PROBE == 3) {               // (keep the loads alive, skip the arithmetic)
@@ -1462,20 +1492,31 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
           }
         }
       }
+      // (ORD) a block's chain starts as an ASSIGNMENT of its first row in torch (a = p[0]; a += p[1] ...): -0.f + v == v
+      // for every v, signed zeros included; the leftover rows' chain starts from +0.f (r = 0; r += ...)
+      if constexpr (ORD != 0) {
+        const int ib = i - 16 * (ord_b1 - ord_b0);                 // >= 0: a leftover row
+        if ((ib < 0 && (i & 15) == 0) || ib == 0) {
+          const float z = ib == 0 ? 0.f : -0.f;
+#pragma unroll
+          for (int k = 0; k < NP; ++k) chain[k] = (f2_t){z, z};
+        }
+      }
       uint32_t meta;
       if (ok) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
+          f2_t w;
           if constexpr (DT == VC2_BF16) {
-            acc[2 * k] += double(__uint_as_float(Q[k] << 16));
-            acc[2 * k + 1] += double(__uint_as_float(Q[k] & 0xFFFF0000u));
+            w = (f2_t){__uint_as_float(Q[k] << 16), __uint_as_float(Q[k] & 0xFFFF0000u)};
           } else {
             union { uint32_t u; h2_t h; } c;
             c.u = Q[k];
-            const f2_t w = __builtin_convertvector(c.h, f2_t);
-            acc[2 * k] += double(w.x);
-            acc[2 * k + 1] += double(w.y);
+            w = __builtin_convertvector(c.h, f2_t);
           }
+          acc[2 * k] += double(w.x);
+          acc[2 * k + 1] += double(w.y);
+          if constexpr (ORD != 0) chain[k] = pk_add_f32(chain[k], w);
         }
         meta = (strict == 2 || near_T_boundary<DT>(nrm32, margin_fast)) ? 1u : 0u;
       } else {
@@ -1497,16 +1538,30 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
         const double inv = 1.0 / double(dn);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-          const double va = double(rnT<DT>(div_via_f64(XA[k], inv)));
-          const double vb = double(rnT<DT>(div_via_f64(XB[k], inv)));
+          const float fa = rnT<DT>(div_via_f64(XA[k], inv)), fb = rnT<DT>(div_via_f64(XB[k], inv));
+          const double va = double(fa), vb = double(fb);
           asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc[2 * k]) : "v"(va));     // (asm: keeps the two paths' adds apart --
           asm volatile("v_add_f64 %0, %0, %1" : "+v"(acc[2 * k + 1]) : "v"(vb)); //  merged, they cost 4 NCH register pairs)
+          if constexpr (ORD != 0) chain[k] = pk_add_f32(chain[k], (f2_t){fa, fb});
           if (k + 1 < NP) asm volatile("" : "+v"(XA[k + 1]), "+v"(XB[k + 1]));
         }
         meta = ((strict == 2 || near_T_boundary<DT>(n32, kFragileUlpsNorm)) ? 1u : 0u) | 2u;
       }
       if (lane == (i & 63)) { pk_dn = dn; pk_meta = meta; }
       if ((i & 63) == 63) flush(i - 63, 64);
+      if constexpr (ORD != 0) {
+        const int ib = i - 16 * (ord_b1 - ord_b0);
+        if ((ib < 0 && (i & 15) == 15) || i == cnt - 1) {          // a block (or the leftover chain) is complete
+          const int blk = ib < 0 ? ord_b0 + (i >> 4) : nblk;
+          float* dst = bsum + (size_t(uint32_t(f * (nblk + 1) + blk))) * C + 2 * lane;
+#ifndef VC2_ORD_PROBE_NOSTORE
+#pragma unroll
+          for (int k = 0; k < NP; ++k) *reinterpret_cast<f2_t*>(dst + 128 * k) = chain[k];
+#else
+          if (chain[0].x == 12345.678f) *dst = chain[1].x;
+#endif
+        }
+      }
     }
     if (cnt & 63) flush(cnt & ~63, cnt & 63);
 #ifdef VC2_DEBUG_TIMING
@@ -1736,6 +1791,69 @@ __device__ __forceinline__ float lds_column_short(const float* xs, bool simple, 
 // No global queues, no separate fix-up kernel.
 constexpr int kCen2List = 1024;
 
+// ORD (round 5): sweep 2 left, per frame and 16-row block, the fp32 sum of the block's x^ added in row order, and the chain
+// of the N % 16 leftover rows (k_norm_colsum2<.., ORD = 1>; bsum[f][N / 16 + 1][C]).  Torch's outer-sum cascade of a frame
+// (N <= 512: at most two level-1 groups) from them, exactly as lds_cascade_short combines the same quantities: groups of
+// 16 block sums in order (the first one assigned), the complete groups' sums added to acc2 from zero, the partial group
+// = acc1, then ((leftover chain + acc1) + acc2) + 0.  A block that holds a row whose denominator a norm fix-up changed
+// (corr, nc entries: normally none) is recomputed from x and the final den[].
+struct OrdSrc { const float* bsum; int on; };
+template <int DT>
+__device__ __attribute__((noinline)) float ord_frame_sum(const float* __restrict__ bsum, int f, int c, int C, int N, int nc,
+                                               const NormCorr* __restrict__ corr, const void* __restrict__ x, int D, int col,
+                                               const float* __restrict__ den) {
+  const int nb = N >> 4, ntail = N & 15;                          // nb <= 32
+  const float* __restrict__ bs = bsum + size_t(uint32_t(f * (nb + 1))) * C + c;
+  float v[33];
+#pragma unroll
+  for (int b = 0; b < 33; ++b) v[b] = bs[size_t(b <= nb ? b : nb) * C];       // (all in flight; entry nb: the leftover chain)
+  if (ntail == 0) v[32] = 0.f;                                   // (read below only through index nb)
+  unsigned long long dirty = 0ull;
+  for (int e = 0; e < nc; ++e)
+    if (corr[e].frame == f) { const int b = (corr[e].row - f * N) >> 4; dirty |= 1ull << (b < nb ? b : nb); }
+  float tail = 0.f;                                              // v[nb] without a run-time register index
+#pragma unroll
+  for (int b = 0; b < 33; ++b) if (b == nb) tail = ntail ? v[b] : 0.f;
+  if (dirty) {                                                   // (wave-uniform: f is)
+#pragma unroll
+    for (int b = 0; b < 33; ++b) {
+      if (b <= nb && ((dirty >> b) & 1ull)) {
+        const int64_t r0 = int64_t(f) * N + 16 * b;
+        float xv[16];                                             // (sixteen loads in flight, then the adds in row order)
+        const int nel = b < nb ? 16 : ntail;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xv[u] = xhat_at<DT>(x, r0 + (u < nel ? u : nel - 1), D, col, den);
+        if (b < nb) {
+          float a = xv[0];
+#pragma unroll
+          for (int u = 1; u < 16; ++u) a += xv[u];
+          v[b] = a;
+        } else {
+          float r = 0.f;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) if (u < ntail) r += xv[u];
+          tail = r;
+        }
+      }
+    }
+  }
+  float acc2 = 0.f, acc1 = 0.f;
+  const int n1c = nb >> 4;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int cnt = nb - 16 * g < 16 ? nb - 16 * g : 16;
+    if (cnt > 0) {
+      float t = v[16 * g];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) if (u < cnt) t += v[16 * g + u];
+      if (g < n1c) acc2 += t; else acc1 = t;
+    }
+  }
+  float r = tail;
+  r += acc1; r += acc2; r += 0.f;
+  return r;
+}
+
 // where sweep 1's partials of this rank's frames live (part == nullptr: none): group g = piece g % splits of frame
 // g / splits holds (sum (x - K), sum (x - K)^2) per channel, K = the first row of the frame's stat block
 struct FrameStatSrc {
@@ -1814,7 +1932,8 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
                                                                    int* __restrict__ vtick, FrameStatSrc fs,
                                                                    double kk, int want_bounds,
                                                                    float* __restrict__ dmin_out, double kk_a,
-                                                                   uint32_t* __restrict__ rlist, int rcap, FixRiders fr) {
+                                                                   uint32_t* __restrict__ rlist, int rcap, FixRiders fr,
+                                                                   OrdSrc ord = OrdSrc{nullptr, 0}) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fix_rows[];     // riders: kFixWaves row buffers
   __shared__ double sm[kCentreFL][64];
   __shared__ double sb[kCentreFL][64];
@@ -1882,7 +2001,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   const int cq = min(c, C - 1), fq = min(f, F - 1);
   const int col = cols ? cols[cq] : cq;
   // this frame's segments: one per sweep-2 chunk that meets it (make_plan)
-  const int Sf = int((int64_t(fq + 1) * N - 1) / S_q) - int((int64_t(fq) * N) / S_q) + 1;
+  const int Sf = ord.on ? S : int((int64_t(fq + 1) * N - 1) / S_q) - int((int64_t(fq) * N) / S_q) + 1;   // (ORD: S pieces per frame)
   double v0[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) v0[u] = part[(int64_t(fq) * S + min(u, Sf - 1)) * C + cq];
@@ -1924,16 +2043,19 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
         sf += double(xn) - double(xo);
       }
     }
-    fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
+    if (ord.on) fc[int64_t(f) * C + c] = rnT<DT>(ord_frame_sum<DT>(ord.bsum, f, c, C, N, nc, corr, x, D, col, den) / float(N));
+    else fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
     q = float(sf) / float(N);
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(501);
-  if (replay) {
+  if (replay && !(ord.on && !bounded)) {                          // (ORD: the means are final; only the bounds of sum |x^| may be wanted)
     if (bounded && dmin_out && blockIdx.x == 0 && cl == 0 && f < F) dmin_out[f] = dmin;     // (k_video_centre's lazy bounds)
     if (active && frame_mean_near<DT>(q, bounded, all, strict, kk, kk_a, want_bounds != 0, fs, f, col, x, D, N,
                                       dmin, ab, pre_stats ? &ssq_pre : nullptr)) {
-      const int j = atomicAdd(&count, 1);
-      if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
+      if (!ord.on) {
+        const int j = atomicAdd(&count, 1);
+        if (j < kCen2List) flist[j] = uint32_t(fl) * 64u + uint32_t(cl);
+      }
     }
   }
   if (tid == 0 && g == 0 && blockIdx.x == 0) VC2_STAMP(503);
@@ -1973,6 +2095,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
 struct FrameFix {
   const double* part; int S, S_q, strict; double kk, kk_a; FrameStatSrc fs;
   const int* corr_count; const NormCorr* corr;
+  OrdSrc ord;
 };
 struct FrameReplay {
   const uint32_t* list; const int* count; int cap;   // entries frame * C + column (count may exceed cap: never written beyond)
@@ -2026,6 +2149,13 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
     const int f = int(ent / uint32_t(nbx)), bx = int(ent - uint32_t(f) * uint32_t(nbx));
     const int c = bx * 64 + lane;
     const bool active = c < C, all = m.strict == 2;
+    if (m.ord.on) {                                               // ORD: the block sums, the corrected rows' blocks redone
+      if (active) {
+        const int col = cols ? cols[c] : c;
+        r.fc[int64_t(f) * C + c] = rnT<DT>(ord_frame_sum<DT>(m.ord.bsum, f, c, C, N, *m.corr_count, m.corr, x, D, col, den) / float(N));
+      }
+      continue;
+    }
     const bool bounded = m.strict == 3 || m.kk_a > 0.0;
     float dmin = INFINITY;
     if (bounded) {
@@ -3625,13 +3755,14 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups (G = F * stat_splits), stat blocks
   int stat_splits, NB, BF;      // groups per frame; stat blocks of BF (<= kStatBlockFrames) frames
   int64_t F_total;              // frames of the WHOLE video (frame-sharded pass: canonical blockings depend on it)
+  int ord_S, ord_m;             // sweep 2, ORD form (k_norm_colsum2<.., ORD>): ord_S workgroups per frame, ord_m 16-row blocks per wave (0: n/a)
   int S, S_q, S_W;              // sweep 2: S_W chunks of S_q consecutive rows (frame boundaries inside a chunk cut it in
                                 //   segments); a frame's segments fill its first slots of S in `part`
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
   int skew2_q10;                // how much the first split of a frame exceeds the mean, in 1/1024 (k_dist)
   // workspace offsets (bytes)
   size_t o_part_stats, o_stats, o_bstats, o_var_f32, o_var_T, o_mask, o_cols, o_order, o_opos, o_spos, o_perm, o_den, o_part_col, o_fc, o_csum, o_csum_part, o_vc,
-      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_fmark, o_tmp_f32, o_rlist, total_bytes;
+      o_rflag, o_vpart, o_total, o_s, o_zbuf, o_scales_f32, o_scales_T, o_offs, o_ticket, o_nfixlist, o_corr, o_vscratch, o_vticket, o_dmin, o_fmark, o_tmp_f32, o_rlist, o_bsum, total_bytes;
   int vstride;
 };
 
@@ -3691,6 +3822,16 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
     p->S_q = int(q);
     p->S_W = int(cdiv(p->R, q));
     p->S = int(std::min<int64_t>(8, (N - 1) / q + 2));
+    // the ORD form (torch-ordered frame sums, see k_norm_colsum2): frames of <= 512 tokens, the streamlined sweep's
+    // shapes, every frame workgroup resident next to the riders
+    p->ord_S = p->ord_m = 0;
+    if (cur_mode() != 0 && dt != VC2_F32 && (D == 1024 || D == 3584 || D == 4096) && N <= 512) {
+      const int64_t nblk = std::max<int64_t>(1, N / 16);
+      for (int64_t m = 1; m <= cdiv(nblk, kRowWaves); ++m) {
+        const int64_t S_o = cdiv(nblk, kRowWaves * m);
+        if (S_o <= 8 && F * S_o <= 512 - riders) { p->ord_S = int(S_o); p->ord_m = int(m); break; }
+      }
+    }
   }
   {
     // sweep 3: one workgroup per (frame, split); ~1024 workgroups when the video allows, and at most 25 rows each so
@@ -3754,6 +3895,7 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->o_vticket = take(size_t(D) * 4);
   p->o_dmin = take(size_t(F) * 4);                 // per frame: the smallest denominator (centre-mean margins)
   p->o_tmp_f32 = take(size_t(std::max<int64_t>(p->R, D)) * 4);
+  p->o_bsum = take(p->ord_m > 0 ? size_t(F) * size_t(N / 16 + 1) * size_t(D / 2) * 4 : 0);   // (ORD) frame block sums, fp32
   p->o_rlist = take(size_t(2) * F * D * 4);        // frame means to replay: frame * C + column (k_frame_centres / fix riders -> frame_replay_wave)
   p->total_bytes = o;
   return VC2_OK;
@@ -3955,16 +4097,41 @@ inline int s2v2_nch(const Plan& p, const ChanSet& cs) {
   const int nch = int(p.D / 512);
   return (nch == 2 || nch == 7 || nch == 8) ? nch : 0;
 }
+// the ORD form of sweep 2 + centre kernels (torch-ordered frame sums): when the plan has a geometry for it and the
+// streamlined sweep applies.  OPT-IN (environment VC2_S2_ORD=1): bit-identical results (the whole parity suite passes
+// with it, no frame mean is ever replayed), but a wave must sweep whole 16-row blocks, which leaves 384 workgroups of
+// 64 / 68 rows where the row-interleaved form has 448 of 56 -- the busiest CU streams 132 rows instead of 112: sweep 2
+// 30.6 -> 34.7 us at the target shape, more than the centre kernels win there (fp16: -14 us in k_video_centre, +9 in the
+// sweep).  NOTES_r05.md.
+#ifndef VC2_S2_ORD_DEFAULT
+#define VC2_S2_ORD_DEFAULT 0
+#endif
+inline bool ord_on(const Plan& p, const ChanSet& cs) {
+  const char* e = getenv("VC2_S2_ORD");                          // (read per pass: the test-suite runs both forms in one process)
+  return (e ? atoi(e) : VC2_S2_ORD_DEFAULT) != 0 && p.ord_m > 0 && s2v2_nch(p, cs) != 0;
+}
 template <int DT, int NCH>
 int launch_norm_v2(const Plan& p, const void* x, const ChanSet& cs, void* ws, const OrderArgs& rider, hipStream_t st) {
   size_t smem = s2v2_lds(NCH);                                                     // row buffers + the combine's scratch
   if (rider.perm) smem = std::max(smem, chan_order_lds(rider.D, rider.k, 4));      // the rider workgroup's arrays
-  int rc = allow_big_lds(&k_norm_colsum2<DT, NCH, 1>, smem, "k_norm_colsum2");
+  const unsigned nr = rider.perm ? unsigned(rider.parts & 0xFF) : 0u;
+  if (ord_on(p, cs)) {
+    int rc = allow_big_lds(&k_norm_colsum2<DT, NCH, 1, 1>, smem, "k_norm_colsum2");
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_norm_colsum2<DT, NCH, 1, 1>), dim3(unsigned(p.F * p.ord_S) + nr),
+                       dim3(kRowWaves * 64), smem, st, x, int(p.N), cs.cols, cs.strict, p.ord_S, int(p.N), p.R,
+                       wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
+                       wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider,
+                       wsp<float>(ws, p.o_bsum), p.ord_m);
+    return VC2_OK;
+  }
+  int rc = allow_big_lds(&k_norm_colsum2<DT, NCH, 1, 0>, smem, "k_norm_colsum2");
   if (rc) return rc;
-  hipLaunchKernelGGL((k_norm_colsum2<DT, NCH, 1>), dim3(unsigned(p.S_W + (rider.perm ? (rider.parts & 0xFF) : 0))),
+  hipLaunchKernelGGL((k_norm_colsum2<DT, NCH, 1, 0>), dim3(unsigned(p.S_W) + nr),
                      dim3(kRowWaves * 64), smem, st, x, int(p.N), cs.cols, cs.strict, p.S, p.S_q, p.R,
                      wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
-                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider);
+                     wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider,
+                     (float*)nullptr, 0);
   return VC2_OK;
 }
 template <int DT, int VEC, int NPLB>
@@ -4050,6 +4217,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   double* part = wsp<double>(ws, p.o_part_col);
   double* cpart = wsp<double>(ws, p.o_csum_part);
   const int npl = int(cdiv(C, 64));
+  const bool ord = ord_on(p, cs);                                // torch-ordered frame sums (k_norm_colsum2<.., ORD>)
   OrderArgs ride = rider;
   if (ride.perm && (p.VEC == 1 || !fast_acc(p, cs) || g_prof || ride.k > 4096)) {   // no rider on this sweep variant (or per-kernel
     int rc = launch_chan_order(ride, st);                          // timing wanted): the ORDER job as its own kernel
@@ -4105,12 +4273,13 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   auto launch_fc = [&](auto kernel) {
     if ((rcl = allow_big_lds(kernel, fix_lds, "k_frame_centres", 24 * 1024))) return;
     hipLaunchKernelGGL(kernel, dim3(unsigned(bxn), unsigned(FG + fy)), dim3(64 * kCentreFL), fix_lds, st,
-                       part, int(p.F), p.S, p.S_q, int(p.N), C, wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
+                       part, int(p.F), ord ? p.ord_S : p.S, p.S_q, int(p.N), C, wsp<float>(ws, p.o_fc), cpart, x, int(p.D), cs.cols, cs.spos,
                        wsp<float>(ws, p.o_den),
                        (cs.strict && !fused) ? wsp<int>(ws, p.o_ticket) + kTkCorrCount : (int*)nullptr,
                        wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs,
                        margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0, wsp<float>(ws, p.o_dmin),
-                       (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, wsp<uint32_t>(ws, p.o_rlist), rcap, fr);
+                       (own_stats && cs.strict == 4 && !ord) ? double(VC2_FRAME_A) : 0.0, wsp<uint32_t>(ws, p.o_rlist), rcap, fr,
+                       OrdSrc{ord ? wsp<float>(ws, p.o_bsum) : (const float*)nullptr, ord ? 1 : 0});
   };
   if (!fused) {
     VC2_DISPATCH_DT(p.dt, launch_fc(k_frame_centres<DT, 1, 0>));
@@ -4128,14 +4297,17 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
   // by a launch of their own (frame-sharded pass: its video centre comes later, from the all-gathered sums)
   const FrameReplay frp{wsp<uint32_t>(ws, p.o_rlist), wsp<int>(ws, p.o_ticket) + kTkFrameReplays, rcap,
                         wsp<float>(ws, p.o_fc), int(p.N),
-                        FrameFix{part, p.S, p.S_q, cs.strict, margin_depth(p.N, cs.strict),
+                        FrameFix{part, ord ? p.ord_S : p.S, p.S_q, cs.strict, margin_depth(p.N, cs.strict),
                                  (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, fs,
-                                 wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr)},
+                                 wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr),
+                                 OrdSrc{ord ? wsp<float>(ws, p.o_bsum) : (const float*)nullptr, ord ? 1 : 0}},
                         fused ? wsp<uint32_t>(ws, p.o_rlist) + rcap : (const uint32_t*)nullptr,
                         wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2,
                         fused ? wsp<int>(ws, p.o_fmark) : (const int*)nullptr};
   static const int env_rw = [] { const char* e = getenv("VC2_REPLAY_WAVES"); return e ? atoi(e) : 0; }();
-  const int rwaves = env_rw > 0 ? env_rw : cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 4096 : 1024);   // rider waves (debug mode 2 replays every mean; fp16 lists ~8x bf16's)
+  // rider waves (debug mode 2 replays every mean; fp16 lists ~8x bf16's).  ORD: no mean is replayed -- the riders only redo the
+  // frames that hold a row with a corrected norm (one entry per block of 64 columns: bf16 ~2 frames per pass, fp16 ~16)
+  const int rwaves = env_rw > 0 ? env_rw : ord ? (p.dt == VC2_F16 ? 1024 : 256) : cs.strict == 2 ? 8192 : (p.dt == VC2_F16 ? 4096 : 1024);
   if (single_rank) {
     const int lpv = cascade_lp(p.R);
     const int G1v = int(cdiv(p.R >> lpv, int64_t(1) << lpv));
@@ -4150,7 +4322,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                                              wsp<float>(ws, p.o_dmin), int(p.F), frp, Y,
                                              fused ? wsp<int>(ws, p.o_ticket) + kTkCorrCount : (const int*)nullptr,
                                              wsp<NormCorr>(ws, p.o_corr)));
-  } else if (replays) {
+  } else if (replays && !ord) {                 // (ORD: nothing is listed)
     VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_frame_replay<DT>), dim3(unsigned(rwaves)), dim3(64), 0, st, frp, x, int(p.D),
                                              C, cs.cols, cs.spos, wsp<float>(ws, p.o_den)));
   }
