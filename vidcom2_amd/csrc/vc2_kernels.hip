@@ -2697,7 +2697,7 @@ __global__ __launch_bounds__(kRowWaves * 64, V2 ? VC2_S3_WAVES : 1) void k_dist(
   if (tid < 2) lcount[tid] = 0;
   for (int r = tid; r < nrows; r += kRowWaves * 64) {
     dens[r] = den[int64_t(f) * N + n0 + r];
-    rfl[r] = (kFast && rflag) ? rflag[int64_t(f) * N + n0 + r] : 1;
+    rfl[r] = ((kFast || (ACC == 1 && DT == VC2_F16)) && rflag) ? rflag[int64_t(f) * N + n0 + r] : 1;   // (fp16: written by k_norm_colsum2 only -- else null)
   }
   }
   float den_mine = 0.f;                                             // (V2) dens[tid], stored to LDS behind the table loads
@@ -2907,7 +2907,7 @@ __global__ __launch_bounds__(kRowWaves * 64, V2 ? VC2_S3_WAVES : 1) void k_dist(
     if (it) row_issue<DT, VEC, VC2_AUX_S3>(x, int64_t(f) * N + n, D, CV, buf0, lane);
     row_wait();
     const float dn = dens[n - n0];
-    const bool exact_div = !kFast || rfl[n - n0] != 0;
+    const bool exact_div = !(kFast || (ACC == 1 && DT == VC2_F16)) || rfl[n - n0] != 0;
     static_assert(NPLB % 2 == 0, "compact positions are processed in pairs");
     if constexpr (kFast) {
       typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
@@ -2948,18 +2948,34 @@ __global__ __launch_bounds__(kRowWaves * 64, V2 ? VC2_S3_WAVES : 1) void k_dist(
       // fp16: the hardware's packed fp16 subtract / multiply ARE the reference's roundings here (DistArith)
       typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
       const h2_t ones = {static_cast<_Float16>(1.0f), static_cast<_Float16>(1.0f)};
-      const double inv = 1.0 / double(dn);
       float pv = 0.f, pf = 0.f;
+      // (round 5) rows sweep 2 divided with the fused-multiply-add quotient (rflag = 0: x and dn finite, dn a normal fp16
+      // number) get the same quotient here -- it IS the IEEE quotient (tests/tools/check_f16_quotient.c), at three packed
+      // fp32 instructions per pair instead of six fp64-rate ones
+      auto body16 = [&](auto exact_tag) {
+        constexpr bool kExact = decltype(exact_tag)::value;
+        const double inv = kExact ? 1.0 / double(dn) : 0.0;
+        const float r = kExact ? 0.f : __builtin_amdgcn_rcpf(dn);
+        const f2_t r2 = {r, r}, d2 = {dn, dn};
 #pragma unroll
-      for (int k = 0; k < NPLB / 2; ++k) {
-        const float v0 = lds_elem<DT>(buf0, coff[2 * k]), v1 = lds_elem<DT>(buf0, coff[2 * k + 1]);
-        const h2_t xh = __builtin_convertvector((f2_t){div_via_f64(v0, inv), div_via_f64(v1, inv)}, h2_t);
-        const h2_t cvp = __builtin_convertvector((f2_t){cv[2 * k], cv[2 * k + 1]}, h2_t);    // (loop-invariant: hoisted)
-        const h2_t cfp = __builtin_convertvector((f2_t){cf[2 * k], cf[2 * k + 1]}, h2_t);
-        const h2_t dv = xh - cvp, df = xh - cfp;
-        pv = __builtin_amdgcn_fdot2(dv * dv, ones, pv, false);
-        pf = __builtin_amdgcn_fdot2(df * df, ones, pf, false);
-      }
+        for (int k = 0; k < NPLB / 2; ++k) {
+          const float v0 = lds_elem<DT>(buf0, coff[2 * k]), v1 = lds_elem<DT>(buf0, coff[2 * k + 1]);
+          h2_t xh;
+          if constexpr (kExact) xh = __builtin_convertvector((f2_t){div_via_f64(v0, inv), div_via_f64(v1, inv)}, h2_t);
+          else {
+            const f2_t xx = {v0, v1};
+            const f2_t q0 = pk_mul_f32(xx, r2);
+            const f2_t e = pk_fnma_f32(d2, q0, xx);
+            xh = __builtin_convertvector(pk_fma_f32(e, r2, q0), h2_t);
+          }
+          const h2_t cvp = __builtin_convertvector((f2_t){cv[2 * k], cv[2 * k + 1]}, h2_t);    // (loop-invariant: hoisted)
+          const h2_t cfp = __builtin_convertvector((f2_t){cf[2 * k], cf[2 * k + 1]}, h2_t);
+          const h2_t dv = xh - cvp, df = xh - cfp;
+          pv = __builtin_amdgcn_fdot2(dv * dv, ones, pv, false);
+          pf = __builtin_amdgcn_fdot2(df * df, ones, pf, false);
+        }
+      };
+      if (exact_div) body16(std::true_type{}); else body16(std::false_type{});
       settle(wave_sum_bcast_f32(pv), wave_sum_bcast_f32(pf), it);
     } else {
       acc_t pv = 0, pf = 0;                                       // accumulation order: i, then i + 1
@@ -4175,7 +4191,9 @@ int launch_dist_acc(const Plan& p, const void* x, const ChanSet& cs, void* ws, c
     ProfScope ps_(KID_DIST, st);
     hipLaunchKernelGGL(kernel, dim3(unsigned(p.F * p.S2)), dim3(kRowWaves * 64), smem, st, x,
                        int(p.N), int(p.D), p.CV, C, cols, cs.spos, cs.strict, p.S2, p.rows_per_split2, p.skew2_q10,
-                       wsp<float>(ws, p.o_den), wsp<uint8_t>(ws, p.o_rflag), wsp<float>(ws, p.o_vc),
+                       wsp<float>(ws, p.o_den),
+                       (DT == VC2_F16 && s2v2_nch(p, cs) == 0) ? (uint8_t*)nullptr : wsp<uint8_t>(ws, p.o_rflag),   // (fp16: only k_norm_colsum2 writes it)
+                       wsp<float>(ws, p.o_vc),
                        wsp<float>(ws, p.o_fc), o.v_T, o.f_T, o.total, wsp<double>(ws, p.o_vpart));
     return VC2_OK;
   };
