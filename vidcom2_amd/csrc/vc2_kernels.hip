@@ -1221,30 +1221,28 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
 // The same results as k_norm_colsum<.., ACC = 1>, for the shapes real models have -- 16-bit rows of NCH full 1 KiB
 // chunks (D = 512 NCH), the reference's ratio of one half (C = D / 2 = 64 * 4 NCH: no padded compact positions) -- with
 // the row loop rebuilt around what round 4's profiles showed it spends its time on:
-//   * rows in flight.  The row's 4 NCH selected elements per lane are read from LDS into registers FIRST (bf16:
-//     ds_read_u16_d16_hi -- the element lands in the high half, i.e. as its fp32 value, no unpack), which frees the row buffer at once:
-//     the DMA of row i + 2 is issued into it before row i is computed, so a wave keeps TWO rows on their way from memory
-//     (16 per CU instead of 8) with the same two buffers.  The wait for row i is `s_waitcnt vmcnt(NCH)` -- the younger
-//     row's NCH loads stay outstanding -- which is only sound because nothing else is in the vector-memory queue inside
-//     the loop: the per-row stores (den, rflag) and the "torch order" queue pushes are parked in lanes (lane j keeps the
-//     wave's j-th row) and written once per 64 rows / segment.
-//   * instruction issue.  DMA: NCH global_load_lds with immediate offsets from a scalar row base (the general kernel
-//     runs a 14-instruction loop per chunk); LDS addresses: one register per element, the buffer parity is the
-//     instruction's immediate offset (the general kernel recomputes 4 NCH addresses per row); no padding masks; the
+//   * the row pipeline.  The row's 4 NCH selected elements per lane are read from LDS into registers FIRST (bf16:
+//     ds_read_u16_d16_hi -- the element lands in the high half, i.e. as its fp32 value, no unpack), which frees the row
+//     buffer at once: the DMA of the wave's NEXT row is issued into the same buffer before this row is computed -- ONE
+//     buffer per wave, the next row on its way during the whole computation, and the pipeline runs THROUGH frame
+//     boundaries (the next row may belong to the chunk's next segment: the cross-wave combine of a segment goes through a
+//     scratch area, not through the row buffers).  Measured (NOTES_r05.md): two rows in flight per wave, or three
+//     workgroups per CU, are no faster -- the sweep is bound by the memory side of its structure, not by rows in flight.
+//     Nothing else sits in the vector-memory queue inside the loop: the per-row stores (den, rflag) and the "torch
+//     order" queue pushes are parked in lanes (lane j keeps the wave's j-th row) and written once per 64 rows / segment.
+//   * instruction issue.  DMA: NCH global_load_lds with immediate offsets from one base (the general kernel runs a
+//     14-instruction loop per chunk); LDS addresses: one register per element, computed once (the general kernel
+//     recomputes 4 NCH addresses per row); no padding masks; the
 //     element range test of the bf16 quotient is ONE v_min3_f32 per pair on the products (a nonzero normal bf16 result is
 //     all the midpoint argument above kBf16SpanLo needs; overflow / underflow of the squares shows in the norm itself,
 //     which is tested once per row); the correctly rounded square root in fp32.
 //   * fp16 gets a fast quotient too: q0 = x * r, e = fma(-dn, q0, x), q = fma(e, r, q0) with r = v_rcp_f32(dn) IS the IEEE
 //     fp32 quotient for every nonzero finite fp16 x and dn -- proved by exhaustion (all 1.0e9 pairs, r off by up to +-4
 //     ulps: tests/tools/check_f16_quotient.c) -- so RN_f16 of it is what torch's fp16 division returns; the squares are
-//     exact fp32 fused multiply-adds in two chains (the bound of acc_norm_ulps).
+//     exact fp32 fused multiply-adds in four chains (within the bound of acc_norm_ulps).
 // Rows the fast path cannot take (norm outside the range where the fp32 sum of squares is safe, a zero / subnormal
 // quotient in bf16, non-finite data) are redone on the spot exactly as the general kernel does them (fp64 sum of squares,
 // exactly rounded division; rflag[row] = 1 tells sweep 3).
-template <int NCH> __device__ __forceinline__ void s2_wait_row(bool younger_in_flight) {
-  if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 template <int J, int NCH>
 __device__ __forceinline__ void s2_issue_chunks(const unsigned char* __restrict__ src_lane, unsigned char* lds_uniform) {
   if constexpr (J < NCH) {                                        // (the immediate offset applies to BOTH addresses; 13 bits signed)
@@ -3809,7 +3807,8 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
   p->F_total = F_total > 0 ? F_total : F;
   // sweep-1 groups: `stat_splits` pieces per frame -- a function of the WHOLE video's frame count, so that every
   // rank of a frame-sharded pass cuts its frames exactly like the unsharded pass does
-  p->stat_splits = int(std::max<int64_t>(1, std::min<int64_t>(cdiv(128, p->F_total), std::max<int64_t>(1, N / 32))));
+  static const int env_groups = [] { const char* e = getenv("VC2_STAT_GROUPS"); return e ? atoi(e) : 128; }();   // (experiments: row groups aimed at)
+  p->stat_splits = int(std::max<int64_t>(1, std::min<int64_t>(cdiv(env_groups, p->F_total), std::max<int64_t>(1, N / 32))));
   p->rows_per_group = int(cdiv(N, p->stat_splits));
   p->stat_splits = int(cdiv(N, p->rows_per_group));
   p->G = int(F * p->stat_splits);
