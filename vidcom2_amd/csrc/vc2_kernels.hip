@@ -94,6 +94,9 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // VEC columns, K = x[0][c] (a shift: constant columns give exactly 0 and the final subtraction
 // is well conditioned).  The 4 waves combine through LDS; one partial per (row group, column).
 constexpr int kStatsWaves = 4;
+#ifndef VC2_S1_PROBE
+#define VC2_S1_PROBE 0
+#endif
 
 // Row groups are CANONICAL: a group is one of `splits` pieces of one frame, the shift K of a group
 // is the first row of its STAT BLOCK (kStatBlockFrames frames), and the groups of a block are added in a fixed order
@@ -223,11 +226,30 @@ __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __r
     } else
     for (int64_t r = r0 + wave; r < r1; r += int64_t(kStatsWaves) * U) {
       RawVec<DT, VEC> raw[U];
+#if VC2_S1_PROBE == 2      // (timing probe, results invalid: the arithmetic alone -- one round of loads, reused)
+      if (r == r0 + wave) {
+#endif
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t rr = r + int64_t(u) * kStatsWaves;
         raw[u] = rr < r1 ? load_raw<DT, VEC>(x, rr * D + int64_t(cv) * VEC) : zero_raw<DT, VEC>();
       }
+#if VC2_S1_PROBE == 2
+      }
+      if constexpr (VEC == 8) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("" : "+v"(raw[u].v.x), "+v"(raw[u].v.y), "+v"(raw[u].v.z), "+v"(raw[u].v.w));
+      }
+#endif
+#if VC2_S1_PROBE == 1      // (timing probe, results invalid: the loads alone)
+      if constexpr (VEC == 8) {
+        unsigned acc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= raw[u].v.x ^ raw[u].v.y ^ raw[u].v.z ^ raw[u].v.w;
+        s[0] += double(acc);
+      }
+      continue;
+#endif
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t rr = r + int64_t(u) * kStatsWaves;
@@ -334,8 +356,10 @@ inline FoldTab make_fold_tab(int NB, int64_t n_each, int64_t n_last) {
   t.ntot = an;
   return t;
 }
-template <int DT>
-__global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
+// CW columns per workgroup, kRedGL lanes per column.  Narrow slabs (CW = 16: 224 workgroups at D = 3584) spread the
+// 7 MB of sweep-1 partials over the whole chip instead of 56 CUs; the fold shape does not depend on CW.
+template <int DT, int CW = 64>
+__global__ __launch_bounds__(CW * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
                                                                 int64_t n_each, int64_t n_last, int D,
                                                                 void* __restrict__ var_T, float* __restrict__ var_f32,
                                                                 int* __restrict__ counters, PartSrc ps, FoldTab ft,
@@ -343,13 +367,13 @@ __global__ __launch_bounds__(64 * kRedGL) void k_var_from_stats(const double* __
                                                                 int nfixq = 0, unsigned long long* __restrict__ kstatus = nullptr) {
   // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
   // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
-  __shared__ double sm[3][kRedGL][64];
+  __shared__ double sm[3][kRedGL][CW];
   if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(100);
   if (counters && blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;  // strict-mode queues of this pass
   if (kstatus && blockIdx.x == 0 && threadIdx.x == 0) *kstatus = 0ull;             // K_out[1]: k_select ORs its bits in
   if (fixq) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfixq; i += gridDim.x * blockDim.x) fixq[i] = 0ull;
-  const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x % CW, gl = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + cl;
   ChanAgg a{0.0, 0.0, 0.0};
   if (c < D)
     for (int b = gl; b < NB; b += kRedGL) {
@@ -1660,6 +1684,30 @@ __device__ __forceinline__ float block_sum_rows(const void* __restrict__ x, int 
   return a;
 }
 
+// ... of NC columns at once: one round of loads (the denominators once) instead of NC rounds; per column the same
+// quotients added in the same order as block_sum_rows
+template <int DT, int NC>
+__device__ __forceinline__ void block_sum_rows_n(const void* __restrict__ x, int D, const int (&col)[NC],
+                                                 const float* __restrict__ den, int64_t e0, int lp, float (&a)[NC]) {
+  for (int c0 = 0; c0 < (1 << lp); c0 += 16) {
+    float dn[16], v[NC][16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) dn[u] = den[e0 + c0 + u];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[j][u] = ldT<DT>(x, (e0 + c0 + u) * D + col[j]);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[j][u] = rnT<DT>(v[j][u] / dn[u]);
+      a[j] = c0 == 0 ? v[j][0] : a[j] + v[j][0];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) a[j] += v[j][u];
+    }
+  }
+}
+
 // sum of the level-0 sums of blocks [first_block, first_block + nbl), nbl <= 2^lp, elements at rows r0 + e*rs
 template <int DT>
 __device__ float wave_l1_group(const void* __restrict__ x, int D, int col, const float* __restrict__ den,
@@ -2348,6 +2396,7 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
   const int64_t nbv = R >> lp;
   const int G1v = int((nbv + B - 1) >> lp);
   const int sub = lane >> lp, li = lane & (B - 1);
+  uint64_t plain = 0ull;                            // flagged columns that take the plain cascade
   for (uint64_t m = flagged; m; m &= m - 1) {
     const int vl = __builtin_ctzll(m), cc = bx * 64 + vl;
     const int col = __shfl(my_col, vl, 64), sp = __shfl(my_sp, vl, 64);
@@ -2358,16 +2407,42 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
       }
       continue;
     }
+    plain |= 1ull << vl;
+  }
+  // up to four flagged columns of the block per round of loads (fp16 flags 1 .. 4 columns per block, each a round trip
+  // of 16 strided rows per lane: one after the other they took 7-8 us each and set this launch's time)
+  auto batch = [&](auto nc_tag, uint64_t& m) {
+    constexpr int NC = decltype(nc_tag)::value;
+    int col[NC], cc[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int vl = __builtin_ctzll(m);
+      m &= m - 1;
+      cc[j] = bx * 64 + vl;
+      col[j] = __shfl(my_col, vl, 64);
+    }
     for (int g4 = y * gpw; g4 < G1v; g4 += Y * gpw) {   // gpw level-1 groups at once (four at lp = 4)
       const int g1 = g4 + sub;
       const int nbl = g1 < G1v ? int(min<int64_t>(B, nbv - (int64_t(g1) << lp))) : 0;
-      float a = 0.f;
-      if (li < nbl) a = block_sum_rows<DT>(x, D, col, den, 0, 1, ((int64_t(g1) << lp) + li) << lp, lp);
+      float a[NC];
+#pragma unroll
+      for (int j = 0; j < NC; ++j) a[j] = 0.f;
+      if (li < nbl) block_sum_rows_n<DT, NC>(x, D, col, den, ((int64_t(g1) << lp) + li) << lp, lp, a);
       const int l0 = lane & ~(B - 1);
-      float sgrp = __shfl(a, l0, 64);                // the block sums of my group, added in block order
-      for (int u = 1; u < B; ++u) { const float t = __shfl(a, l0 + u, 64); if (u < nbl) sgrp += t; }
-      if (li == 0 && g1 < G1v) l1g[int64_t(cc) * vstride + g1] = sgrp;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        float sgrp = __shfl(a[j], l0, 64);           // the block sums of my group, added in block order
+        for (int u = 1; u < B; ++u) { const float t = __shfl(a[j], l0 + u, 64); if (u < nbl) sgrp += t; }
+        if (li == 0 && g1 < G1v) l1g[int64_t(cc[j]) * vstride + g1] = sgrp;
+      }
     }
+  };
+  for (uint64_t m = plain; m;) {
+    const int left = __popcll(m);
+    if (left >= 4) batch(std::integral_constant<int, 4>{}, m);
+    else if (left == 3) batch(std::integral_constant<int, 3>{}, m);
+    else if (left == 2) batch(std::integral_constant<int, 2>{}, m);
+    else batch(std::integral_constant<int, 1>{}, m);
   }
   // Release / acquire FENCES around the ticket.  (A fence-free variant -- the groups as relaxed agent-scope atomic
   // stores, s_waitcnt vmcnt(0), a relaxed ticket, coherent loads in the last arriver -- was 0.8 us faster and WRONG:
@@ -4000,12 +4075,21 @@ int launch_chan_stats(const Plan& p, const void* x, void* ws, double* bstats, vo
                                              0, st, src, int(p.D), bstats));
   if (var_f32 || var_T) {
     const int64_t n_each = int64_t(p.BF) * p.N, n_last = p.R - int64_t(p.NB - 1) * n_each;
-    VC2_DISPATCH_DT(p.dt, hipLaunchKernelGGL((k_var_from_stats<DT>), dim3(unsigned(cdiv(p.D, 64))), dim3(64 * kRedGL),
-                                             0, st, (const double*)nullptr, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
-                                             zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src,
-                                             make_fold_tab(p.NB, n_each, n_last),
-                                             zero_queue_counters ? wsp<unsigned long long>(ws, p.o_nfixlist) : nullptr,
-                                             int(p.R + cdiv(p.F, 2)), reinterpret_cast<unsigned long long*>(kstatus)));
+    // narrow column slabs (16 columns x 16 lanes: 224 workgroups at D = 3584) spread the loads of sweep 1's partials
+    // (7 MB) over the whole chip instead of 56 CUs; VC2_VAR_CW = 64 is the wide form (experiments)
+    static const int cw_env = [] { const char* e = getenv("VC2_VAR_CW"); return e ? atoi(e) : 16; }();
+    auto go = [&](auto dt_tag, auto cw_tag) {
+      constexpr int DT = decltype(dt_tag)::value, CW = decltype(cw_tag)::value;
+      hipLaunchKernelGGL((k_var_from_stats<DT, CW>), dim3(unsigned(cdiv(p.D, CW))), dim3(CW * kRedGL), 0, st,
+                         (const double*)nullptr, p.NB, n_each, n_last, int(p.D), var_T, var_f32,
+                         zero_queue_counters ? wsp<int>(ws, p.o_ticket) : (int*)nullptr, src,
+                         make_fold_tab(p.NB, n_each, n_last),
+                         zero_queue_counters ? wsp<unsigned long long>(ws, p.o_nfixlist) : nullptr,
+                         int(p.R + cdiv(p.F, 2)), reinterpret_cast<unsigned long long*>(kstatus));
+    };
+    VC2_DISPATCH_DT(p.dt, (cw_env == 64 ? go(std::integral_constant<int, DT>{}, std::integral_constant<int, 64>{})
+                           : cw_env == 32 ? go(std::integral_constant<int, DT>{}, std::integral_constant<int, 32>{})
+                                          : go(std::integral_constant<int, DT>{}, std::integral_constant<int, 16>{})));
   } }
   return check_launch("chan_stats");
 }
