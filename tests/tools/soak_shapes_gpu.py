@@ -10,6 +10,7 @@ PRIMARY = os.environ.get("VC2_SOAK_MODE", "torch")       # the mode under test (
 O.set_mode("torch"); _ffi.set_mode(PRIMARY)
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 LARGE = os.environ.get("VC2_SOAK_LARGE", "0") != "0"      # shapes of 6e7 .. 2.2e8 elements (target = 9e7), which the default run skips
+ONLY_DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32, "": None}[os.environ.get("VC2_SOAK_DTYPE", "")]
 bad = n = bad3 = 0
 t0 = time.time()
 for seed in range(lo, hi):
@@ -30,6 +31,8 @@ for seed in range(lo, hi):
     if LARGE:
         dt = rng.choice([torch.float16, torch.bfloat16])
         dist = rng.choice(["cancel", "cancel", "drift", "iid"])
+    if ONLY_DT is not None:                   # (VC2_SOAK_DTYPE=f16|bf16|f32: one dtype only)
+        dt = ONLY_DT
     base = rng.choice([0.05, 0.15, 0.25, 0.5, 0.9])
     x = synth.make(F, N, D, dt, seed, dist)
     try:
