@@ -18,7 +18,7 @@ N > 1 : "target": weak scaling -- every rank holds 128 frames of ONE long video 
         with three (+1) small RCCL all-gathers (stat blocks, centre sums, replay blocks, per-frame uniqueness scores);
         "cfg4" (BASELINE configs[3]): STRONG scaling -- one 512-frame video, 512/N frames per rank, same exchanges;
         "cfg5" (configs[4]): 16 clips of 128x196x4096 fp16, 16/N clips per rank, replicas (no collective: the
-        reference's document-level data parallelism), two clips in flight per GPU.
+        reference's document-level data parallelism), three clips in flight per GPU (compress_batch's default).
         The sharded lines carry "exchanges_us": the mean time of every all-gather with its message size.
 
 Environment knobs: VC2_BENCH_WATCHDOG=<s> (a run still going after s seconds dumps every thread's Python stack and
@@ -251,7 +251,7 @@ def relaunch_under_launcher(args) -> int:
 
 def bench_replicas(args, rank, world, dev, vc, _ffi, synth):
     """cfg5: 16 independent clips, 16 / world per rank, no collective (the reference's document-level DP,
-    lmms-eval evaluator.py:488-491); every rank keeps two clips in flight on two streams."""
+    lmms-eval evaluator.py:488-491); every rank keeps compress_batch's default number of clips in flight (three), one stream each."""
     F, N, D, dtype, base = WORKLOADS["cfg5"]
     if CFG5_CLIPS % world:
         raise SystemExit(f"[bench] cfg5: {CFG5_CLIPS} clips do not split over {world} ranks")
@@ -266,7 +266,7 @@ def bench_replicas(args, rank, world, dev, vc, _ffi, synth):
         ref = oracle.compress_indices(clips[0].cpu(), N, base)
         if res0.ks.cpu().tolist() != ref["ks"].tolist() or not torch.equal(res0.global_idx.cpu(), ref["global_idx"]):
             raise SystemExit("[bench] PARITY FAILURE (cfg5 clip 0): kept indices / budgets differ from the oracle")
-    step = lambda: vc.vidcom2.compress_batch(clips, N, base, in_flight=2)      # noqa: E731
+    step = lambda: vc.vidcom2.compress_batch(clips, N, base)      # noqa: E731
     for _ in range(args.warmup):
         step()
     dist_on = world > 1
@@ -692,19 +692,19 @@ def main():
                         "pass_frac_of_8TBs": round(alg_bytes_pass(Fo, No, Do, eso, bo) / (eo / args.steps) / 1e9 / HBM_PEAK_GBS, 4)})
             out[wl] = leg
             if wl == "cfg5clip":
-                # BASELINE config 5 on ONE GPU: the whole batch of 16 clips through compress_batch (two lanes: a clip's
+                # BASELINE config 5 on ONE GPU: the whole batch of 16 clips through compress_batch (its default lanes: a clip's
                 # single-workgroup kernels overlap the other clip's sweeps).  Four distinct clips, four times each.
                 clips4 = [xo] + [synth.make(Fo, No, Do, dto, seed=sd, dist="drift").to(dev) for sd in (1, 2, 3)]
                 batch = [clips4[i % 4] for i in range(CFG5_CLIPS)]
-                rb = vc.vidcom2.compress_batch(batch, No, bo, in_flight=2)
+                rb = vc.vidcom2.compress_batch(batch, No, bo)
                 if not (rb[0].K == ro.K and torch.equal(rb[0].global_idx, ro.global_idx) and torch.equal(rb[4].global_idx, ro.global_idx)):
                     raise SystemExit("[bench] PARITY FAILURE (cfg5_batch16): the batch's clip 0 differs from the single pass")
                 del rb
                 for _ in range(3):
-                    vc.vidcom2.compress_batch(batch, No, bo, in_flight=2)
+                    vc.vidcom2.compress_batch(batch, No, bo)
                 nbat = max(5, args.steps // 4)
-                ebat = min(time_steps(lambda: vc.vidcom2.compress_batch(batch, No, bo, in_flight=2), nbat, False) for _ in range(2)) / nbat
-                out["cfg5_batch16"] = {"workload": f"{CFG5_CLIPS} clips x {Fo}x{No}x{Do} {DT_NAME[dto]} retain {bo}, compress_batch(in_flight=2), one GPU",
+                ebat = min(time_steps(lambda: vc.vidcom2.compress_batch(batch, No, bo), nbat, False) for _ in range(2)) / nbat
+                out["cfg5_batch16"] = {"workload": f"{CFG5_CLIPS} clips x {Fo}x{No}x{Do} {DT_NAME[dto]} retain {bo}, compress_batch(in_flight={vc.vidcom2.BATCH_LANES}), one GPU",
                                        "ms_per_batch": round(ebat * 1e3, 3), "us_per_clip": round(ebat / CFG5_CLIPS * 1e6, 1),
                                        "tokens_per_s": round(CFG5_CLIPS * Fo * No / ebat, 1),
                                        "pass_frac_of_8TBs": round(CFG5_CLIPS * alg_bytes_pass(Fo, No, Do, 2, bo) / ebat / 1e9 / HBM_PEAK_GBS, 4),

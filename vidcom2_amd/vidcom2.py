@@ -432,10 +432,26 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
     return plan.finish()
 
 
-def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2, gather: bool = True):
+_LANES: dict = {}
+
+
+def _lane_streams(dev: torch.device, n: int):
+    """The n extra streams compress_batch runs clips on -- created once per (device, thread) and kept: the plan cache is
+    keyed by stream, so fresh streams per call meant fresh plans (and workspaces) per call: 0.5-1.2 ms of set-up per batch."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), threading.get_ident())
+    lst = _LANES.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(dev))
+    return lst[:n]
+
+
+BATCH_LANES = 3          # compress_batch's default: clips in flight (16 cfg5 clips: 254 / 216 / 203 / 197 us per clip with 1 / 2 / 3 / 4)
+
+
+def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = BATCH_LANES, gather: bool = True):
     """Compress several clips (a list of [F_i * tpf, D] tensors) with up to `in_flight` of them running
     concurrently, one HIP stream each.  A single pass leaves the GPU idle during its single-workgroup selection
-    replays; a second clip in flight fills those gaps (DESIGN.md "clips in flight": 1.3x tokens/s with two re-used plans).
+    replays; further clips in flight fill those gaps (DESIGN.md "clips in flight"; every lane keeps a plan = a workspace).
     Returns one CompressionResult per clip, in order.  The reference has no batched form: its harness loops
     over clips (lmms-eval, batch size 1 per rank)."""
     clips = [_prep(c, "clip") for c in clips]
@@ -446,7 +462,7 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2
         if x.dim() != 2 or tpf <= 0 or x.shape[0] % int(tpf) != 0:
             raise RuntimeError(f"clip {i}: shape {tuple(x.shape)} is not [frames * {tpf}, dim]")
     cur = torch.cuda.current_stream(dev)
-    lanes = [cur] + [torch.cuda.Stream(dev) for _ in range(max(1, min(int(in_flight), len(clips))) - 1)]
+    lanes = [cur] + _lane_streams(dev, max(1, min(int(in_flight), len(clips))) - 1)
     same = all(c.shape == clips[0].shape and c.dtype == clips[0].dtype and c.device == dev for c in clips)
     if not same:
         return _compress_batch_mixed(clips, int(tpf), base_scale, lanes, gather)
@@ -468,9 +484,8 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = 2
     kout_all = torch.empty((n, 2), dtype=torch.int64, device=dev)
     for st in lanes[1:]:
         st.wait_stream(cur)               # inputs and these buffers belong to the caller's stream
-        for t in (idx_all, ks_all, rows_all, kout_all):
-            if t is not None:
-                t.record_stream(st)
+    # (no record_stream on the batch's buffers: every lane is joined into the caller's stream below, before this function
+    #  returns -- whatever the caller does with them, freeing included, is ordered behind the lanes' work)
     for i, x in enumerate(clips):
         plan = plans[i % len(lanes)]
         plan.idx, plan.ks, plan.rows, plan.v, plan.f, plan.kout = idx_all[i], ks_all[i], (rows_all[i] if gather else None), None, None, kout_all[i]
