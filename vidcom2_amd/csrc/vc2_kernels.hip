@@ -3328,9 +3328,10 @@ __global__ void k_widen(const void* __restrict__ in, int64_t n, float* __restric
 constexpr int kFrameNT = 256;
 constexpr int kFusedScalesMaxF = 1024;      // up to this many frames every k_select workgroup derives the budgets itself
 
-__device__ __forceinline__ float block_max_nanprop_256(float v, float* sm) {
+// NaN-propagating block maximum (256 threads).  sm: exchange cells nobody has written before in this launch -- no barrier in
+// front of the write
+__device__ __forceinline__ float block_max_nanprop_256_once(float v, float* sm) {
   v = wave_max_nanprop_bcast(v);
-  __syncthreads();
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
   float r = sm[0];
@@ -3407,9 +3408,13 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
                                                      int* status = nullptr, long long* khost = nullptr,
                                                      int* arrive = nullptr, int force_guard = -1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float smf[4];
-  __shared__ double smd[4];
+  // every block-wide reduction of the budget phase has exchange cells of its own: written once per launch, so ONE barrier
+  // per reduction (write, barrier, read) instead of two -- 5 barriers on the budget path instead of 12 (round 5)
+  __shared__ float smf[2][4];
+  __shared__ double smd[2][4];
   __shared__ long long smi[8];
+  __shared__ long long smk;
+  __shared__ float smsc;
   const int fl = blockIdx.x, FS = gridDim.x;                   // local frame, frames selected by this launch
   const int f = f0 + fl;                                        // its index among the F budget frames
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3451,7 +3456,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
     }
     // a thread without frames must not inject -inf into a NaN-propagating max of finite values: -inf is the
     // identity there as well (max(-inf, v) = v), and NaN still wins
-    const float mx = block_max_nanprop_256(m, smf);
+    const float mx = block_max_nanprop_256_once(m, smf[0]);
     float zm = -INFINITY;
 #pragma unroll
     for (int j = 0; j < FPT; ++j) {
@@ -3463,7 +3468,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
         zm = (zm != zm) ? zm : ((z != z) ? z : fmaxf(zm, z));
       }
     }
-    const float zmax = block_max_nanprop_256(zm, smf);
+    const float zmax = block_max_nanprop_256_once(zm, smf[1]);
     double es = 0.0;
     float ee[FPT];
 #pragma unroll
@@ -3473,10 +3478,9 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       if (i < F) { ee[j] = float(exp(double(zz[j] - zmax))); es += double(ee[j]); }
     }
     es = wave_sum_bcast(es);
+    if (lane == 0) smd[0][wave] = es;
     __syncthreads();
-    if (lane == 0) smd[wave] = es;
-    __syncthreads();
-    const double esum = smd[0] + smd[1] + smd[2] + smd[3];
+    const double esum = smd[0][0] + smd[0][1] + smd[0][2] + smd[0][3];
     double ps = 0.0;
 #pragma unroll
     for (int j = 0; j < FPT; ++j) {
@@ -3485,10 +3489,9 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
       if (i < F) { pp[j] = rnT<DT>(float(double(ee[j]) / esum)); ps += double(pp[j]); }
     }
     ps = wave_sum_bcast(ps);
+    if (lane == 0) smd[1][wave] = ps;
     __syncthreads();
-    if (lane == 0) smd[wave] = ps;
-    __syncthreads();
-    const float pmean = mean_T<DT>(smd[0] + smd[1] + smd[2] + smd[3], F);
+    const float pmean = mean_T<DT>(smd[1][0] + smd[1][1] + smd[1][2] + smd[1][3], F);
 #pragma unroll
     for (int j = 0; j < FPT; ++j) {
       const int i = tid + j * kFrameNT;
@@ -3516,20 +3519,17 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   //  SLOWER than this block-wide form, whose ten barriers cost less than one wave's serial exp / load slots.)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o, 64); all += __shfl_xor(all, o, 64); }
-  __syncthreads();
   if (lane == 0) { smi[wave] = before; smi[4 + wave] = all; }
+  // the thread that holds frame f publishes k and the scale (cells of their own: the same barrier serves both)
+  {
+    const bool holder = (vpart || frame_scores) ? (tid == f % kFrameNT) : (tid == (f - f0) % kFrameNT);
+    if (holder) { smk = kmine; smsc = scmine; }
+  }
   __syncthreads();
   const int64_t o0 = smi[0] + smi[1] + smi[2] + smi[3];
   const int64_t Ktot = smi[4] + smi[5] + smi[6] + smi[7];
-  __syncthreads();
-  // the thread that holds frame f publishes k and the scale
-  {
-    const bool holder = (vpart || frame_scores) ? (tid == f % kFrameNT) : (tid == (f - f0) % kFrameNT);
-    if (holder) { smi[0] = kmine; smf[0] = scmine; }
-  }
-  __syncthreads();
-  const int kraw = int(smi[0]);                                 // round(scale * tpf): may exceed N when tpf != N
-  const float scale_f = smf[0];
+  const int kraw = int(smk);                                    // round(scale * tpf): may exceed N when tpf != N
+  const float scale_f = smsc;
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(801 + (fl ? 50 : 0));
   const int k = kraw < N ? kraw : N;
   if (tid == 0) {
