@@ -395,6 +395,28 @@ def test_compress_batch_matches_sequential():
         vc.compress_batch([xs[0][:100]], 196)
 
 
+def test_compress_batch_same_shape_reuses_lanes_and_plans():
+    """A batch of clips of one shape runs on compress_batch's kept lane streams with one cached plan per lane: a second
+    call creates neither streams nor plans (the plan cache is keyed by stream -- fresh streams per call once meant fresh
+    plans and workspaces per call), and every clip still gets what it gets alone."""
+    from vidcom2_amd import vidcom2 as V
+    xs = [make_input(16, 196, 1024, "f16", 70 + i, "drift").cuda() for i in range(7)]
+    want = [V.compress(x, 196, 0.25) for x in xs]
+    V.compress_batch(xs, 196, 0.25)
+    dev = xs[0].device
+    lanes_before = list(V._lane_streams(dev, V.BATCH_LANES - 1))
+    plans_before = dict(V._PLAN_CACHE)
+    got = V.compress_batch(xs, 196, 0.25)
+    assert [s.cuda_stream for s in V._lane_streams(dev, V.BATCH_LANES - 1)] == [s.cuda_stream for s in lanes_before]
+    assert set(V._PLAN_CACHE.keys()) == set(plans_before.keys())
+    assert all(V._PLAN_CACHE[k] is plans_before[k] for k in plans_before)
+    for g, w in zip(got, want):
+        assert g.K == w.K and torch.equal(g.global_idx, w.global_idx) and torch.equal(g.rows, w.rows) and torch.equal(g.ks, w.ks)
+    # the cached plans do not keep pointing into the batch's buffers
+    for p in V._PLAN_CACHE.values():
+        assert p.rows is None or p.rows.data_ptr() != got[0].rows.data_ptr()
+
+
 def test_selection_engine_loop_bounds_never_expire():
     """Every loop of the selection / sort replay (vc2_select2.h) is bounded; a bound that expires is counted on the
     device.  After a spread of passes (incl. everything the tests above ran in this process) all counters are 0."""
