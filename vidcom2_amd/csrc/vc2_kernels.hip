@@ -456,13 +456,12 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   __syncthreads();
   if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
   else topk_smallest2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, k, tid);
-  __syncthreads();
+  // (no barrier here: both replays end with one, and the cases that replay nothing have the barrier above behind them)
   if (tid == 0) VC2_STAMP(205);
   if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
-  // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction)
-  for (int i = tid; i < D; i += kSelNT) S.la[i] = (k >= D) ? 1 : 0;
-  __syncthreads();
-  if (k < D) for (int i = tid; i < k; i += kSelNT) S.la[T::idx(S.w[i])] = 1;
+  // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction).  S.w holds
+  // every channel exactly once, the kept ones in [0, k): ONE pass writes every flag (no zeroing pass, no barrier between)
+  for (int i = tid; i < D; i += kSelNT) S.la[T::idx(S.w[i])] = (i < k || k >= D) ? 1 : 0;
   __syncthreads();
   const int Ept = (D + kSelNT - 1) / kSelNT;
   const int b = tid * Ept, e = min(D, b + Ept);
@@ -3362,10 +3361,9 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
   else if (tid < 64) topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
   __syncthreads();
   if (tid == 0 && f == 0) VC2_STAMP(803);
-  // kept flags (la is free now), then ordered compaction = idx.sort().values
-  for (int i = tid; i < N; i += kFrameNT) S.la[i] = (k >= N) ? 1 : 0;
-  __syncthreads();
-  if (k < N) for (int i = tid; i < k; i += kFrameNT) S.la[T::idx(S.w[i])] = 1;
+  // kept flags (la is free now), then ordered compaction = idx.sort().values.  S.w holds every token exactly once, the
+  // kept ones in [0, k): one pass writes every flag
+  for (int i = tid; i < N; i += kFrameNT) S.la[T::idx(S.w[i])] = (i < k || k >= N) ? 1 : 0;
   __syncthreads();
   const int Ept = (N + kFrameNT - 1) / kFrameNT;
   const int b = tid * Ept, e = min(N, b + Ept);
