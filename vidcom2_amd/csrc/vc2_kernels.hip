@@ -451,13 +451,19 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   constexpr int NW = kSelNT / 64;
   const int tid = threadIdx.x;
   Sel2<W> S = sel2_carve<W>(smem, D, status);
+#if defined(VC2_DEBUG_TIMING)
+  S.dbg_slot = 0;
+#endif
+  if (tid == 0) VC2_ROUND(S, 201, D);                             // the variances are in registers
 #pragma unroll
   for (int j = 0; j < kSelPre; ++j) { const int i = tid + j * kSelNT; if (i < D) S.w[i] = T::pack(topk_key(pre[j]), i); }
   __syncthreads();
+  if (tid == 0) VC2_ROUND(S, 202, D);                             // packed words in LDS
   if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
   else topk_smallest2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, k, tid);
   // (no barrier here: both replays end with one, and the cases that replay nothing have the barrier above behind them)
   if (tid == 0) VC2_STAMP(205);
+  if (tid == 0) VC2_ROUND(S, 291, k);
   if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
   // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction).  S.w holds
   // every channel exactly once, the kept ones in [0, k): ONE pass writes every flag (no zeroing pass, no barrier between)
@@ -469,6 +475,7 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   for (int p = b; p < e; ++p) cnt += S.la[p];
   uint32_t tot;
   int o = int(block_excl_scan<NW>(cnt, S.xch, tot));
+  if (tid == 0) VC2_ROUND(S, 292, k);                             // flags + scan done
   for (int p = b; p < e; ++p) {
     const bool on = S.la[p] != 0;
     if (mask) mask[p] = on ? 1 : 0;
@@ -482,6 +489,7 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
       for (int i = tid; i < k; i += kSelNT) { const W w = S.w[i]; wperm[i] = uint32_t(w); wcpos[i] = S.lb[T::idx(w)]; }
     }
   }
+  if (tid == 0) VC2_ROUND(S, 299, k);
 }
 
 #ifndef VC2_DEV_ONLY
@@ -492,6 +500,7 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int bad = 0;
   if (threadIdx.x == 0) VC2_STAMP(200);
+  if (threadIdx.x == 0) VC2_ROUND_RAW(0, 120, 200);
   float pre[kSelPre];                                  // (one round of loads; the bodies pack from registers)
 #pragma unroll
   for (int j = 0; j < kSelPre; ++j) { const int i = threadIdx.x + j * kSelNT; pre[j] = var_f32[i < D ? i : D - 1]; }
@@ -3354,13 +3363,18 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
   using T = WordTr<W>;
   const int tid = threadIdx.x;
   Sel2<W> S = sel2_carve<W>(smem, N, status);
+#if defined(VC2_DEBUG_TIMING)
+  S.dbg_slot = f == 0 ? 1 : -1;
+#endif
   // (the frame's words were packed into S.w by select_frame_load before the budgets were derived)
   __syncthreads();
   if (tid == 0 && f == 0) VC2_STAMP(802);
+  if (tid == 0) VC2_ROUND(S, 802, N);
   if (N > sel2_capacity(1, 4)) topk_smallest2<W, 4, 4, 8>(S, N, k, tid);
   else if (tid < 64) topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
   __syncthreads();
   if (tid == 0 && f == 0) VC2_STAMP(803);
+  if (tid == 0) VC2_ROUND(S, 803, k);
   // kept flags (la is free now), then ordered compaction = idx.sort().values.  S.w holds every token exactly once, the
   // kept ones in [0, k): one pass writes every flag
   for (int i = tid; i < N; i += kFrameNT) S.la[T::idx(S.w[i])] = (i < k || k >= N) ? 1 : 0;
@@ -3388,6 +3402,7 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
       if (oo < cap) idx_out[oo] = int64_t(f) * grid_h * (grid_h + 1) + int64_t(a) * (grid_h + 1) + grid_h;
     }
   }
+  if (tid == 0) VC2_ROUND(S, 809, k);
 }
 
 // Budget sources, in order of preference: vpart (sweep-3 workgroup partials, S2 per frame) or frame_scores
@@ -3418,6 +3433,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int extra = map_mode == VC2_MAP_GRID_VID ? grid_h : 0;
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(800 + (fl ? 50 : 0));
+  if (tid == 0 && fl == 0) VC2_ROUND_RAW(1, 120, 800);
   if constexpr (DT == VC2_F32) select_frame_load<uint64_t>(smem, total, fl, N);
   else select_frame_load<uint32_t>(smem, total, fl, N);
   // ---- budgets of all frames; thread t holds frames t, t + 256, ...
@@ -3529,6 +3545,7 @@ __global__ __launch_bounds__(kFrameNT) void k_select(const float* __restrict__ t
   const int kraw = int(smk);                                    // round(scale * tpf): may exceed N when tpf != N
   const float scale_f = smsc;
   if (tid == 0 && (fl == 0 || fl == FS - 1)) VC2_STAMP(801 + (fl ? 50 : 0));
+  if (tid == 0 && fl == 0) VC2_ROUND_RAW(1, 121, 801);
   const int k = kraw < N ? kraw : N;
   if (tid == 0) {
     ks[fl] = kraw;                                              // (the caller turns k > N into torch.topk's error)
@@ -5204,6 +5221,12 @@ int vc2_debug_set(int key, int value) {
 int vc2_debug_wg(unsigned long long* out /*[8][2][4096]*/) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 8 * 2 * 4096);
+  return 0;
+}
+int vc2_debug_read_rounds(unsigned long long* t, int* v) {      // [2][128] each: the per-round stamps (VC2_ROUND)
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(vc2::g_dbg_rt), sizeof(unsigned long long) * 256);
+  (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(vc2::g_dbg_rv), sizeof(int) * 256);
   return 0;
 }
 int vc2_debug_read(unsigned long long* t, int* v, int* n, int reset) {

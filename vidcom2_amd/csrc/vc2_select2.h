@@ -29,6 +29,22 @@
 #else
 #define VC2_SEL_STAMP(tag) ((void)0)
 #endif
+// ... and cheap per-ROUND stamps of the two selection kernels (no atomic: a counter in the caller's Sel2, one store per
+// stamp): slot 0 = k_chan_select, slot 1 = k_select's frame 0; value = tag | range length << 12
+// (scripts/dev/chain_rounds.py -> profiles/r06_chan_select_rounds.csv)
+#if defined(VC2_DEBUG_TIMING)
+namespace vc2 {
+__device__ unsigned long long g_dbg_rt[2][128];
+__device__ int g_dbg_rv[2][128];
+}
+#define VC2_ROUND(S, tag, len) do { if ((S).dbg_slot >= 0 && (S).dbg_i < 127) { \
+    g_dbg_rt[(S).dbg_slot][(S).dbg_i] = wall_clock64(); g_dbg_rv[(S).dbg_slot][(S).dbg_i] = int(tag) | (int(len) << 12); \
+    ++(S).dbg_i; g_dbg_rv[(S).dbg_slot][127] = (S).dbg_i; } } while (0)
+#define VC2_ROUND_RAW(slot, i, tag) do { g_dbg_rt[slot][i] = wall_clock64(); g_dbg_rv[slot][i] = int(tag); } while (0)
+#else
+#define VC2_ROUND(S, tag, len) ((void)0)
+#define VC2_ROUND_RAW(slot, i, tag) ((void)0)
+#endif
 
 namespace vc2 {
 
@@ -81,6 +97,10 @@ template <typename W> struct Sel2 {
   uint32_t* xch;   // [24] cross-wave exchange: [0,16) per-wave totals, [16] cut, [20..21] dummy cells (predicated stores)
   int dumw;        // index of a dummy word in w[] (predicated swaps of no-op elements land there)
   int* status;     // the pass's status word (guard_hit), or nullptr
+#if defined(VC2_DEBUG_TIMING)
+  int dbg_slot;    // per-round stamps (VC2_ROUND): -1 none
+  mutable int dbg_i;
+#endif
 };
 __host__ __device__ inline size_t sel2_bytes(int n, int wbytes) {
   return (size_t(n + kSel2Pad) * size_t(wbytes) + 15) / 16 * 16 + size_t(n + kSel2Pad) * 2 * 2 + kSel2XchBytes + 32;
@@ -88,6 +108,9 @@ __host__ __device__ inline size_t sel2_bytes(int n, int wbytes) {
 template <typename W> __device__ __forceinline__ Sel2<W> sel2_carve(unsigned char* smem, int n, int* status = nullptr) {
   Sel2<W> S;
   S.status = status;
+#if defined(VC2_DEBUG_TIMING)
+  S.dbg_slot = -1; S.dbg_i = 0;
+#endif
   const size_t wb = (size_t(n + kSel2Pad) * sizeof(W) + 15) / 16 * 16;
   S.w = reinterpret_cast<W*>(smem);
   unsigned char* p = smem + wb;
@@ -399,6 +422,7 @@ __device__ __forceinline__ void introselect_tail64(const Sel2<W>& S, int lo_, in
   for (int guard = 0; h - l > 3 && guard < 256; ++guard) {
     if (depth == 0) { fallback = true; break; }
     --depth;
+    if (lane == 0) VC2_ROUND(S, 250, h - l);
     const int pa = l + 1, pb = l + (h - l) / 2, pc = h - 1;
     const W wlo = rdlane(el, l), wa = rdlane(el, pa), wb = rdlane(el, pb), wc = rdlane(el, pc);
     const uint32_t ka = T::key(wa), kb = T::key(wb), kc = T::key(wc);
@@ -475,6 +499,7 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
       }
       --depth;
       if (tid == 0) VC2_SEL_STAMP(210);                           // a cooperative round begins
+      if (tid == 0) VC2_ROUND(S, 210, hi - lo);
       int cut;
       if constexpr (NWA == NW) {
         cut = sel2_partition<W, NW, 1, COOP>(S, lo, hi, S.la, S.lb, tid);
@@ -511,13 +536,16 @@ __device__ __forceinline__ void introselect2(const Sel2<W>& S, int n, int nth, i
       }
       --depth;
       if (tid == 0) VC2_SEL_STAMP(230);                           // a one-wave LDS round begins
+      if (tid == 0) VC2_ROUND(S, 230, hi - lo);
       const int cut = sel2_partition<W, 1, 0, SOLO>(S, lo, hi, S.la, S.lb, tid);
       if (cut <= nth) lo = cut; else hi = cut;
       if (guard == 255 && tid == 0) guard_hit(1, S.status);
     }
+    if (!done && tid == 0) VC2_ROUND(S, 240, hi - lo);
     if (!done && tid == 0) s2_insertion_sort(S.w, lo, hi);
   }
   sel2_sync<NW>();
+  if (tid == 0) VC2_ROUND(S, 290, 0);
 }
 
 // torch.topk(v, k, largest=False) SET: afterwards S.w[0, k) holds the kept elements (ATen/native/TopKImpl.h:
