@@ -442,34 +442,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t c, uint32_t* xch, u
 }
 
 constexpr int kSelPre = (8192 + kSelNT - 1) / kSelNT;     // variances a thread holds (D <= 8192)
-template <typename W>
-__device__ __forceinline__ void chan_select_body(unsigned char* smem, const float (&pre)[kSelPre], int D, int k,
-                                                 uint8_t* __restrict__ mask, int* __restrict__ cols,
-                                                 int* __restrict__ perm, uint32_t* __restrict__ wperm,
-                                                 uint32_t* __restrict__ wcpos, int* status) {
+// what follows the selection replay: S.w[0, k) holds the kept channels in the order nth_element left them
+template <typename W, int NT>
+__device__ __forceinline__ void chan_select_epilogue(const Sel2<W>& S, int D, int k, uint8_t* __restrict__ mask,
+                                                     int* __restrict__ cols, int* __restrict__ perm,
+                                                     uint32_t* __restrict__ wperm, uint32_t* __restrict__ wcpos) {
   using T = WordTr<W>;
-  constexpr int NW = kSelNT / 64;
+  constexpr int NW = NT / 64;
   const int tid = threadIdx.x;
-  Sel2<W> S = sel2_carve<W>(smem, D, status);
-#if defined(VC2_DEBUG_TIMING)
-  S.dbg_slot = 0;
-#endif
-  if (tid == 0) VC2_ROUND(S, 201, D);                             // the variances are in registers
-#pragma unroll
-  for (int j = 0; j < kSelPre; ++j) { const int i = tid + j * kSelNT; if (i < D) S.w[i] = T::pack(topk_key(pre[j]), i); }
-  __syncthreads();
-  if (tid == 0) VC2_ROUND(S, 202, D);                             // packed words in LDS
-  if (k >= D) { if (perm) introselect2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
-  else topk_smallest2<W, NW, kSelSolo, kSelCoop, kSelActive>(S, D, k, tid);
-  // (no barrier here: both replays end with one, and the cases that replay nothing have the barrier above behind them)
   if (tid == 0) VC2_STAMP(205);
   if (tid == 0) VC2_ROUND(S, 291, k);
-  if (perm) for (int i = tid; i < k; i += kSelNT) perm[i] = T::idx(S.w[i]);
+  if (perm) for (int i = tid; i < k; i += NT) perm[i] = T::idx(S.w[i]);
   // kept flags (la is free now), mask bytes, and the ascending list of kept channels (ordered compaction).  S.w holds
   // every channel exactly once, the kept ones in [0, k): ONE pass writes every flag (no zeroing pass, no barrier between)
-  for (int i = tid; i < D; i += kSelNT) S.la[T::idx(S.w[i])] = (i < k || k >= D) ? 1 : 0;
+  for (int i = tid; i < D; i += NT) S.la[T::idx(S.w[i])] = (i < k || k >= D) ? 1 : 0;
   __syncthreads();
-  const int Ept = (D + kSelNT - 1) / kSelNT;
+  const int Ept = (D + NT - 1) / NT;
   const int b = tid * Ept, e = min(D, b + Ept);
   uint32_t cnt = 0;
   for (int p = b; p < e; ++p) cnt += S.la[p];
@@ -486,10 +474,35 @@ __device__ __forceinline__ void chan_select_body(unsigned char* smem, const floa
   if constexpr (sizeof(W) == 4) {
     if (wperm && wcpos && k < D) {
       __syncthreads();
-      for (int i = tid; i < k; i += kSelNT) { const W w = S.w[i]; wperm[i] = uint32_t(w); wcpos[i] = S.lb[T::idx(w)]; }
+      for (int i = tid; i < k; i += NT) { const W w = S.w[i]; wperm[i] = uint32_t(w); wcpos[i] = S.lb[T::idx(w)]; }
     }
   }
   if (tid == 0) VC2_ROUND(S, 299, k);
+}
+
+// the LDS-round engine (vc2_select2.h, second generation) on NT threads: every D <= 8192, both word widths
+template <typename W, int NT, int NPRE>
+__device__ __forceinline__ void chan_select_body(unsigned char* smem, const float (&pre)[NPRE], int D, int k,
+                                                 uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                 int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                 uint32_t* __restrict__ wcpos, int* status) {
+  using T = WordTr<W>;
+  constexpr int NW = NT / 64;
+  constexpr int SOLO = NT == kSelNT ? kSelSolo : 4, COOP = NT == kSelNT ? kSelCoop : 8, ACT = NT == kSelNT ? kSelActive : NW;
+  const int tid = threadIdx.x;
+  Sel2<W> S = sel2_carve<W>(smem, D, status);
+#if defined(VC2_DEBUG_TIMING)
+  S.dbg_slot = 0;
+#endif
+  if (tid == 0) VC2_ROUND(S, 201, D);                             // the variances are in registers
+#pragma unroll
+  for (int j = 0; j < NPRE; ++j) { const int i = tid + j * NT; if (i < D) S.w[i] = T::pack(topk_key(pre[j]), i); }
+  __syncthreads();
+  if (tid == 0) VC2_ROUND(S, 202, D);                             // packed words in LDS
+  if (k >= D) { if (perm) introselect2<W, NW, SOLO, COOP, ACT>(S, D, D - 1, tid); }    // nth_element(n-1) still permutes
+  else topk_smallest2<W, NW, SOLO, COOP, ACT>(S, D, k, tid);
+  // (no barrier here: both replays end with one, and the cases that replay nothing have the barrier above behind them)
+  chan_select_epilogue<W, NT>(S, D, k, mask, cols, perm, wperm, wcpos);
 }
 
 #ifndef VC2_DEV_ONLY
@@ -508,11 +521,60 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
   for (int j = 0; j < kSelPre; ++j) bad |= key_fits_u32(pre[j]) ? 0 : 1;
   // widened 16-bit variances pack into 32-bit words (the common case); arbitrary fp32 ones take 64-bit words
   // (wperm / wcpos are only requested for 16-bit inputs)
-  if (__syncthreads_or(bad)) chan_select_body<uint64_t>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr, status);
-  else chan_select_body<uint32_t>(smem, pre, D, k, mask, cols, perm, wperm, wcpos, status);
+  if (__syncthreads_or(bad)) chan_select_body<uint64_t, kSelNT, kSelPre>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr, status);
+  else chan_select_body<uint32_t, kSelNT, kSelPre>(smem, pre, D, k, mask, cols, perm, wperm, wcpos, status);
   if (threadIdx.x == 0) VC2_STAMP(209);
 }
 #endif
+
+// Round 6: the channel selection on FOUR waves (one per SIMD) with the whole array in registers for every partition round
+// (vc2_select2.h, third generation: sel3_rounds) -- D <= 256 E channels whose variances pack into 32-bit words (16-bit
+// inputs: always).  Thread t holds channels t, t + 256, ...: position p of the array = slot p / 256 of thread p % 256, which
+// is row (p / 64) of wave (p / 64) % 4 -- the layout sel3_rounds wants.  Variances that need 64-bit words take the LDS-round
+// engine on the same four waves.
+constexpr int kSel3NT = 256;
+template <int E>
+__global__ __launch_bounds__(kSel3NT) void k_chan_select3(const float* __restrict__ var_f32, int D, int k,
+                                                          uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                          int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                          uint32_t* __restrict__ wcpos, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using T = WordTr<uint32_t>;
+  const int tid = threadIdx.x;
+  int bad = 0;
+  if (tid == 0) VC2_STAMP(200);
+  if (tid == 0) VC2_ROUND_RAW(0, 120, 200);
+  float pre[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) { const int i = tid + j * kSel3NT; pre[j] = var_f32[i < D ? i : D - 1]; }
+#pragma unroll
+  for (int j = 0; j < E; ++j) bad |= key_fits_u32(pre[j]) ? 0 : 1;
+  if (__syncthreads_or(bad)) {
+    chan_select_body<uint64_t, kSel3NT, E>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr, status);
+    if (tid == 0) VC2_STAMP(209);
+    return;
+  }
+  Sel2<uint32_t> S = sel2_carve<uint32_t>(smem, D, status);
+#if defined(VC2_DEBUG_TIMING)
+  S.dbg_slot = 0;
+#endif
+  if (tid == 0) VC2_ROUND(S, 201, D);
+  uint32_t el[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = tid + j * kSel3NT;
+    el[j] = T::pack(topk_key(pre[j]), i < D ? i : 0);
+    if (i < D) S.w[i] = el[j];
+  }
+  __syncthreads();
+  if (tid == 0) VC2_ROUND(S, 202, D);
+  constexpr int NW = kSel3NT / 64;
+  if (k >= D) { if (perm) introselect3<NW, E, 4>(S, el, D, D - 1, tid); }              // nth_element(n-1) still permutes
+  else if (k > 0 && int64_t(k) * 64 <= int64_t(D)) { if (tid == 0) s2_heap_select(S.w, 0, k, D); __syncthreads(); }   // partial_sort regime
+  else if (k > 0) introselect3<NW, E, 4>(S, el, D, k - 1, tid);
+  chan_select_epilogue<uint32_t, kSel3NT>(S, D, k, mask, cols, perm, wperm, wcpos);
+  if (tid == 0) VC2_STAMP(209);
+}
 __host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
 
 // torch.topk(sorted=True)'s ORDER of the k kept channels from `perm` (what nth_element / partial_sort left in
@@ -3371,7 +3433,18 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
   if (tid == 0 && f == 0) VC2_STAMP(802);
   if (tid == 0) VC2_ROUND(S, 802, N);
   if (N > sel2_capacity(1, 4)) topk_smallest2<W, 4, 4, 8>(S, N, k, tid);
-  else if (tid < 64) topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
+  else if (tid < 64) {
+    // (round-6 experiment, compile-time opt-in: every round above 64 elements in registers too -- sel3_rounds; measured
+    //  1.1-1.4 us per round against the LDS rounds' 1.2-1.4, k_select 14.0 against 13.0 us: not kept as the default)
+#ifdef VC2_SEL3_SOLO
+    if constexpr (sizeof(W) == 4) {
+      if (N <= 256) topk_smallest3_solo<4>(S, N, k, tid);
+      else if (N <= 512) topk_smallest3_solo<8>(S, N, k, tid);
+      else topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
+    } else
+#endif
+    topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
+  }
   __syncthreads();
   if (tid == 0 && f == 0) VC2_STAMP(803);
   if (tid == 0) VC2_ROUND(S, 803, k);
@@ -4129,10 +4202,22 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what,
 }
 
 int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask, int* cols, int* perm,
-                       hipStream_t st, uint32_t* wperm = nullptr, uint32_t* wcpos = nullptr, int* status = nullptr) {
+                       hipStream_t st, uint32_t* wperm = nullptr, uint32_t* wcpos = nullptr, int* status = nullptr,
+                       bool words64_expected = false) {
   if (k <= 0 || k > D) return fail(VC2_ERR_UNSUPPORTED, "channel count k=%lld out of range for D=%lld",
                                    (long long)k, (long long)D);
   const size_t smem = chan_select_lds(int(D));
+  // VC2_SEL3=1 (experiment, round 6; OFF by default): D <= 4096 on four waves with the array in registers (k_chan_select3).
+  // Bit-identical (409 selection / full-pass tests green with it) and SLOWER: 26.1 against 20.9 us at D = 3584 -- its
+  // rounds are ~70 instructions per 64-element row with VALU -> SGPR -> VALU dependencies that one wave per SIMD cannot hide
+  // (4.2 / 3.0 / 2.3 / 2.4 us for the rounds the 16-wave LDS form does in 2.0 each: profiles/r06_b_sel3_register_rounds.csv)
+  static const int sel3_env = [] { const char* e = getenv("VC2_SEL3"); return e ? atoi(e) : 0; }();
+  if (sel3_env != 0 && D <= 4096 && !words64_expected) {
+    ProfScope ps_(KID_CHAN_SELECT, st);
+    { int rca = allow_big_lds(&k_chan_select3<16>, smem, "k_chan_select3"); if (rca) return rca; }
+    hipLaunchKernelGGL(k_chan_select3<16>, dim3(1), dim3(kSel3NT), smem, st, var_f32, int(D), int(k), mask, cols, perm, wperm, wcpos, status);
+    return check_launch("chan_select3");
+  }
   { int rca = allow_big_lds(&k_chan_select, smem, "k_chan_select"); if (rca) return rca; }
   { ProfScope ps_(KID_CHAN_SELECT, st);
   hipLaunchKernelGGL(k_chan_select, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, perm, wperm,
@@ -5034,7 +5119,7 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   uint32_t* wperm = strict && 2 * kc <= std::max<int64_t>(p.R, D) ? wsp<uint32_t>(ws, p.o_tmp_f32) : nullptr;
   uint32_t* wcpos = wperm ? wperm + kc : nullptr;
   int* const status = wsp<int>(ws, p.o_ticket) + kTkStatus;       // the pass's status word (-> K_out[1])
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos, status))) return rc;
+  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos, status, /*words64_expected=*/p.ES == 4))) return rc;
   const ChanSet cs = make_chanset(p, cols, spos, kc);
   // torch.topk's ORDER of the selected channels (needed only by the "torch order" fix-ups, which run after sweep 2)
   // is replayed by a rider workgroup of sweep 2 itself

@@ -88,7 +88,7 @@ __device__ unsigned long long g_sel2_dbg[128];
 
 constexpr int kXchCut = 16, kXchDummy = 20;
 constexpr int kSel2Pad = 64;           // positions a round may read past the end of the range (never used)
-constexpr int kSel2XchBytes = 128;
+constexpr int kSel2XchBytes = 512;     // 128 words: [0, 24) the LDS rounds' cells; [32, 128) the register rounds' (kX3*)
 
 template <typename W> struct Sel2 {
   W* w;            // [n + kSel2Pad]
@@ -476,6 +476,218 @@ __device__ __forceinline__ void introselect_tail64(const Sel2<W>& S, int lo_, in
     }
     wave_lds_order();
   }
+}
+
+// ---- third generation (round 6): the range lives in REGISTERS for ALL rounds ---------------------------------------
+// Measured (profiles/r06_a_chan_select_rounds.csv): a cooperative LDS round of the 16-wave channel selection costs 2.0 us
+// whatever its range (3584 or 1207 elements: four waves per SIMD, ~350 instructions each, issue-bound), a one-wave LDS
+// round 0.8-1.6 us, a register round (introselect_tail64) 0.36 us.  Here every round is a register round:
+//   * position p of the array is owned by (row r = (p - base) / 64, lane (p - base) % 64); row r belongs to wave r % NW and
+//     is that wave's register slot r / NW (E slots per lane: NW * E rows <= 64).  The words never move between rounds --
+//     a swap EXCHANGES two registers through a mailbox in rank space;
+//   * a v_cmp IS a ballot: the two stop sets of a row are two SGPR pairs; ranks are v_mbcnt on top of per-row prefix
+//     counts, which cross the waves as one packed word per row (one LDS store per wave, one barrier, one DPP scan);
+//   * the i-th stop from the left that is "not less than the pivot" (A) is swapped with the i-th from the right that is
+//     "not greater" (B) while it stands left of it -- decided per lane from the ranks alone (introselect_tail64's rule);
+//     swapped A number r leaves its word in mbA[r] and takes mbB[r], B number s (from the right) leaves mbB[s] and takes mbA[s];
+//   * S.w stays a SHADOW of the registers (one store per swapped element): the next round's pivot candidates, the serial
+//     fallbacks, the tail and the caller's epilogue read it.
+// Three workgroup barriers per multi-wave round (counts / mailbox / shadow + cut), none in the one-wave instantiation.
+constexpr int kX3Cnt = 32;      // xch words [32, 96): per-row stop counts, #A | #B << 16
+constexpr int kX3Cut = 96;      // [96, 112): per-wave cut candidates
+constexpr int kX3Dum = 112;     // predicated stores of lanes that have nothing to store
+
+__device__ __forceinline__ int mbcnt64(uint64_t m) {
+  return int(__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)));
+}
+
+// Partition rounds of std::__introselect on S.w[lo, hi) while hi - lo > stop_len and depth > 0.  el[j] = the word at
+// position base + (j * NW + wave) * 64 + lane (== S.w there; positions outside the array: anything).  All 64 * NW threads
+// call with identical (base, lo, hi, nth, depth); lo / hi / depth come back updated (identical in every thread).
+// mb: the mailbox, mbtop + 1 words (mbtop even, >= 2 (n / 2) + 16).
+// Slots are processed in GROUPS of four (1024 consecutive positions at NW = 4): a group the range does not meet is skipped
+// by one wave-uniform branch, inside a group the code is branch-free.  The two stop sets of a row are computed twice (before
+// and after the count barrier) rather than kept: 4 E SGPRs across a barrier mean spills to VGPR lanes.
+constexpr int kSel3Group = 4;
+__device__ __forceinline__ int mbcnt64_from(uint64_t m, int base) {      // base + lanes of m below me
+  return int(__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), uint32_t(base))));
+}
+template <int NW, int E>
+__device__ __forceinline__ void sel3_rounds(const Sel2<uint32_t>& S, uint32_t (&el)[E], int base, int& lo, int& hi, int nth,
+                                            int& depth, int stop_len, uint32_t* mb, int mbtop, int tid) {
+  using T = WordTr<uint32_t>;
+  constexpr int G = kSel3Group, NG = E / G;
+  static_assert(NW * E <= 64, "one lane per row in the prefix scan");
+  static_assert(E % G == 0, "whole groups");
+  const int lane = tid & 63;
+  const int wave = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;
+  const int p0 = base + wave * 64 + lane;                            // my position in slot 0; slot j: + j * NW * 64
+  // mailbox: swapped A number r leaves its word at index r, swapped B number s (from the right) at mbtop - s; each takes the
+  // other's, i.e. index mbtop - (its own).  dumi and mbtop - dumi lie in the gap between the two halves.
+  const int dumi = mbtop / 2 - 2;
+  for (int guard = 0; hi - lo > stop_len && hi - lo > 3 && depth > 0 && guard < 256; ++guard) {
+    --depth;
+    if (tid == 0) VC2_ROUND(S, NW > 1 ? 310 : 330, hi - lo);
+    const int first = lo + 1;
+    const uint32_t len = uint32_t(hi - first);
+    const int pb = lo + (hi - lo) / 2, pc = hi - 1;
+    const uint32_t wlo = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[lo])));
+    const uint32_t wa = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[first])));
+    const uint32_t wb = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[pb])));
+    const uint32_t wc = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[pc])));
+    int msrc;
+    uint32_t wp;
+    {
+      const uint32_t ka = T::key(wa), kb = T::key(wb), kc = T::key(wc);
+      const bool ab = ka < kb, bc = kb < kc, ac = ka < kc;          // __move_median_to_first
+      const int sel = ab ? (bc ? 1 : (ac ? 2 : 0)) : (ac ? 0 : (bc ? 2 : 1));
+      msrc = sel == 0 ? first : (sel == 1 ? pb : pc);
+      wp = sel == 0 ? wa : (sel == 1 ? wb : wc);
+    }
+    const uint32_t pk = T::key(wp);
+    // which groups of mine meet [lo, hi)  (bit g; wave-uniform)
+    uint32_t gact = 0u;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int gs = base + g * G * NW * 64, ge = gs + G * NW * 64;
+      gact |= (ge > lo && gs < hi) ? (1u << g) : 0u;
+    }
+    uint32_t cntrow = 0u;                                          // lane j: the packed counts of my slot j
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (NG > 1 && !((gact >> g) & 1u)) continue;                  // (no per-lane state is written in a skipped group)
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = g * G + jj;
+        const int p = p0 + j * NW * 64;
+        el[j] = (p == msrc) ? wlo : el[j];                          // iter_swap(lo, median), register copy
+        el[j] = (p == lo) ? wp : el[j];
+        const uint32_t k = T::key(el[j]);
+        const uint64_t m_in = __builtin_amdgcn_ballot_w64(uint32_t(p - first) < len);
+        const uint64_t mA = __builtin_amdgcn_ballot_w64(k >= pk) & m_in, mB = __builtin_amdgcn_ballot_w64(k <= pk) & m_in;
+        const uint32_t c = uint32_t(__builtin_popcountll(mA)) | (uint32_t(__builtin_popcountll(mB)) << 16);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(cntrow) : "s"(c), "n"(j));      // (c is wave-uniform: two s_bcnt1)
+      }
+    }
+    if (lane < E) S.xch[kX3Cnt + lane * NW + wave] = cntrow;        // (rows of skipped groups: zero)
+    sel2_sync<NW>();                                                // ---- 1: counts; every thread has read the candidates
+    if (tid == 0) { S.w[lo] = wp; S.w[msrc] = wlo; }                // iter_swap(lo, median), shadow copy
+    const uint32_t crow = lane < NW * E ? S.xch[kX3Cnt + lane] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(crow);
+    const uint32_t excl = incl - crow;
+    const int totB = int(uint32_t(__builtin_amdgcn_readlane(int(incl), 63)) >> 16);
+    uint32_t cand = 0xFFFFFFFFu;
+    int di[E];                                                      // where I left my word (dumi: nowhere)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (NG > 1 && !((gact >> g) & 1u)) continue;
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = g * G + jj;
+        const int p = p0 + j * NW * 64;
+        uint32_t w = el[j];
+        asm volatile("" : "+v"(w));                                 // (recompute the stop sets: see above)
+        const uint32_t k = T::key(w);
+        const bool in = uint32_t(p - first) < len, ge = k >= pk, le = k <= pk;
+        const uint64_t m_in = __builtin_amdgcn_ballot_w64(in);
+        const uint64_t mA = __builtin_amdgcn_ballot_w64(ge) & m_in, mB = __builtin_amdgcn_ballot_w64(le) & m_in;
+        const bool a = in && ge, b = in && le;
+        const uint32_t ex = uint32_t(__builtin_amdgcn_readlane(int(excl), j * NW + wave));
+        const int rA = mbcnt64_from(mA, int(ex & 0xFFFFu));                         // A's left of me
+        const int Bge = totB - mbcnt64_from(mB, int(ex >> 16));                     // B's at or right of me
+        const bool swapA = a && (Bge - (b ? 1 : 0)) > rA;                           // B's strictly right of me > A's left of me
+        const bool swapB = b && rA >= Bge;                                          // A's strictly left of me > B's strictly right of me
+        di[j] = swapA ? rA : (swapB ? mbtop + 1 - Bge : dumi);                      // (B number s = Bge - 1 -> mbtop - s)
+        mb[di[j]] = el[j];
+        const uint32_t cc = ((a && !swapA) || swapB) ? uint32_t(p) : 0xFFFFFFFFu;   // where `first` halts: the first A that
+        cand = cc < cand ? cc : cand;                                              //   stays, or the leftmost swapped B
+      }
+    }
+    const uint32_t wcut = wave_min_bcast_u32(cand);
+    if constexpr (NW > 1) { if (lane == 0) S.xch[kX3Cut + wave] = wcut; }
+    sel2_sync<NW>();                                                // ---- 2: mailbox, cut candidates
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (NG > 1 && !((gact >> g) & 1u)) continue;
+#pragma unroll
+      for (int jj = 0; jj < G; ++jj) {
+        const int j = g * G + jj;
+        const uint32_t got = mb[mbtop - di[j]];
+        const bool sw = di[j] != dumi;
+        el[j] = sw ? got : el[j];
+        S.w[sw ? p0 + j * NW * 64 : S.dumw] = el[j];
+      }
+    }
+    uint32_t cutv = wcut;
+    if constexpr (NW > 1) {
+#pragma unroll
+      for (int v = 0; v < NW; ++v) { const uint32_t t = S.xch[kX3Cut + v]; cutv = t < cutv ? t : cutv; }
+      cutv = uint32_t(__builtin_amdgcn_readfirstlane(int(cutv)));
+    }
+    sel2_sync<NW>();                                                // ---- 3: the shadow is current, the cells are free
+    const int cut = cutv < uint32_t(hi) ? int(cutv) : hi;
+    if (cut <= nth) lo = cut; else hi = cut;
+    if (guard == 255 && tid == 0) guard_hit(6, S.status);
+  }
+}
+
+// the rest of std::__introselect on S.w[lo, hi) by ONE wave (tid < 64): register rounds over up to 64 * E2 elements, the
+// last <= 64 by introselect_tail64, serial libstdc++ pieces at the depth limit / for <= 3 elements.  (A range longer than
+// 64 * E2 -- only possible with other callers' arguments -- falls back to the LDS rounds.)
+template <int E2>
+__device__ __forceinline__ void introselect3_finish(const Sel2<uint32_t>& S, int lo, int hi, int nth, int depth, int nmax,
+                                                    uint32_t* mb, int mbtop, int lane) {
+  if (hi - lo > kSel2TailMax && hi - lo <= 64 * E2 && depth > 0) {
+    uint32_t e2[E2];
+    const int base = lo;
+#pragma unroll
+    for (int j = 0; j < E2; ++j) { const int p = base + 64 * j + lane; e2[j] = S.w[p < nmax ? p : nmax - 1]; }
+    sel3_rounds<1, E2>(S, e2, base, lo, hi, nth, depth, kSel2TailMax, mb, mbtop, lane);
+  }
+  bool done = false;
+  for (int guard = 0; hi - lo > 3 && guard < 256; ++guard) {
+    if (hi - lo <= kSel2TailMax) { introselect_tail64<uint32_t>(S, lo, hi, nth, depth, lane); done = true; break; }
+    if (depth == 0) {
+      if (lane == 0) { s2_heap_select(S.w, lo, nth + 1, hi); const uint32_t t = S.w[lo]; S.w[lo] = S.w[nth]; S.w[nth] = t; }
+      done = true;
+      break;
+    }
+    --depth;
+    if (lane == 0) VC2_ROUND(S, 230, hi - lo);
+    const int cut = sel2_partition<uint32_t, 1, 0, 4>(S, lo, hi, S.la, S.lb, lane);
+    if (cut <= nth) lo = cut; else hi = cut;
+    if (guard == 255 && lane == 0) guard_hit(1, S.status);
+  }
+  if (!done && lane == 0) { VC2_ROUND(S, 240, hi - lo); s2_insertion_sort(S.w, lo, hi); }
+}
+
+// std::nth_element(first, first + nth, first + n) on S.w[0, n), n <= 64 * NW * E.  el[j]: the word at position
+// (j * NW + wave) * 64 + lane, already stored to S.w as well (a barrier behind the stores).  All 64 * NW threads call.
+template <int NW, int E, int E2>
+__device__ __forceinline__ void introselect3(const Sel2<uint32_t>& S, uint32_t (&el)[E], int n, int nth, int tid) {
+  if (n == 0 || nth >= n) return;
+  int lo = 0, hi = n;
+  int depth = 2 * (31 - __clz(n));
+  uint32_t* const mb = reinterpret_cast<uint32_t*>(S.la);           // la | lb: n + kSel2Pad words: A words [0, n / 2), B words (mbtop - n / 2, mbtop]
+  const int mbtop = (n / 2) * 2 + 16;
+  if constexpr (NW > 1) sel3_rounds<NW, E>(S, el, 0, lo, hi, nth, depth, 64 * E2, mb, mbtop, tid);
+  if (tid < 64) introselect3_finish<E2>(S, lo, hi, nth, depth, n + kSel2Pad - 1, mb, mbtop, tid);
+  sel2_sync<NW>();
+  if (tid == 0) VC2_ROUND(S, 290, 0);
+}
+
+// one-wave selections (k_select: N tokens of a frame): S.w[0, n) holds the words, n <= 64 * E2; lanes of ONE wave call
+template <int E2>
+__device__ __forceinline__ void topk_smallest3_solo(const Sel2<uint32_t>& S, int n, int k, int lane) {
+  if (k <= 0 || k >= n) return;
+  if (int64_t(k) * 64 <= int64_t(n)) {
+    if (lane == 0) s2_heap_select(S.w, 0, k, n);
+    wave_lds_order();
+    return;
+  }
+  introselect3_finish<E2>(S, 0, n, k - 1, 2 * (31 - __clz(n)), n + kSel2Pad - 1, reinterpret_cast<uint32_t*>(S.la), (n / 2) * 2 + 16, lane);
+  wave_lds_order();
+  if (lane == 0) VC2_ROUND(S, 290, 0);
 }
 
 // std::nth_element(first, first + nth, first + n) on S.w[0, n).  All 64*NW threads of the workgroup call this
