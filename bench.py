@@ -659,6 +659,26 @@ def main():
         e4 = time_steps(two, args.steps, False)
         out["two_clips_in_flight"] = {"ms_per_round": round(e4 / args.steps * 1e3, 4),
                                       "tokens_per_s": round(2 * F * N / (e4 / args.steps), 1)}
+        # ... and THREE: the throughput operating point of a serving loop -- one clip's 60 us chain of
+        # single-workgroup kernels runs under the sweeps of the two others.  Three DIFFERENT clips (513 MiB: X no longer
+        # fits the Infinity Cache, as with real clips); per-clip time, tokens/s and fraction of the 8 TB/s roofline
+        streams3 = streams + [torch.cuda.Stream()]
+        plans3 = plans + [vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base)]
+        xs3 = xs2 + [synth.make(F, N, D, dtype, seed=2, dist="drift").to(dev)]
+
+        def three():
+            for st, pl, xi in zip(streams3, plans3, xs3):
+                with torch.cuda.stream(st):
+                    pl.enqueue(xi)
+        for _ in range(args.warmup):
+            three()
+        e5 = min(time_steps(three, args.steps, False) for _ in range(2))
+        per_clip = e5 / args.steps / 3
+        out["three_clips_in_flight"] = {"us_per_clip": round(per_clip * 1e6, 2), "tokens_per_s": round(F * N / per_clip, 1),
+                                        "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / per_clip / 1e9, 1),
+                                        "pass_frac_of_8TBs": round(alg_bytes_pass(F, N, D, es, base) / per_clip / 1e9 / HBM_PEAK_GBS, 4),
+                                        "note": "three different clips, one stream and one plan each; inputs resident"}
+        del plans3, xs3
 
     # ---- side: the other dtypes of BASELINE.json's shapes, each behind its own parity gate (C++ oracle, same tensor):
     #      the target shape in fp32, and ONE clip of the batched-eval config (128 x 196 x 4096 fp16) --------------

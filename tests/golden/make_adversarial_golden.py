@@ -6,6 +6,14 @@ through the REFERENCE itself (build container only: needs /root/reference):
     python tests/golden/make_adversarial_golden.py      ->  tests/golden/adversarial_cases.json
     python tests/golden/make_adversarial_golden.py big  ->  tests/golden/adversarial_big_cases.json (round 5: the same inputs at
                                                             the target shape and at cfg3, bf16 and fp16 -- VERDICT r4 item 4)
+    python tests/golden/make_adversarial_golden.py f32  ->  tests/golden/adversarial_f32_cases.json (round 6, VERDICT r5 item 5:
+                                                            the same inputs in fp32, where nothing is rounded to a coarser type
+                                                            and a near-tie of two tokens' scores is decided by the last bit of
+                                                            torch's fp32 accumulation order AND of its vectorised exp -- the
+                                                            fixture records, per case, whether the oracle's `torch` mode picks
+                                                            the reference's kept indices ("stable") and, where it does not, how
+                                                            many tokens differ and how close the reference's own scores of the
+                                                            swapped tokens are)
 
 Data only (seeds, shapes, digests, index lists).  Also records, per case, how often the reference's centre values
 differ from the exactly rounded means -- i.e. how often torch's fp32 cascade decided a rounding -- and the largest
@@ -32,7 +40,7 @@ from vidcom2_amd import synth  # noqa: E402
 
 torch.set_grad_enabled(False)
 torch.set_num_threads(8)
-DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 CASES = [("adv", 16, 196, 512, "bf16", 0), ("adv", 16, 196, 512, "f16", 0), ("adv", 32, 100, 1024, "bf16", 1),
          ("adv", 8, 324, 768, "f16", 2), ("adv", 64, 196, 256, "bf16", 3)]
 # (name, F, N, D, dtype, seed, base)
@@ -40,7 +48,55 @@ BIG_CASES = [("adv_target", 128, 196, 3584, "bf16", 4, 0.25), ("adv_target", 128
              ("adv_cfg3", 64, 324, 3584, "bf16", 6, 0.125), ("adv_cfg3", 64, 324, 3584, "f16", 7, 0.125)]
 
 
+F32_CASES = [("adv_cfg1", 8, 196, 1024, "f32", 20, 0.25), ("adv_cfg1", 8, 196, 1024, "f32", 21, 0.25),
+             ("adv_small", 16, 196, 512, "f32", 22, 0.25), ("adv_cfg2", 32, 196, 3584, "f32", 23, 0.25),
+             ("adv_cfg2", 32, 196, 3584, "f32", 24, 0.25), ("adv_cfg3", 64, 324, 3584, "f32", 25, 0.125),
+             ("adv_target", 128, 196, 3584, "f32", 26, 0.25), ("adv_target", 128, 196, 3584, "f32", 27, 0.25)]
+
+
+def main_f32():
+    """fp32 `cancel` inputs: reference outputs + how the oracle's `torch` mode relates to them (see the module docstring)."""
+    import oracle as O
+    out = []
+    for (name, Fr, N, D, dn, seed, base) in F32_CASES:
+        x = synth.make(Fr, N, D, DT[dn], seed, "cancel")
+        sel = R.select_low_var_channels(x)
+        v, f = R.compute_gaussian_scores(sel, N)
+        scales = R.compute_scales(-v.mean(dim=-1), base)
+        ks = (scales * N).round().long().clamp(min=1).tolist()
+        idx = R.select_outlier_indices(v + f, scales, N)
+        g = R._map_linear_offset(idx, N).tolist()
+        total = (v + f).reshape(-1)
+        O.set_mode("torch")
+        try:
+            o = O.compress_indices(x, N, base)
+        finally:
+            O.set_mode("exact")
+        og = o["global_idx"].tolist()
+        only_ref, only_or = sorted(set(g) - set(og)), sorted(set(og) - set(g))
+        # the reference's OWN scores of the tokens the two sides disagree on: a disagreement is a near-tie iff, frame by
+        # frame, the scores of what one side keeps and the other drops are within the fp32 noise of each other
+        gap = 0.0
+        for fr in sorted({t // N for t in only_ref + only_or}):
+            a = [float(total[t]) for t in only_ref if t // N == fr]
+            b = [float(total[t]) for t in only_or if t // N == fr]
+            gap = max(gap, max(a + b) - min(a + b))
+        dv = float((o["v"].double() - v.double()).abs().max())
+        df = float((o["f"].double() - f.double()).abs().max())
+        out.append({"name": name, "F": Fr, "N": N, "D": D, "dtype": dn, "seed": seed, "dist": "cancel", "base": base,
+                    "x_sha256": synth.sha256_tensor(x), "ks": ks, "global_idx": g,
+                    "v_head": v[0, :16].tolist(), "f_head": f[0, :16].tolist(), "v_mean": float(v.double().mean()),
+                    "oracle_ks_equal": o["ks"].tolist() == ks, "stable": og == g,
+                    "oracle_only": only_or, "reference_only": only_ref, "tie_gap": gap,
+                    "oracle_max_dv": dv, "oracle_max_df": df})
+        print(name, Fr, N, D, seed, "stable" if og == g else f"{len(only_ref)} of {len(g)} kept tokens differ",
+              f"tie gap {gap:.2e}  max|dv| {dv:.2e} max|df| {df:.2e}  ks equal: {o['ks'].tolist() == ks}")
+    json.dump({"cases": out}, open(os.path.join(HERE, "adversarial_f32_cases.json"), "w"), indent=None)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f32":
+        return main_f32()
     big = len(sys.argv) > 1 and sys.argv[1] == "big"
     out = []
     for case in (BIG_CASES if big else CASES):

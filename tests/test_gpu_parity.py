@@ -571,6 +571,25 @@ def test_adversarial_centre_means(c, mode):
     assert synth.sha256_tensor(got.v_score) == c["v_sha256"] and synth.sha256_tensor(got.f_score) == c["f_sha256"]
 
 
+@pytest.mark.parametrize("c", load_json("adversarial_f32_cases.json")["cases"],
+                         ids=lambda c: f"advf32-{c['F']}x{c['N']}x{c['D']}-{c['seed']}")
+def test_fp32_cancellation_residue(c):
+    """the `cancel` inputs in fp32 (tests/golden/adversarial_f32_cases.json, from the reference).  The HIP
+    path must stand where the oracle stands: budgets equal to the reference's, scores within 1e-5, the reference's kept
+    indices on the `stable` cases and, on the others, exactly the recorded near-tie tokens swapped (reference scores
+    within 1e-6 of each other: decided by torch's fp32 summation order and its vectorised exp)."""
+    x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
+    assert synth.sha256_tensor(x) == c["x_sha256"]
+    got = vc.compress(x.to(dev()), c["N"], c["base"], want_scores=True)
+    assert got.ks.cpu().tolist() == c["ks"]
+    kept = set(got.global_idx.cpu().tolist())
+    assert sorted(kept - set(c["global_idx"])) == c["oracle_only"]
+    assert sorted(set(c["global_idx"]) - kept) == c["reference_only"]
+    assert np.allclose(got.v_score.cpu()[0, :16].tolist(), c["v_head"], rtol=0, atol=1e-5)
+    assert np.allclose(got.f_score.cpu()[0, :16].tolist(), c["f_head"], rtol=0, atol=1e-5)
+    assert abs(float(got.v_score.double().mean()) - c["v_mean"]) < 1e-6
+
+
 @pytest.mark.parametrize("c", [c for c in ADV if c["D"] in (1024, 3584)], ids=lambda c: f"ord-{c['F']}x{c['N']}x{c['D']}-{c['dtype']}")
 def test_torch_ordered_frame_sums_reproduce_the_reference(c):
     """VC2_S2_ORD=1 (opt-in): sweep 2 adds every frame's x^ in torch's own order (16-row blocks, k_norm_colsum2<.., ORD>)
@@ -748,6 +767,76 @@ def test_a_guard_hit_of_any_frame_reaches_the_caller():
         L.vc2_selftest_force_guard(-1)
         c = (ctypes.c_int32 * 8)()
         L.vc2_selftest_counters(c, 1)
+
+
+@pytest.mark.gpu
+def test_a_late_guard_hit_is_reported_when_the_plan_is_dropped():
+    """VERDICT r5 item 7 / ADVICE r5: a pass that returned on the early words of the host mirror and whose plan is never
+    used again -- dropped, cleared out of (or evicted from) the plan cache, or followed by an un-mirrored enqueue -- still
+    gets its final status word read: a RuntimeWarning where nothing may raise, the exception in front of ANY next pass."""
+    import gc
+    import warnings as W
+    from vidcom2_amd import vidcom2 as V
+    dev = torch.device("cuda:0")
+    F, N, D = 16, 196, 1024
+    x = synth.make(F, N, D, torch.bfloat16, 3, "drift").to(dev)
+    L = _ffi.lib()
+
+    def late_pass():
+        """a plan whose last pass returned early with a guard hit still on its way (None: finish() already saw it)"""
+        plan = V.CompressPlan(F, N, D, torch.bfloat16, dev, 0.25)
+        plan.enqueue(x, mirror=True); plan.finish(); plan._settle()
+        L.vc2_selftest_force_guard(3)
+        plan.new_outputs(); plan.enqueue(x, mirror=True)
+        try:
+            plan.finish()
+        except RuntimeError:
+            plan = None
+        L.vc2_selftest_force_guard(-1)
+        torch.cuda.synchronize()
+        return plan
+    try:
+        seen = 0
+        for how in ("del", "quiet", "plain_enqueue") * 4:
+            plan = late_pass()
+            if plan is None or plan._late is None:
+                continue
+            seen += 1
+            if how == "plain_enqueue":                           # an un-mirrored next pass settles the previous one too
+                with pytest.raises(RuntimeError, match="PREVIOUS pass.*selection replay"):
+                    plan.new_outputs(); plan.enqueue(x, mirror=False)
+                plan._late = None
+                continue
+            with W.catch_warnings(record=True) as rec:
+                W.simplefilter("always")
+                if how == "del":
+                    del plan; gc.collect()
+                else:
+                    plan.settle_quietly()
+            assert any("selection replay" in str(r.message) for r in rec), how
+        # (the early words normally precede the final one: at least one of the twelve tries must have been late)
+        assert seen >= 1
+        # the plan cache: clearing it settles its plans
+        V.clear_plan_cache()
+        good = vc.compress(x, N, 0.25)
+        L.vc2_selftest_force_guard(3)
+        try:
+            vc.compress(x, N, 0.25)
+            late = True
+        except RuntimeError:
+            late = False
+        L.vc2_selftest_force_guard(-1)
+        torch.cuda.synchronize()
+        with W.catch_warnings(record=True) as rec:
+            W.simplefilter("always")
+            V.clear_plan_cache()
+        assert (not late) or any("selection replay" in str(r.message) for r in rec)
+        assert torch.equal(vc.compress(x, N, 0.25).global_idx, good.global_idx)
+    finally:
+        L.vc2_selftest_force_guard(-1)
+        c = (ctypes.c_int32 * 8)()
+        L.vc2_selftest_counters(c, 1)
+        V.clear_plan_cache()
 
 
 @pytest.mark.gpu

@@ -176,6 +176,38 @@ def test_oracle_matches_the_reference_on_adversarial_centre_means():
         O.set_mode("exact")
 
 
+def test_fp32_cancellation_residue_is_pinned():
+    """VERDICT r5 item 5.  tests/golden/adversarial_f32_cases.json: the `cancel` inputs in fp32, through the reference.
+    With fp32 scores nothing is rounded to a coarser type, so two tokens whose scores tie -- or differ in the last bit --
+    are ordered by the last bit of torch's fp32 accumulation order and of its vectorised exp (MKL VML in this torch build:
+    DESIGN.md section 3), which neither the oracle nor the kernels model.  What IS pinned, per case: budgets equal the
+    reference's; scores within 1e-5 (measured < 5e-7); the kept set equals the reference's on the `stable` cases and, on
+    the others, differs by exactly the recorded tokens (<= 0.2 % of the kept ones) whose REFERENCE scores lie within
+    1e-6 of each other -- near-ties, not errors."""
+    cases = load_json("adversarial_f32_cases.json")["cases"]
+    assert len(cases) >= 6 and any(not c["stable"] for c in cases) and any(c["stable"] for c in cases)
+    assert {(c["F"], c["N"], c["D"]) for c in cases} >= {(8, 196, 1024), (32, 196, 3584), (128, 196, 3584)}
+    for c in cases:
+        assert c["oracle_ks_equal"] and c["oracle_max_dv"] < 1e-5 and c["oracle_max_df"] < 1e-5
+        assert c["tie_gap"] <= 1e-6 and len(c["reference_only"]) == len(c["oracle_only"])
+        assert len(c["reference_only"]) <= max(1, len(c["global_idx"]) // 500)
+        assert c["stable"] == (not c["reference_only"])
+    O.set_mode("torch")
+    try:
+        for c in [c for c in cases if c["F"] * c["N"] * c["D"] <= 16 * 196 * 1024]:     # (the larger ones: the -m gpu test, HIP == this relation)
+            x = synth.make(c["F"], c["N"], c["D"], DT[c["dtype"]], c["seed"], c["dist"])
+            assert synth.sha256_tensor(x) == c["x_sha256"]
+            r = O.compress_indices(x, c["N"], c["base"])
+            assert r["ks"].tolist() == c["ks"]
+            got = set(r["global_idx"].tolist())
+            assert sorted(got - set(c["global_idx"])) == c["oracle_only"]
+            assert sorted(set(c["global_idx"]) - got) == c["reference_only"]
+            assert np.allclose(r["v"][0, :16].tolist(), c["v_head"], rtol=0, atol=1e-5)
+            assert np.allclose(r["f"][0, :16].tolist(), c["f_head"], rtol=0, atol=1e-5)
+    finally:
+        O.set_mode("exact")
+
+
 def test_oracle_matches_the_reference_on_long_clips():
     """tests/golden/make_long_golden.py: more than 2^19 tokens per video, where torch's outer-sum cascade switches to
     level_power 5 (blocks of 32 rows).  Four of the fixtures are built (`cancel`) so that the reference's video centre

@@ -4196,7 +4196,7 @@ template <typename K> int allow_big_lds(K kernel, size_t smem, const char* what,
   if (g_attr_done.count(key)) return VC2_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      int(160 * 1024 - 256 - static_lds));
-  if (e != hipSuccess) return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(VC2_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e)); }
   g_attr_done.insert(key);
   return VC2_OK;
 }
@@ -5023,10 +5023,14 @@ int vc2_keep_positions(const uint8_t* video_mask, int64_t S, const int64_t* kept
       (void)hipGetLastError();
     }
   }
-  const int use_bitmap = S <= kKeepBitmapMaxS ? 1 : 0;
-  const size_t smem = use_bitmap ? size_t((S + 31) / 32) * 4 + 16 : 16;
+  int use_bitmap = S <= kKeepBitmapMaxS ? 1 : 0;
+  size_t smem = use_bitmap ? size_t((S + 31) / 32) * 4 + 16 : 16;
   auto go = [&](auto kernel) -> int {
     int rca = allow_big_lds(kernel, smem, "k_keep_positions", 128);
+    if (rca && use_bitmap) {      // (a device that does not grant the bitmap's LDS: the binary-search form needs 16 bytes)
+      use_bitmap = 0; smem = 16; g_err[0] = 0;
+      rca = allow_big_lds(kernel, smem, "k_keep_positions", 128);
+    }
     if (rca) return rca;
     hipLaunchKernelGGL(kernel, dim3(1), dim3(kKeepNT), smem, static_cast<hipStream_t>(stream), video_mask, S, kept,
                        K_dev, K_max, visual_mask, keep_out, keep_out ? keep_cap : 0, vis_rows_out,

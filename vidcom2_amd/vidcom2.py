@@ -11,6 +11,7 @@ input's device.  Tensors must live on a ROCm device: there is no CPU fallback.
 """
 from __future__ import annotations
 
+import atexit
 import collections
 import ctypes
 import os
@@ -195,8 +196,9 @@ class CompressPlan:
                 raise RuntimeError(f"tail must be [{self.tail_rows}, {self.D}] {self.dtype} on {self.device}")
             tail = tail.contiguous()
         khost = None
+        self._settle()                                   # (a previous pass that returned on its early status words: ANY next
+        #                                                   enqueue of the plan reads its final word first, mirrored or not)
         if mirror:
-            self._settle()                               # (a previous pass that returned on its early status words)
             if self._khost is None:
                 self._khost = _khost_get()               # (pinned words from the process-wide pool: never freed)
                 self._khost_addr, self._khost_word, self._khost_final = self._khost.addr, self._khost.word, self._khost.final
@@ -213,9 +215,26 @@ class CompressPlan:
                                         ptr(tail if self.tail_rows else None), self.tail_rows,
                                         1 if have_stats else 0, khost,
                                         stream_ptr(self.device) if stream is None else ctypes.c_void_p(stream.cuda_stream))
+        if rc != 0 and mirror:                           # (nothing was launched: the mirror block is not in flight)
+            self._khost.in_flight = False
+            self._khost_armed = False
         check(rc, "vc2_compress")
 
+    def settle_quietly(self) -> None:
+        """The last word on a pass that returned on its early status words, for the places that must not raise -- the
+        plan is dropped (`__del__`), evicted from or cleared out of the plan cache, or the process ends: a late
+        selection-guard hit is REPORTED there (RuntimeWarning; a "cannot happen" bit -- the caller's result is already
+        in its hands), where `_settle` raises it in front of the plan's next pass."""
+        try:
+            self._settle()
+        except RuntimeError as e:
+            warnings.warn(f"vidcom2_amd: {e}", RuntimeWarning, stacklevel=2)
+        except Exception:                                # (interpreter shutdown: torch half gone)
+            pass
+
     def __del__(self):
+        if getattr(self, "_late", None) is not None:
+            self.settle_quietly()
         kh = getattr(self, "_khost", None)
         if kh is not None:
             try:
@@ -316,9 +335,12 @@ def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores
                 _PLAN_CACHE[key] = plan
                 # bounded by entries AND by bytes (a long clip's workspace is hundreds of MB): oldest first
                 # (a cached plan keeps its workspace AND its last output set, plus a spare one: all counted)
+                evicted = []
                 while len(_PLAN_CACHE) > _PLAN_CACHE_MAX or \
                         (len(_PLAN_CACHE) > 1 and sum(p.cached_bytes() for p in _PLAN_CACHE.values()) > _PLAN_CACHE_BYTES):
-                    _PLAN_CACHE.popitem(last=False)
+                    evicted.append(_PLAN_CACHE.popitem(last=False)[1])
+            for old in evicted:               # (outside the lock: may read a device word)
+                old.settle_quietly()          # a pass that returned on its early status words gets its last word here
     else:
         plan.new_outputs()
     return plan
@@ -326,7 +348,13 @@ def _cached_plan(F, N, D, dtype, device, base_scale, mapper, grid_h, want_scores
 
 def clear_plan_cache() -> None:
     with _PLAN_LOCK:
+        plans = list(_PLAN_CACHE.values())
         _PLAN_CACHE.clear()
+    for p in plans:
+        p.settle_quietly()
+
+
+atexit.register(clear_plan_cache)            # (the last call of the process: its final status word is read, not lost)
 
 
 class _KHost:
@@ -343,7 +371,7 @@ class _KHost:
         self.in_flight = False
 
 
-_KHOST_LOCK = threading.Lock()
+_KHOST_LOCK = threading.RLock()       # (re-entrant: a garbage collection inside the locked region may finalise a plan -> _khost_put)
 _KHOST_FREE: list = []
 _KHOST_QUARANTINE: list = []         # returned while their pass may still write the final word
 
@@ -433,27 +461,37 @@ def compress(flattened_feat: torch.Tensor, tpf: int, base_scale: float = 0.25, m
 
 
 _LANES: dict = {}
+_LANES_LOCK = threading.Lock()
 
 
 def _lane_streams(dev: torch.device, n: int):
     """The n extra streams compress_batch runs clips on -- created once per (device, thread) and kept: the plan cache is
     keyed by stream, so fresh streams per call meant fresh plans (and workspaces) per call: 0.5-1.2 ms of set-up per batch."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), threading.get_ident())
-    lst = _LANES.setdefault(key, [])
-    while len(lst) < n:
-        lst.append(torch.cuda.Stream(dev))
-    return lst[:n]
+    with _LANES_LOCK:
+        if key not in _LANES:                 # a new thread: drop the lanes of threads that have ended
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _LANES if k[1] not in alive]:
+                del _LANES[k]
+        lst = _LANES.setdefault(key, [])
+        while len(lst) < n:
+            lst.append(torch.cuda.Stream(dev))
+        return lst[:n]
 
 
 BATCH_LANES = 3          # compress_batch's default: clips in flight (16 cfg5 clips: 254 / 216 / 203 / 197 us per clip with 1 / 2 / 3 / 4)
 
 
-def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = BATCH_LANES, gather: bool = True):
+def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = BATCH_LANES, gather: bool = True,
+                   own_storage: bool = False):
     """Compress several clips (a list of [F_i * tpf, D] tensors) with up to `in_flight` of them running
     concurrently, one HIP stream each.  A single pass leaves the GPU idle during its single-workgroup selection
     replays; further clips in flight fill those gaps (DESIGN.md "clips in flight"; every lane keeps a plan = a workspace).
     Returns one CompressionResult per clip, in order.  The reference has no batched form: its harness loops
-    over clips (lmms-eval, batch size 1 per rank)."""
+    over clips (lmms-eval, batch size 1 per rank).
+    Storage: for clips of ONE shape every result is a VIEW into batch-wide buffers (one allocation per output kind), so
+    keeping any clip's rows / indices alive keeps the whole batch's buffers alive (n * capacity * D elements);
+    own_storage=True hands every clip its own tensors instead (one extra device copy of the kept rows)."""
     clips = [_prep(c, "clip") for c in clips]
     if not clips:
         return []
@@ -499,7 +537,10 @@ def compress_batch(clips, tpf: int, base_scale: float = 0.25, in_flight: int = B
     for i, (K, status) in enumerate(words):
         if status:
             _raise_status(int(status), p0.cap, int(K))
-        out.append(CompressionResult(rows_all[i, :K] if gather else None, idx_all[i, :K], ks_all[i], int(K), None, None))
+        rows_i, idx_i, ks_i = (rows_all[i, :K] if gather else None), idx_all[i, :K], ks_all[i]
+        if own_storage:
+            rows_i, idx_i, ks_i = (rows_i.clone() if gather else None), idx_i.clone(), ks_i.clone()
+        out.append(CompressionResult(rows_i, idx_i, ks_i, int(K), None, None))
     return out
 
 
