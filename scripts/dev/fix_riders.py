@@ -9,7 +9,7 @@ import torch
 import vidcom2_amd as vc
 from vidcom2_amd import _ffi, synth
 wl = sys.argv[2] if len(sys.argv) > 2 else "cfg5clip"
-F, N, D, dt = {"cfg5clip": (128, 196, 4096, torch.float16), "target": (128, 196, 3584, torch.bfloat16)}[wl]
+F, N, D, dt = {"cfg5clip": (128, 196, 4096, torch.float16), "target": (128, 196, 3584, torch.bfloat16), "target_f16": (128, 196, 3584, torch.float16)}[wl]
 x = synth.make(F, N, D, dt, 0, "drift").cuda()
 plan = vc.vidcom2.CompressPlan(F, N, D, dt, x.device, 0.25)
 L = ctypes.CDLL(_ffi.LIB_PATH)

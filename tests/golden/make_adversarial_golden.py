@@ -67,30 +67,33 @@ def main_f32():
         idx = R.select_outlier_indices(v + f, scales, N)
         g = R._map_linear_offset(idx, N).tolist()
         total = (v + f).reshape(-1)
-        O.set_mode("torch")
-        try:
-            o = O.compress_indices(x, N, base)
-        finally:
-            O.set_mode("exact")
-        og = o["global_idx"].tolist()
-        only_ref, only_or = sorted(set(g) - set(og)), sorted(set(og) - set(g))
-        # the reference's OWN scores of the tokens the two sides disagree on: a disagreement is a near-tie iff, frame by
-        # frame, the scores of what one side keeps and the other drops are within the fp32 noise of each other
-        gap = 0.0
-        for fr in sorted({t // N for t in only_ref + only_or}):
-            a = [float(total[t]) for t in only_ref if t // N == fr]
-            b = [float(total[t]) for t in only_or if t // N == fr]
-            gap = max(gap, max(a + b) - min(a + b))
-        dv = float((o["v"].double() - v.double()).abs().max())
-        df = float((o["f"].double() - f.double()).abs().max())
-        out.append({"name": name, "F": Fr, "N": N, "D": D, "dtype": dn, "seed": seed, "dist": "cancel", "base": base,
-                    "x_sha256": synth.sha256_tensor(x), "ks": ks, "global_idx": g,
-                    "v_head": v[0, :16].tolist(), "f_head": f[0, :16].tolist(), "v_mean": float(v.double().mean()),
-                    "oracle_ks_equal": o["ks"].tolist() == ks, "stable": og == g,
-                    "oracle_only": only_or, "reference_only": only_ref, "tie_gap": gap,
-                    "oracle_max_dv": dv, "oracle_max_df": df})
-        print(name, Fr, N, D, seed, "stable" if og == g else f"{len(only_ref)} of {len(g)} kept tokens differ",
-              f"tie gap {gap:.2e}  max|dv| {dv:.2e} max|df| {df:.2e}  ks equal: {o['ks'].tolist() == ks}")
+        rec = {"name": name, "F": Fr, "N": N, "D": D, "dtype": dn, "seed": seed, "dist": "cancel", "base": base,
+               "x_sha256": synth.sha256_tensor(x), "ks": ks, "global_idx": g,
+               "v_head": v[0, :16].tolist(), "f_head": f[0, :16].tolist(), "v_mean": float(v.double().mean())}
+        # two relations: the oracle's `torch` mode (fp32 accumulation in torch's order: the closest restatement) and its
+        # `exact` mode (fp64 accumulation: what the HIP path computes for fp32 inputs -- its kept set must equal THIS one)
+        for mode in ("torch", "exact"):
+            O.set_mode(mode)
+            try:
+                o = O.compress_indices(x, N, base)
+            finally:
+                O.set_mode("exact")
+            og = o["global_idx"].tolist()
+            only_ref, only_or = sorted(set(g) - set(og)), sorted(set(og) - set(g))
+            # the reference's OWN scores of the tokens the two sides disagree on: a disagreement is a near-tie iff, frame by
+            # frame, the scores of what one side keeps and the other drops are within the fp32 noise of each other
+            gap = 0.0
+            for fr in sorted({t // N for t in only_ref + only_or}):
+                a = [float(total[t]) for t in only_ref if t // N == fr]
+                b = [float(total[t]) for t in only_or if t // N == fr]
+                gap = max(gap, max(a + b) - min(a + b))
+            dv = float((o["v"].double() - v.double()).abs().max())
+            df = float((o["f"].double() - f.double()).abs().max())
+            rec[mode] = {"ks_equal": o["ks"].tolist() == ks, "stable": og == g, "oracle_only": only_or,
+                         "reference_only": only_ref, "tie_gap": gap, "max_dv": dv, "max_df": df}
+            print(name, Fr, N, D, seed, mode, "stable" if og == g else f"{len(only_ref)} of {len(g)} kept tokens differ",
+                  f"tie gap {gap:.2e}  max|dv| {dv:.2e} max|df| {df:.2e}  ks equal: {o['ks'].tolist() == ks}")
+        out.append(rec)
     json.dump({"cases": out}, open(os.path.join(HERE, "adversarial_f32_cases.json"), "w"), indent=None)
 
 

@@ -575,33 +575,37 @@ def test_adversarial_centre_means(c, mode):
                          ids=lambda c: f"advf32-{c['F']}x{c['N']}x{c['D']}-{c['seed']}")
 def test_fp32_cancellation_residue(c):
     """the `cancel` inputs in fp32 (tests/golden/adversarial_f32_cases.json, from the reference).  The HIP
-    path must stand where the oracle stands: budgets equal to the reference's, scores within 1e-5, the reference's kept
-    indices on the `stable` cases and, on the others, exactly the recorded near-tie tokens swapped (reference scores
-    within 1e-6 of each other: decided by torch's fp32 summation order and its vectorised exp)."""
+    path must stand where the oracle's fp64-accumulating mode stands (what the kernels do for fp32 inputs): budgets equal to
+    the reference's, scores within 1e-5, the reference's kept indices on the `stable` cases and, on the others, exactly the
+    recorded near-tie tokens swapped (reference scores within 1e-6 of each other: decided by torch's fp32 summation order
+    and its vectorised exp)."""
     x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
     assert synth.sha256_tensor(x) == c["x_sha256"]
     got = vc.compress(x.to(dev()), c["N"], c["base"], want_scores=True)
     assert got.ks.cpu().tolist() == c["ks"]
     kept = set(got.global_idx.cpu().tolist())
-    assert sorted(kept - set(c["global_idx"])) == c["oracle_only"]
-    assert sorted(set(c["global_idx"]) - kept) == c["reference_only"]
+    m = c["exact"]                   # (fp32 inputs: the kernels accumulate in fp64 -- the oracle's `exact` relation to the reference)
+    assert sorted(kept - set(c["global_idx"])) == m["oracle_only"]
+    assert sorted(set(c["global_idx"]) - kept) == m["reference_only"]
     assert np.allclose(got.v_score.cpu()[0, :16].tolist(), c["v_head"], rtol=0, atol=1e-5)
     assert np.allclose(got.f_score.cpu()[0, :16].tolist(), c["f_head"], rtol=0, atol=1e-5)
     assert abs(float(got.v_score.double().mean()) - c["v_mean"]) < 1e-6
 
 
+@pytest.mark.parametrize("ord_form", ["1", "0"])
 @pytest.mark.parametrize("c", [c for c in ADV if c["D"] in (1024, 3584)], ids=lambda c: f"ord-{c['F']}x{c['N']}x{c['D']}-{c['dtype']}")
-def test_torch_ordered_frame_sums_reproduce_the_reference(c):
-    """VC2_S2_ORD=1 (opt-in): sweep 2 adds every frame's x^ in torch's own order (16-row blocks, k_norm_colsum2<.., ORD>)
-    and k_frame_centres combines the block sums the way torch's cascade does -- no margin, no replay for any frame
-    mean.  A completely different route to the same bits: on the adversarial `cancel` inputs (the reference's own centres
-    are decided by the summation order in up to 335 places) it must reproduce the reference exactly, like the default
-    form with its margins and replays does."""
+def test_torch_ordered_frame_sums_reproduce_the_reference(c, ord_form):
+    """VC2_S2_ORD=1 (the DEFAULT since round 6): sweep 2 adds every frame's x^ in torch's own order (16-row blocks,
+    k_norm_colsum2<.., ORD>) and k_frame_centres combines the block sums the way torch's cascade does -- no margin, no
+    replay for any frame mean.  VC2_S2_ORD=0: the form of rounds 1-5 (exact fp64 frame sums, a margin around every T
+    rounding boundary, boundary-near means replayed in torch's order).  Two completely different routes to the same bits:
+    on the adversarial `cancel` inputs (the reference's own centres are decided by the summation order in up to 335
+    places) BOTH must reproduce the reference exactly."""
     import os
     x = make_input(c["F"], c["N"], c["D"], c["dtype"], c["seed"], c["dist"])
     old = os.environ.get("VC2_S2_ORD")
     try:
-        os.environ["VC2_S2_ORD"] = "1"
+        os.environ["VC2_S2_ORD"] = ord_form
         got = vc.compress(x.to(dev()), c["N"], c["base"], want_scores=True)
         torch.cuda.synchronize()
     finally:
@@ -618,9 +622,11 @@ def test_torch_ordered_frame_sums_reproduce_the_reference(c):
                                    (4, 16, 1024, "f16", "drift"), (6, 7, 1024, "bf16", "cancel"), (2, 512, 1024, "f16", "iid"),
                                    (40, 33, 1024, "bf16", "cancel"), (130, 48, 1024, "f16", "drift")],
                          ids=lambda s_: "x".join(map(str, s_)))
-def test_torch_ordered_frame_sums_on_odd_frame_lengths(shape):
-    """The ORD form against the oracle where its geometry has corners: frames of 9 / 4 leftover rows, none, fewer than one
-    block, 32 blocks, more blocks than a workgroup's waves, several blocks per wave (many frames)."""
+@pytest.mark.parametrize("ord_form", ["1", "0"])
+def test_torch_ordered_frame_sums_on_odd_frame_lengths(shape, ord_form):
+    """The ORD form (and, ord_form = 0, the margin-and-replay form it replaced as the default) against the oracle where the
+    ORD geometry has corners: frames of 9 / 4 leftover rows, none, fewer than one block, 32 blocks, more blocks than a
+    workgroup's waves, unequal pieces per frame (OrdGeo), several blocks per wave (many frames)."""
     import os
     F, N, D, dn, dist = shape
     x = make_input(F, N, D, dn, 11, dist)
@@ -628,7 +634,7 @@ def test_torch_ordered_frame_sums_on_odd_frame_lengths(shape):
     ref = O.compress_indices(x, N, 0.25)
     old = os.environ.get("VC2_S2_ORD")
     try:
-        os.environ["VC2_S2_ORD"] = "1"
+        os.environ["VC2_S2_ORD"] = ord_form
         got = vc.compress(x.to(dev()), N, 0.25, want_scores=True)
         torch.cuda.synchronize()
     finally:

@@ -185,27 +185,32 @@ def test_fp32_cancellation_residue_is_pinned():
     the others, differs by exactly the recorded tokens (<= 0.2 % of the kept ones) whose REFERENCE scores lie within
     1e-6 of each other -- near-ties, not errors."""
     cases = load_json("adversarial_f32_cases.json")["cases"]
-    assert len(cases) >= 6 and any(not c["stable"] for c in cases) and any(c["stable"] for c in cases)
+    assert len(cases) >= 6 and any(not c["torch"]["stable"] for c in cases) and any(c["torch"]["stable"] for c in cases)
     assert {(c["F"], c["N"], c["D"]) for c in cases} >= {(8, 196, 1024), (32, 196, 3584), (128, 196, 3584)}
     for c in cases:
-        assert c["oracle_ks_equal"] and c["oracle_max_dv"] < 1e-5 and c["oracle_max_df"] < 1e-5
-        assert c["tie_gap"] <= 1e-6 and len(c["reference_only"]) == len(c["oracle_only"])
-        assert len(c["reference_only"]) <= max(1, len(c["global_idx"]) // 500)
-        assert c["stable"] == (not c["reference_only"])
-    O.set_mode("torch")
-    try:
-        for c in [c for c in cases if c["F"] * c["N"] * c["D"] <= 16 * 196 * 1024]:     # (the larger ones: the -m gpu test, HIP == this relation)
-            x = synth.make(c["F"], c["N"], c["D"], DT[c["dtype"]], c["seed"], c["dist"])
-            assert synth.sha256_tensor(x) == c["x_sha256"]
-            r = O.compress_indices(x, c["N"], c["base"])
+        for mode in ("torch", "exact"):                  # (`exact`: fp64 accumulation -- what the HIP path does for fp32 inputs)
+            m = c[mode]
+            assert m["ks_equal"] and m["max_dv"] < 1e-5 and m["max_df"] < 1e-5
+            # torch-order accumulation: <= 0.2 % of the kept tokens, reference scores within 5e-7; fp64 accumulation (the
+            # kernels' fp32 path): <= 1 %, within 2e-6 -- 42 of 6272 at the target shape, the measured worst case
+            assert m["tie_gap"] <= (5e-7 if mode == "torch" else 2e-6) and len(m["reference_only"]) == len(m["oracle_only"])
+            assert len(m["reference_only"]) <= max(2, len(c["global_idx"]) // (500 if mode == "torch" else 100))
+            assert m["stable"] == (not m["reference_only"])
+    for c in [c for c in cases if c["F"] * c["N"] * c["D"] <= 16 * 196 * 1024]:     # (the larger ones: the -m gpu test, HIP == the `exact` relation)
+        x = synth.make(c["F"], c["N"], c["D"], DT[c["dtype"]], c["seed"], c["dist"])
+        assert synth.sha256_tensor(x) == c["x_sha256"]
+        for mode in ("torch", "exact"):
+            O.set_mode(mode)
+            try:
+                r = O.compress_indices(x, c["N"], c["base"])
+            finally:
+                O.set_mode("exact")
             assert r["ks"].tolist() == c["ks"]
             got = set(r["global_idx"].tolist())
-            assert sorted(got - set(c["global_idx"])) == c["oracle_only"]
-            assert sorted(set(c["global_idx"]) - got) == c["reference_only"]
+            assert sorted(got - set(c["global_idx"])) == c[mode]["oracle_only"]
+            assert sorted(set(c["global_idx"]) - got) == c[mode]["reference_only"]
             assert np.allclose(r["v"][0, :16].tolist(), c["v_head"], rtol=0, atol=1e-5)
             assert np.allclose(r["f"][0, :16].tolist(), c["f_head"], rtol=0, atol=1e-5)
-    finally:
-        O.set_mode("exact")
 
 
 def test_oracle_matches_the_reference_on_long_clips():

@@ -1337,6 +1337,29 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_norm_colsum(const void* __re
 // Rows the fast path cannot take (norm outside the range where the fp32 sum of squares is safe, a zero / subnormal
 // quotient in bf16, non-finite data) are redone on the spot exactly as the general kernel does them (fp64 sum of squares,
 // exactly rounded division; rflag[row] = 1 tells sweep 3).
+// ORD geometry (round 6: UNEQUAL pieces).  A wave sweeps whole 16-row blocks of ONE frame, so a frame of nblk = N / 16
+// blocks is cut into S_f workgroups of nblk / S_f blocks (+ 1 for the first nblk % S_f): with one S for every frame the
+// target shape (12 blocks, 448 workgroup slots for 128 frames) had 3 x 128 = 384 workgroups of 4 blocks -- 64 / 68 rows,
+// the busiest CU 132 rows against the row-interleaved form's 112: 34.7 against 30.6 us.  Now the first nA frames take S - 1
+// workgroups and the others S: 64 frames x 3 workgroups of 4 blocks + 64 frames x 4 workgroups of 3 blocks = 448 -- 7 blocks
+// per CU.  The launch lists the LARGER workgroups first (riders, then the nA frames' workgroups, then the others'): the
+// dispatcher hands workgroup i and workgroup i + 256 to the same CU, a large one and a small one.
+// The frame's N % 16 leftover rows (their own chain) go to wave 3 of the frame's last workgroup, whether it has blocks or not.
+struct OrdGeo { int S, nA; };                                     // S: workgroups of the frames >= nA (the stride of `part`)
+__host__ __device__ inline int ord_frame_wgs(const OrdGeo& g, int f) { return f < g.nA ? g.S - 1 : g.S; }
+__host__ __device__ inline int ord_total_wgs(const OrdGeo& g, int F) { return g.nA * (g.S - 1) + (F - g.nA) * g.S; }
+struct OrdPiece { int f, j, Sf, b0, nb; };                        // workgroup -> frame, piece, its blocks [b0, b0 + nb)
+__host__ __device__ inline OrdPiece ord_piece(const OrdGeo& g, int bid, int nblk) {
+  OrdPiece o;
+  const int na = g.nA * (g.S - 1);
+  if (bid < na) { o.Sf = g.S - 1; o.f = bid / o.Sf; o.j = bid - o.f * o.Sf; }
+  else { const int t = bid - na; o.Sf = g.S; o.f = g.nA + t / g.S; o.j = t - (o.f - g.nA) * g.S; }
+  const int per = nblk / o.Sf, ext = nblk - per * o.Sf;
+  o.nb = per + (o.j < ext ? 1 : 0);
+  o.b0 = o.j * per + (o.j < ext ? o.j : ext);
+  return o;
+}
+
 template <int J, int NCH>
 __device__ __forceinline__ void s2_issue_chunks(const unsigned char* __restrict__ src_lane, unsigned char* lds_uniform) {
   if constexpr (J < NCH) {                                        // (the immediate offset applies to BOTH addresses; 13 bits signed)
@@ -1418,17 +1441,20 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
   // construction -- no margins, no list of boundary-near means, no replays (bf16 replayed ~400 of them per pass, fp16
   // ~3300: k_video_centre 39 us at the cfg5 shape).  The fp64 column sums stay: the video centre is formed from them.
   const int nblk = N >> 4, ntail = N & 15;
-  int row_a, row_b, ord_f = 0, ord_b0 = 0, ord_b1 = 0, ord_r0 = 0, ord_cnt = 0;
+  int row_a, row_b, ord_f = 0, ord_j = 0, ord_b0 = 0, ord_b1 = 0, ord_r0 = 0, ord_cnt = 0;
   if constexpr (ORD != 0) {
-    ord_f = bid / S;
-    const int j = bid - ord_f * S;
-    ord_b0 = min(nblk, (kRowWaves * j + wave) * ord_m);
-    ord_b1 = min(nblk, ord_b0 + ord_m);
-    const bool owns_tail = ntail != 0 && (nblk == 0 ? (j == 0 && wave == 0) : (ord_b0 < nblk && ord_b1 == nblk));
+    // (ORD: `q` carries OrdGeo::nA and `ord_m` is unused -- the pieces are unequal, see OrdGeo)
+    const OrdPiece pc = ord_piece(OrdGeo{S, q}, bid, nblk);
+    ord_f = pc.f; ord_j = pc.j;
+    const int m = (pc.nb + kRowWaves - 1) / kRowWaves;            // consecutive blocks per wave
+    ord_b0 = min(pc.b0 + pc.nb, pc.b0 + wave * m);
+    ord_b1 = min(pc.b0 + pc.nb, ord_b0 + m);
+    const bool owns_tail = ntail != 0 && pc.j == pc.Sf - 1 && wave == kRowWaves - 1;
+    if (ord_b1 == ord_b0) ord_b0 = ord_b1 = (owns_tail ? nblk : ord_b0);      // (no block: the leftover chain alone, or nothing)
     ord_r0 = ord_f * N + 16 * ord_b0;
     ord_cnt = 16 * (ord_b1 - ord_b0) + (owns_tail ? ntail : 0);
-    if (nblk == 0 && owns_tail) ord_r0 = ord_f * N;
     row_a = ord_f * N; row_b = min(Rr, row_a + N);
+    (void)ord_m;
   } else {
     row_a = bid * q; row_b = min(Rr, row_a + q);
   }
@@ -1473,7 +1499,7 @@ __global__ __launch_bounds__(kRowWaves * 64, VC2_S2_WAVES) void k_norm_colsum2(c
   int f = f_a;
   for (int seg_a = row_a; seg_a < row_b; ++f) {
     const int seg_b = min(row_b, (f + 1) * N);
-    const int sp = ORD ? bid - f * S : bid - (f * N) / q;
+    const int sp = ORD ? ord_j : bid - (f * N) / q;
     const int r0 = ORD ? ord_r0 : seg_a + wave;
     const int cnt = ORD ? ord_cnt : (r0 < seg_b ? (seg_b - r0 + kRowWaves - 1) / kRowWaves : 0);
     double acc[NPLB];
@@ -1913,7 +1939,7 @@ constexpr int kCen2List = 1024;
 // 16 block sums in order (the first one assigned), the complete groups' sums added to acc2 from zero, the partial group
 // = acc1, then ((leftover chain + acc1) + acc2) + 0.  A block that holds a row whose denominator a norm fix-up changed
 // (corr, nc entries: normally none) is recomputed from x and the final den[].
-struct OrdSrc { const float* bsum; int on; };
+struct OrdSrc { const float* bsum; int on; int nA; };            // nA: OrdGeo::nA (frames below it have one piece less)
 template <int DT>
 __device__ __attribute__((noinline)) float ord_frame_sum(const float* __restrict__ bsum, int f, int c, int C, int N, int nc,
                                                const NormCorr* __restrict__ corr, const void* __restrict__ x, int D, int col,
@@ -1962,6 +1988,37 @@ __device__ __attribute__((noinline)) float ord_frame_sum(const float* __restrict
       float t = v[16 * g];
 #pragma unroll
       for (int u = 1; u < 16; ++u) if (u < cnt) t += v[16 * g + u];
+      if (g < n1c) acc2 += t; else acc1 = t;
+    }
+  }
+  float r = tail;
+  r += acc1; r += acc2; r += 0.f;
+  return r;
+}
+
+// ... the same cascade when no row of the frame had its norm corrected (nc == 0: always in the fused centre launch, whose
+// corrections arrive as entries of the next launch) -- INLINED and sized by the frame: the general form above is a real call
+// whose callee-saved registers go to scratch (32 VGPRs stored and reloaded per thread: 58 MB of scratch traffic per pass,
+// +8 us on k_frame_centres -- round 6), and it keeps 33 values live where a 196-token frame has 13.
+template <int NB>      // NB >= nb + 1: 16 (N < 256) or 33
+__device__ __forceinline__ float ord_frame_sum_clean(const float* __restrict__ bsum, int f, int c, int C, int N) {
+  const int nb = N >> 4, ntail = N & 15;
+  const float* __restrict__ bs = bsum + size_t(uint32_t(f * (nb + 1))) * C + c;
+  float v[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) v[b] = bs[size_t(b <= nb ? b : nb) * C];        // (all in flight; entry nb: the leftover chain)
+  float tail = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) if (b == nb) tail = ntail ? v[b] : 0.f;
+  float acc2 = 0.f, acc1 = 0.f;
+  const int n1c = nb >> 4;
+#pragma unroll
+  for (int g = 0; g < (NB > 16 ? 2 : 1); ++g) {
+    const int cnt = nb - 16 * g < 16 ? nb - 16 * g : 16;
+    if (cnt > 0) {
+      float t = v[16 * g];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) if (16 * g + u < NB && u < cnt) t += v[16 * g + u];
       if (g < n1c) acc2 += t; else acc1 = t;
     }
   }
@@ -2049,7 +2106,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
                                                                    double kk, int want_bounds,
                                                                    float* __restrict__ dmin_out, double kk_a,
                                                                    uint32_t* __restrict__ rlist, int rcap, FixRiders fr,
-                                                                   OrdSrc ord = OrdSrc{nullptr, 0}) {
+                                                                   OrdSrc ord = OrdSrc{nullptr, 0, 0}) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fix_rows[];     // riders: kFixWaves row buffers
   __shared__ double sm[kCentreFL][64];
   __shared__ double sb[kCentreFL][64];
@@ -2117,7 +2174,7 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
   const int cq = min(c, C - 1), fq = min(f, F - 1);
   const int col = cols ? cols[cq] : cq;
   // this frame's segments: one per sweep-2 chunk that meets it (make_plan)
-  const int Sf = ord.on ? S : int((int64_t(fq + 1) * N - 1) / S_q) - int((int64_t(fq) * N) / S_q) + 1;   // (ORD: S pieces per frame)
+  const int Sf = ord.on ? (fq < ord.nA ? S - 1 : S) : int((int64_t(fq + 1) * N - 1) / S_q) - int((int64_t(fq) * N) / S_q) + 1;   // (ORD: OrdGeo)
   double v0[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) v0[u] = part[(int64_t(fq) * S + min(u, Sf - 1)) * C + cq];
@@ -2159,7 +2216,12 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
         sf += double(xn) - double(xo);
       }
     }
-    if (ord.on) fc[int64_t(f) * C + c] = rnT<DT>(ord_frame_sum<DT>(ord.bsum, f, c, C, N, nc, corr, x, D, col, den) / float(N));
+    if (ord.on) {
+      float s;
+      if (nc == 0) s = N < 256 ? ord_frame_sum_clean<16>(ord.bsum, f, c, C, N) : ord_frame_sum_clean<33>(ord.bsum, f, c, C, N);
+      else s = ord_frame_sum<DT>(ord.bsum, f, c, C, N, nc, corr, x, D, col, den);
+      fc[int64_t(f) * C + c] = rnT<DT>(s / float(N));
+    }
     else fc[int64_t(f) * C + c] = mean_T<DT>(sf, N);
     q = float(sf) / float(N);
   }
@@ -3932,7 +3994,8 @@ struct Plan {
   int G, rows_per_group;        // sweep-1 row groups (G = F * stat_splits), stat blocks
   int stat_splits, NB, BF;      // groups per frame; stat blocks of BF (<= kStatBlockFrames) frames
   int64_t F_total;              // frames of the WHOLE video (frame-sharded pass: canonical blockings depend on it)
-  int ord_S, ord_m;             // sweep 2, ORD form (k_norm_colsum2<.., ORD>): ord_S workgroups per frame, ord_m 16-row blocks per wave (0: n/a)
+  int ord_S, ord_m;             // sweep 2, ORD form (k_norm_colsum2<.., ORD>): frames [0, ord_nA) are swept by ord_S - 1 workgroups each, the
+  int ord_nA;                   //   others by ord_S (ord_nA = 0: all by ord_S) -- OrdGeo; ord_m != 0: the plan has an ORD geometry
   int S, S_q, S_W;              // sweep 2: S_W chunks of S_q consecutive rows (frame boundaries inside a chunk cut it in
                                 //   segments); a frame's segments fill its first slots of S in `part`
   int S2, rows_per_split2;      // sweep-3 splits per frame (<= kDistMaxRows rows each)
@@ -4000,14 +4063,19 @@ int make_plan(int64_t F, int64_t N, int64_t D, int dt, Plan* p, int64_t F_total 
     p->S_q = int(q);
     p->S_W = int(cdiv(p->R, q));
     p->S = int(std::min<int64_t>(8, (N - 1) / q + 2));
-    // the ORD form (torch-ordered frame sums, see k_norm_colsum2): frames of <= 512 tokens, the streamlined sweep's
-    // shapes, every frame workgroup resident next to the riders
-    p->ord_S = p->ord_m = 0;
+    // the ORD form (torch-ordered frame sums, see k_norm_colsum2 / OrdGeo): frames of <= 512 tokens, the streamlined sweep's
+    // shapes, every frame workgroup resident next to the riders.  S - 1 workgroups for the first nA frames, S for the
+    // others, as many as the slots allow (a workgroup needs at least one block; `part` holds 8 pieces per frame)
+    p->ord_S = p->ord_m = p->ord_nA = 0;
     if (cur_mode() != 0 && dt != VC2_F32 && (D == 1024 || D == 3584 || D == 4096) && N <= 512) {
       const int64_t nblk = std::max<int64_t>(1, N / 16);
-      for (int64_t m = 1; m <= cdiv(nblk, kRowWaves); ++m) {
-        const int64_t S_o = cdiv(nblk, kRowWaves * m);
-        if (S_o <= 8 && F * S_o <= 512 - riders) { p->ord_S = int(S_o); p->ord_m = int(m); break; }
+      const int64_t smax = std::min<int64_t>(8, nblk), slots = 512 - riders;
+      const int64_t s_lo = std::min<int64_t>(smax, slots / F);
+      if (s_lo >= 1) {
+        const int64_t more = s_lo < smax ? std::min<int64_t>(F, slots - F * s_lo) : 0;     // frames that take s_lo + 1
+        if (more > 0) { p->ord_S = int(s_lo + 1); p->ord_nA = int(F - more); }
+        else { p->ord_S = int(s_lo); p->ord_nA = 0; }
+        p->ord_m = 1;
       }
     }
   }
@@ -4303,7 +4371,7 @@ inline int s2v2_nch(const Plan& p, const ChanSet& cs) {
 // 30.6 -> 34.7 us at the target shape, more than the centre kernels win there (fp16: -14 us in k_video_centre, +9 in the
 // sweep).  NOTES_r05.md.
 #ifndef VC2_S2_ORD_DEFAULT
-#define VC2_S2_ORD_DEFAULT 0
+#define VC2_S2_ORD_DEFAULT 1
 #endif
 inline bool ord_on(const Plan& p, const ChanSet& cs) {
   const char* e = getenv("VC2_S2_ORD");                          // (read per pass: the test-suite runs both forms in one process)
@@ -4317,8 +4385,8 @@ int launch_norm_v2(const Plan& p, const void* x, const ChanSet& cs, void* ws, co
   if (ord_on(p, cs)) {
     int rc = allow_big_lds(&k_norm_colsum2<DT, NCH, 1, 1>, smem, "k_norm_colsum2");
     if (rc) return rc;
-    hipLaunchKernelGGL((k_norm_colsum2<DT, NCH, 1, 1>), dim3(unsigned(p.F * p.ord_S) + nr),
-                       dim3(kRowWaves * 64), smem, st, x, int(p.N), cs.cols, cs.strict, p.ord_S, int(p.N), p.R,
+    hipLaunchKernelGGL((k_norm_colsum2<DT, NCH, 1, 1>), dim3(unsigned(ord_total_wgs(OrdGeo{p.ord_S, p.ord_nA}, int(p.F))) + nr),
+                       dim3(kRowWaves * 64), smem, st, x, int(p.N), cs.cols, cs.strict, p.ord_S, p.ord_nA, p.R,
                        wsp<float>(ws, p.o_den), wsp<double>(ws, p.o_part_col), wsp<int>(ws, p.o_ticket),
                        wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R), wsp<uint8_t>(ws, p.o_rflag), rider,
                        wsp<float>(ws, p.o_bsum), p.ord_m);
@@ -4480,7 +4548,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                        wsp<NormCorr>(ws, p.o_corr), cs.strict, wsp<int>(ws, p.o_vticket), fs,
                        margin_depth(p.N, cs.strict), (!single_rank && cs.strict == 3) ? 1 : 0, wsp<float>(ws, p.o_dmin),
                        (own_stats && cs.strict == 4 && !ord) ? double(VC2_FRAME_A) : 0.0, wsp<uint32_t>(ws, p.o_rlist), rcap, fr,
-                       OrdSrc{ord ? wsp<float>(ws, p.o_bsum) : (const float*)nullptr, ord ? 1 : 0});
+                       OrdSrc{ord ? wsp<float>(ws, p.o_bsum) : (const float*)nullptr, ord ? 1 : 0, ord ? p.ord_nA : 0});
   };
   if (!fused) {
     VC2_DISPATCH_DT(p.dt, launch_fc(k_frame_centres<DT, 1, 0>));
@@ -4501,7 +4569,7 @@ int launch_phase1(const Plan& p, const void* x, const ChanSet& cs, void* ws, boo
                         FrameFix{part, ord ? p.ord_S : p.S, p.S_q, cs.strict, margin_depth(p.N, cs.strict),
                                  (own_stats && cs.strict == 4) ? double(VC2_FRAME_A) : 0.0, fs,
                                  wsp<int>(ws, p.o_ticket) + kTkCorrCount, wsp<NormCorr>(ws, p.o_corr),
-                                 OrdSrc{ord ? wsp<float>(ws, p.o_bsum) : (const float*)nullptr, ord ? 1 : 0}},
+                                 OrdSrc{ord ? wsp<float>(ws, p.o_bsum) : (const float*)nullptr, ord ? 1 : 0, ord ? p.ord_nA : 0}},
                         fused ? wsp<uint32_t>(ws, p.o_rlist) + rcap : (const uint32_t*)nullptr,
                         wsp<int>(ws, p.o_ticket) + kTkFixEntries, rcap2,
                         fused ? wsp<int>(ws, p.o_fmark) : (const int*)nullptr};
