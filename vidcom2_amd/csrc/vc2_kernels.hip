@@ -527,6 +527,54 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
 }
 #endif
 
+// Round 6, the form that is the default for D <= 4096: sixteen waves as in k_chan_select, but thread t OWNS channels 4t .. 4t + 3
+// in registers for every partition round above 64 elements (vc2_select2.h, sel4_rounds); variances that need 64-bit words
+// (fp32 inputs) take the LDS-round engine on the same sixteen waves.
+__global__ __launch_bounds__(kSelNT) void k_chan_select4(const float* __restrict__ var_f32, int D, int k,
+                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                         int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                         uint32_t* __restrict__ wcpos, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using T = WordTr<uint32_t>;
+  static_assert(kSelNT == 1024 && kSelPre >= 4, "thread t: channels 4t .. 4t + 3");
+  const int tid = threadIdx.x;
+  int bad = 0;
+  if (tid == 0) VC2_STAMP(200);
+  if (tid == 0) VC2_ROUND_RAW(0, 120, 200);
+  constexpr int NW = kSelNT / 64;
+  const int nth = (k >= D || k <= 0) ? D - 1 : k - 1;
+  const int off = sel4_offset(D, nth, NW);                         // thread t: channels 4t - off .. 4t - off + 3 (see introselect4)
+  float pv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const int i = 4 * tid - off + e; pv[e] = var_f32[i < 0 ? 0 : (i < D ? i : D - 1)]; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bad |= key_fits_u32(pv[e]) ? 0 : 1;
+  if (__syncthreads_or(bad)) {                           // 64-bit words: the strided mapping of the LDS-round body
+    float pre[kSelPre];
+#pragma unroll
+    for (int j = 0; j < kSelPre; ++j) { const int i = tid + j * kSelNT; pre[j] = var_f32[i < D ? i : D - 1]; }
+    chan_select_body<uint64_t, kSelNT, kSelPre>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr, status);
+    if (tid == 0) VC2_STAMP(209);
+    return;
+  }
+  Sel2<uint32_t> S = sel2_carve<uint32_t>(smem, D, status);
+#if defined(VC2_DEBUG_TIMING)
+  S.dbg_slot = 0;
+#endif
+  if (tid == 0) VC2_ROUND(S, 201, D);
+  uint32_t el[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const int i = 4 * tid - off + e; el[e] = T::pack(topk_key(pv[e]), (i >= 0 && i < D) ? i : 0); }
+  if (uint32_t(4 * tid - off) < uint32_t(D)) *reinterpret_cast<uint4*>(S.w + (4 * tid - off)) = make_uint4(el[0], el[1], el[2], el[3]);   // (the pad takes the last thread's excess)
+  __syncthreads();
+  if (tid == 0) VC2_ROUND(S, 202, D);
+  if (k >= D) { if (perm) introselect4<NW>(S, el, D, D - 1, tid, off); }                // nth_element(n-1) still permutes
+  else if (k > 0 && int64_t(k) * 64 <= int64_t(D)) { if (tid == 0) s2_heap_select(S.w, 0, k, D); __syncthreads(); }   // partial_sort regime
+  else if (k > 0) introselect4<NW>(S, el, D, k - 1, tid, off);
+  chan_select_epilogue<uint32_t, kSelNT>(S, D, k, mask, cols, perm, wperm, wcpos);
+  if (tid == 0) VC2_STAMP(209);
+}
+
 // Round 6: the channel selection on FOUR waves (one per SIMD) with the whole array in registers for every partition round
 // (vc2_select2.h, third generation: sel3_rounds) -- D <= 256 E channels whose variances pack into 32-bit words (16-bit
 // inputs: always).  Thread t holds channels t, t + 256, ...: position p of the array = slot p / 256 of thread p % 256, which
@@ -4280,6 +4328,14 @@ int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask
   // rounds are ~70 instructions per 64-element row with VALU -> SGPR -> VALU dependencies that one wave per SIMD cannot hide
   // (4.2 / 3.0 / 2.3 / 2.4 us for the rounds the 16-wave LDS form does in 2.0 each: profiles/r06_b_sel3_register_rounds.csv)
   static const int sel3_env = [] { const char* e = getenv("VC2_SEL3"); return e ? atoi(e) : 0; }();
+  // VC2_SEL4 (default 1): D <= 4096, sixteen waves, thread-contiguous registers (k_chan_select4); 0: the LDS rounds
+  static const int sel4_env = [] { const char* e = getenv("VC2_SEL4"); return e ? atoi(e) : 1; }();
+  if (sel4_env != 0 && sel3_env == 0 && D <= 4096 && !words64_expected) {
+    { int rca = allow_big_lds(&k_chan_select4, smem, "k_chan_select4"); if (rca) return rca; }
+    ProfScope ps_(KID_CHAN_SELECT, st);
+    hipLaunchKernelGGL(k_chan_select4, dim3(1), dim3(kSelNT), smem, st, var_f32, int(D), int(k), mask, cols, perm, wperm, wcpos, status);
+    return check_launch("chan_select4");
+  }
   if (sel3_env != 0 && D <= 4096 && !words64_expected) {
     ProfScope ps_(KID_CHAN_SELECT, st);
     { int rca = allow_big_lds(&k_chan_select3<16>, smem, "k_chan_select3"); if (rca) return rca; }

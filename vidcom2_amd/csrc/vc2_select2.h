@@ -637,7 +637,7 @@ __device__ __forceinline__ void sel3_rounds(const Sel2<uint32_t>& S, uint32_t (&
 template <int E2>
 __device__ __forceinline__ void introselect3_finish(const Sel2<uint32_t>& S, int lo, int hi, int nth, int depth, int nmax,
                                                     uint32_t* mb, int mbtop, int lane) {
-  if (hi - lo > kSel2TailMax && hi - lo <= 64 * E2 && depth > 0) {
+  if constexpr (E2 >= kSel3Group) if (hi - lo > kSel2TailMax && hi - lo <= 64 * E2 && depth > 0) {
     uint32_t e2[E2];
     const int base = lo;
 #pragma unroll
@@ -688,6 +688,186 @@ __device__ __forceinline__ void topk_smallest3_solo(const Sel2<uint32_t>& S, int
   introselect3_finish<E2>(S, 0, n, k - 1, 2 * (31 - __clz(n)), n + kSel2Pad - 1, reinterpret_cast<uint32_t*>(S.la), (n / 2) * 2 + 16, lane);
   wave_lds_order();
   if (lane == 0) VC2_ROUND(S, 290, 0);
+}
+
+// ---- fourth form (round 6): registers + thread-contiguous positions + VALU ranks ------------------------------------------
+// What the per-round stamps say (profiles/r06_a_chan_select_rounds.csv, r06_b_sel3_register_rounds.csv): a round of the
+// 16-wave LDS form is ISSUE-bound -- 4 waves per SIMD x ~330 instructions -- and costs 2.0 us whatever its range; a round
+// built on ballots / SGPR masks is LATENCY-bound on one wave per SIMD.  So: keep 16 waves, cut the instructions.
+//   * thread t owns positions 4t .. 4t + 3 for the WHOLE selection, in registers (no re-blocking, no re-read per round);
+//     S.w stays a shadow (one 16-byte store per thread and round);
+//   * ranks are running counts inside the thread on top of ONE DPP scan of the packed per-thread counts and a second,
+//     lane-parallel scan of the 16 wave totals (the LDS form adds them up in a 16-step loop in every thread);
+//   * the swap partners meet in rank space (sel3_rounds' mailbox: A number r at r, B number s at mbtop - s), so there are no
+//     rank -> position tables: one LDS write and one read per element where the LDS form has two and three;
+//   * a wave whose 256 positions do not meet [lo, hi) only keeps the barriers company (one uniform branch).
+// Rounds run while the range is longer than 64; the rest is introselect_tail64 / the serial libstdc++ pieces (wave 0).
+constexpr int kX4State = 28;    // xch words [28, 31): lo, hi, depth after the round (for the waves that sleep through it)
+// ONE partition round.  SOLO = false: all awake waves of the workgroup together (three workgroup barriers); SOLO = true: the
+// range lies inside THIS wave's 256 positions -- no other wave is involved, no barrier (a wave's LDS accesses execute in order).
+template <int NW, bool SOLO>
+__device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&el)[4], int n, int& lo, int& hi, int nth,
+                                           int depth, uint32_t* mb, int mbtop, int p0, int lane, int wave, int off) {
+  using T = WordTr<uint32_t>;
+  const int wspan_lo = wave * 256 - off, wspan_hi = wspan_lo + 256;
+  const int dumi = mbtop / 2 - 2;
+  const int first = lo + 1;
+  const uint32_t len = uint32_t(hi - first);
+  const int pb = lo + (hi - lo) / 2, pc = hi - 1;
+  const uint32_t wlo = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[lo])));
+  const uint32_t wa = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[first])));
+  const uint32_t wb = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[pb])));
+  const uint32_t wc = uint32_t(__builtin_amdgcn_readfirstlane(int(S.w[pc])));
+  int msrc;
+  uint32_t wp;
+  {
+    const uint32_t ka = T::key(wa), kb = T::key(wb), kc = T::key(wc);
+    const bool ab = ka < kb, bc = kb < kc, ac = ka < kc;            // __move_median_to_first
+    const int sel = ab ? (bc ? 1 : (ac ? 2 : 0)) : (ac ? 0 : (bc ? 2 : 1));
+    msrc = sel == 0 ? first : (sel == 1 ? pb : pc);
+    wp = sel == 0 ? wa : (sel == 1 ? wb : wc);
+  }
+  const uint32_t pk = T::key(wp);
+  bool a[4], b[4];
+  uint32_t packed = 0u;
+  if (SOLO || (msrc >= wspan_lo && msrc < wspan_hi) || (lo >= wspan_lo && lo < wspan_hi)) {   // iter_swap(lo, median), register copy
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { el[e] = (p0 + e == msrc) ? wlo : el[e]; el[e] = (p0 + e == lo) ? wp : el[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t k = T::key(el[e]);
+    const bool in = uint32_t(p0 + e - first) < len;
+    a[e] = in && k >= pk;
+    b[e] = in && k <= pk;
+    packed += (a[e] ? 1u : 0u) + (b[e] ? 0x10000u : 0u);
+  }
+  const uint32_t incl = wave_incl_scan_u32(packed);
+  uint32_t bas = incl - packed;
+  int totB;
+  if constexpr (SOLO) {
+    wave_lds_order();                                               // (the candidates are read)
+    totB = int(uint32_t(__builtin_amdgcn_readlane(int(incl), 63)) >> 16);
+  } else {
+    if (lane == 63) S.xch[wave] = incl;
+    __syncthreads();                                                // ---- 1: wave totals; every thread has read the candidates
+    const uint32_t wt = lane < NW ? S.xch[lane] : 0u;
+    const uint32_t wincl = wave_incl_scan_u32(wt);
+    bas += uint32_t(__builtin_amdgcn_readlane(int(wincl - wt), wave));
+    totB = int(uint32_t(__builtin_amdgcn_readlane(int(wincl), 63)) >> 16);
+  }
+  if (uint32_t(lo - p0) < 4u) { S.w[lo] = wp; S.w[msrc] = wlo; }    // iter_swap(lo, median), shadow copy: by the owner of `lo`
+  int rA = int(bas & 0xFFFFu), nBl = int(bas >> 16);                 // A's left of my first element; B's left of it
+  uint32_t cand = 0xFFFFFFFFu;
+  int di[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int Bge = totB - nBl;                                      // B's at or right of this element
+    const bool swapA = a[e] && (Bge - (b[e] ? 1 : 0)) > rA;
+    const bool swapB = b[e] && rA >= Bge;
+    di[e] = swapA ? rA : (swapB ? mbtop + 1 - Bge : dumi);
+    mb[di[e]] = el[e];
+    const uint32_t cc = ((a[e] && !swapA) || swapB) ? uint32_t(p0 + e) : 0xFFFFFFFFu;
+    cand = cc < cand ? cc : cand;
+    rA += a[e] ? 1 : 0; nBl += b[e] ? 1 : 0;
+  }
+  uint32_t cutv = wave_min_bcast_u32(cand);
+  if constexpr (SOLO) {
+    wave_lds_order();
+  } else {
+    if (lane == 0) S.xch[kX3Cut + wave] = cutv;
+    __syncthreads();                                                // ---- 2: mailbox, cut candidates
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const uint32_t got = mb[mbtop - di[e]];
+    el[e] = di[e] != dumi ? got : el[e];
+  }
+  if (uint32_t(p0) < uint32_t(n)) *reinterpret_cast<uint4*>(S.w + p0) = make_uint4(el[0], el[1], el[2], el[3]);   // (the pad takes p0 + 3 >= n)
+  if constexpr (!SOLO) {
+    const uint32_t ct = lane < NW ? S.xch[kX3Cut + lane] : 0xFFFFFFFFu;
+    cutv = wave_min_bcast_u32(ct);
+  }
+  const int cut = cutv < uint32_t(hi) ? int(cutv) : hi;
+  if (cut <= nth) lo = cut; else hi = cut;
+  if constexpr (SOLO) {
+    wave_lds_order();
+  } else {
+    if (lane == 0) { S.xch[kX4State] = uint32_t(lo); S.xch[kX4State + 1] = uint32_t(hi); S.xch[kX4State + 2] = uint32_t(depth); }   // (every
+    __syncthreads();                                                // ---- 3: the shadow is current, the cells are free   awake wave: the same values)
+  }
+}
+
+// std::nth_element(first, first + nth, first + n) on S.w[0, n), n + off <= 256 NW.  el[e]: the word at position 4 tid - off + e,
+// already stored to S.w as well (a barrier behind the stores; words at positions outside [0, n): anything).  All 64 * NW
+// threads call.  off (a multiple of 4, sel4_offset): the positions are shifted against the threads so that `nth` -- which every
+// range contains -- sits in the MIDDLE of a wave's 256 positions: with k = D / 2 = 7 x 256 it stood on a wave boundary and
+// no range ever fitted one wave.
+// Phase 1: rounds by all the waves whose positions meet the range (the others sleep through the barriers) while the range is
+// longer than 64 and spans more than one wave's 256 positions.  Phase 2: the ONE wave that holds the range goes on alone --
+// barrier-free rounds, then introselect_tail64 / the serial libstdc++ pieces -- while the others wait at the final barrier.
+__host__ __device__ inline int sel4_offset(int n, int nth, int nw) {
+  const int off = ((128 - (nth & 255) + 256) & 255) & ~3;
+  return n + off <= 256 * nw ? off : 0;
+}
+template <int NW>
+__device__ __forceinline__ void introselect4(const Sel2<uint32_t>& S, uint32_t (&el)[4], int n, int nth, int tid, int off) {
+  if (n == 0 || nth >= n) return;
+  static_assert(NW <= 16, "wave totals: one lane each, cells [0, 16) of xch");
+  int lo = 0, hi = n;
+  int depth = 2 * (31 - __clz(n));
+  uint32_t* const mb = reinterpret_cast<uint32_t*>(S.la);           // la | lb: n + kSel2Pad words (see introselect3)
+  const int mbtop = (n / 2) * 2 + 16;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = 4 * tid - off;
+  const int wspan_lo = wave * 256 - off, wspan_hi = wspan_lo + 256;
+  bool asleep = false;                                              // (wave-uniform) the range has left my wave's positions for good
+  auto more = [&]() { return hi - lo > kSel2TailMax && depth > 0; };
+  auto one_wave = [&]() { return ((lo + off) >> 8) == ((hi - 1 + off) >> 8); };   // the range lies inside one wave's positions
+  for (int guard = 0; more() && !one_wave() && guard < 256; ++guard) {
+    if (tid == 0) VC2_ROUND(S, 410, hi - lo);
+    if (!asleep && !(wspan_hi > lo && wspan_lo < hi)) {             // the range only shrinks: from now on this wave keeps the
+      asleep = true;                                                //   barriers company and reads what the others decide
+      if (lane == 63) S.xch[wave] = 0u;                             // (my cells are written by nobody else: once is enough)
+      if (lane == 0) S.xch[kX3Cut + wave] = 0xFFFFFFFFu;
+    }
+    if (asleep) {
+      __syncthreads(); __syncthreads(); __syncthreads();
+      lo = __builtin_amdgcn_readfirstlane(int(S.xch[kX4State])); hi = __builtin_amdgcn_readfirstlane(int(S.xch[kX4State + 1]));
+      depth = __builtin_amdgcn_readfirstlane(int(S.xch[kX4State + 2]));
+      continue;
+    }
+    --depth;
+    sel4_round<NW, false>(S, el, n, lo, hi, nth, depth, mb, mbtop, p0, lane, wave, off);
+    if (guard == 255 && tid == 0) guard_hit(6, S.status);
+  }
+  // (every wave arrives here with the same lo / hi / depth; the shadow is current: the last round ended with a barrier)
+  const int owner = one_wave() ? ((lo + off) >> 8) : 0;
+#if defined(VC2_DEBUG_TIMING)                                      // (the stamp counter follows the work: thread 0 -> the owner's lane 0 -> thread 0)
+  if (tid == 0) S.xch[27] = uint32_t(S.dbg_i);
+  __syncthreads();
+  if (wave == owner && lane == 0) S.dbg_i = int(S.xch[27]);
+#endif
+  if (wave == owner) {
+    if (one_wave()) {
+      for (int guard = 0; more() && guard < 256; ++guard) {
+        if (lane == 0) VC2_ROUND(S, 430, hi - lo);
+        --depth;
+        sel4_round<NW, true>(S, el, n, lo, hi, nth, depth, mb, mbtop, p0, lane, wave, off);
+        if (guard == 255 && lane == 0) guard_hit(6, S.status);
+      }
+    }
+    introselect3_finish<1>(S, lo, hi, nth, depth, n + kSel2Pad - 1, mb, mbtop, lane);
+#if defined(VC2_DEBUG_TIMING)
+    if (lane == 0) S.xch[27] = uint32_t(S.dbg_i);
+#endif
+  }
+  __syncthreads();
+#if defined(VC2_DEBUG_TIMING)
+  if (tid == 0) S.dbg_i = int(S.xch[27]);
+#endif
+  if (tid == 0) VC2_ROUND(S, 290, 0);
 }
 
 // std::nth_element(first, first + nth, first + n) on S.w[0, n).  All 64*NW threads of the workgroup call this
