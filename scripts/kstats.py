@@ -9,7 +9,7 @@ for a in sys.argv[1:]:
     for r in csv.DictReader(open(f)):
         m = re.search(r"\b(k_[a-z_0-9]+)", r["Name"])
         if m:
-            name = {"k_norm_colsum2": "k_norm_colsum", "k_dist2": "k_dist"}.get(m.group(1), m.group(1))   # (the streamlined sweeps)
+            name = {"k_norm_colsum2": "k_norm_colsum", "k_dist2": "k_dist", "k_chan_select3": "k_chan_select", "k_chan_select4": "k_chan_select", "k_var_select": "k_chan_select"}.get(m.group(1), m.group(1))   # (the streamlined sweeps)
             rows.append((name, int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
     order = ["k_chan_stats", "k_var_from_stats", "k_chan_select", "k_norm_colsum", "k_norm_fix", "k_frame_centres",
              "k_video_centre", "k_dist", "k_select", "k_gather_rows"]

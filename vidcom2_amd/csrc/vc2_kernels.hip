@@ -192,8 +192,11 @@ template <int DT, int VEC, int U, int POOL>
 __global__ __launch_bounds__(kStatsWaves * 64) void k_chan_stats(const void* __restrict__ x, int64_t R,
                                                                  int D, int CV, int N, int splits,
                                                                  int rows_per_group, int block_frames,
-                                                                 double* __restrict__ part, PoolSrc pool) {
+                                                                 double* __restrict__ part, PoolSrc pool,
+                                                                 uint32_t* __restrict__ var_reset = nullptr) {
   __shared__ double sm[kStatsWaves][2 * VEC][64];
+  // (the pass's variance array back to "not written yet" for k_var_select, which polls it inside its own launch)
+  if (var_reset && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < D; i += kStatsWaves * 64) var_reset[i] = 0xFFFFFFFFu;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cv = blockIdx.x * 64 + lane;
   const bool active = cv < CV;
@@ -358,22 +361,15 @@ inline FoldTab make_fold_tab(int NB, int64_t n_each, int64_t n_last) {
 }
 // CW columns per workgroup, kRedGL lanes per column.  Narrow slabs (CW = 16: 224 workgroups at D = 3584) spread the
 // 7 MB of sweep-1 partials over the whole chip instead of 56 CUs; the fold shape does not depend on CW.
-template <int DT, int CW = 64>
-__global__ __launch_bounds__(CW * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
-                                                                int64_t n_each, int64_t n_last, int D,
-                                                                void* __restrict__ var_T, float* __restrict__ var_f32,
-                                                                int* __restrict__ counters, PartSrc ps, FoldTab ft,
-                                                                unsigned long long* __restrict__ fixq = nullptr,
-                                                                int nfixq = 0, unsigned long long* __restrict__ kstatus = nullptr) {
-  // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
-  // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
-  __shared__ double sm[3][kRedGL][CW];
-  if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(100);
-  if (counters && blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;  // strict-mode queues of this pass
-  if (kstatus && blockIdx.x == 0 && threadIdx.x == 0) *kstatus = 0ull;             // K_out[1]: k_select ORs its bits in
-  if (fixq) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfixq; i += gridDim.x * blockDim.x) fixq[i] = 0ull;
-  const int cl = threadIdx.x % CW, gl = threadIdx.x / CW;
-  const int c = blockIdx.x * CW + cl;
+// (the body: `vb` = the virtual workgroup -- CW columns --, `lt` = the thread inside it (CW * kRedGL of them), `sm` = its
+//  exchange area; VIS: the variances are stored with agent-scope atomic stores, for a consumer that POLLS them inside the
+//  same launch -- k_var_select)
+template <int DT, int CW, bool VIS>
+__device__ __forceinline__ void var_from_stats_body(const double* __restrict__ bstats, int NB, int64_t n_each, int64_t n_last, int D,
+                                                    void* __restrict__ var_T, float* __restrict__ var_f32, const PartSrc& ps,
+                                                    const FoldTab& ft, int vb, int lt, double (*sm)[kRedGL][CW]) {
+  const int cl = lt % CW, gl = lt / CW;
+  const int c = vb * CW + cl;
   ChanAgg a{0.0, 0.0, 0.0};
   if (c < D)
     for (int b = gl; b < NB; b += kRedGL) {
@@ -398,8 +394,29 @@ __global__ __launch_bounds__(CW * kRedGL) void k_var_from_stats(const double* __
   }
   t.n = ft.ntot;
   const float v = rnT<DT>(float(t.m2 / t.n));
-  if (var_f32) var_f32[c] = v;
+  if (var_f32) {
+    if constexpr (VIS) __hip_atomic_store(var_f32 + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else var_f32[c] = v;
+  }
   if (var_T) stT<DT>(var_T, c, v);
+}
+// CW columns per workgroup, kRedGL lanes per column.  Narrow slabs (CW = 16: 224 workgroups at D = 3584) spread the
+// 7 MB of sweep-1 partials over the whole chip instead of 56 CUs; the fold shape does not depend on CW.
+template <int DT, int CW = 64>
+__global__ __launch_bounds__(CW * kRedGL) void k_var_from_stats(const double* __restrict__ bstats, int NB,
+                                                                int64_t n_each, int64_t n_last, int D,
+                                                                void* __restrict__ var_T, float* __restrict__ var_f32,
+                                                                int* __restrict__ counters, PartSrc ps, FoldTab ft,
+                                                                unsigned long long* __restrict__ fixq = nullptr,
+                                                                int nfixq = 0, unsigned long long* __restrict__ kstatus = nullptr) {
+  // ps.part != null: the block statistics are computed here from this rank's sweep-1 partials (the same arithmetic
+  // as k_block_stats: one launch less on the single-rank path); else they are read from bstats
+  __shared__ double sm[3][kRedGL][CW];
+  if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(100);
+  if (counters && blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;  // strict-mode queues of this pass
+  if (kstatus && blockIdx.x == 0 && threadIdx.x == 0) *kstatus = 0ull;             // K_out[1]: k_select ORs its bits in
+  if (fixq) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfixq; i += gridDim.x * blockDim.x) fixq[i] = 0ull;
+  var_from_stats_body<DT, CW, false>(bstats, NB, n_each, n_last, D, var_T, var_f32, ps, ft, int(blockIdx.x), int(threadIdx.x), sm);
   if (blockIdx.x == 0 && threadIdx.x == 0) VC2_STAMP(109);
 }
 
@@ -530,13 +547,19 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select(const float* __restrict_
 // Round 6, the form that is the default for D <= 4096: sixteen waves as in k_chan_select, but thread t OWNS channels 4t .. 4t + 3
 // in registers for every partition round above 64 elements (vc2_select2.h, sel4_rounds); variances that need 64-bit words
 // (fp32 inputs) take the LDS-round engine on the same sixteen waves.
-__global__ __launch_bounds__(kSelNT) void k_chan_select4(const float* __restrict__ var_f32, int D, int k,
-                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
-                                                         int* __restrict__ perm, uint32_t* __restrict__ wperm,
-                                                         uint32_t* __restrict__ wcpos, int* status) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+constexpr int kStatusSpinExpired = 1;    // a bounded wait inside a launch ran out (reported through K_out[1])
+constexpr uint32_t kVarSentinel = 0xFFFFFFFFu;       // "not written yet" (k_var_select): no variance is this NaN -- arithmetic NaNs are
+                                                     // canonical, a widened 16-bit value has sixteen zero low bits
+// POLL: the variances are being written by OTHER workgroups of this launch (k_var_select): every thread spins on its own four
+// words until none is the sentinel (single-word data is its own flag: no ordering between words is needed).  A bounded wait:
+// a word that never arrives is reported (status bit kStatusSpinExpired) and read as it is.
+template <bool POLL>
+__device__ __forceinline__ void chan_select4_body(unsigned char* smem, const float* __restrict__ var_f32, int D, int k,
+                                                  uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                  int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                  uint32_t* __restrict__ wcpos, int* status) {
   using T = WordTr<uint32_t>;
-  static_assert(kSelNT == 1024 && kSelPre >= 4, "thread t: channels 4t .. 4t + 3");
+  static_assert(kSelNT == 1024 && kSelPre >= 4, "thread t: channels 4t - off .. 4t - off + 3");
   const int tid = threadIdx.x;
   int bad = 0;
   if (tid == 0) VC2_STAMP(200);
@@ -545,12 +568,31 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select4(const float* __restrict
   const int nth = (k >= D || k <= 0) ? D - 1 : k - 1;
   const int off = sel4_offset(D, nth, NW);                         // thread t: channels 4t - off .. 4t - off + 3 (see introselect4)
   float pv[4];
+  if constexpr (POLL) {
+    uint32_t raw[4];
+    bool missing = true;
+    for (int spin = 0; missing && spin < (1 << 16); ++spin) {
+      missing = false;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { const int i = 4 * tid - off + e; pv[e] = var_f32[i < 0 ? 0 : (i < D ? i : D - 1)]; }
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * tid - off + e;
+        raw[e] = __hip_atomic_load(reinterpret_cast<const uint32_t*>(var_f32) + (i < 0 ? 0 : (i < D ? i : D - 1)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        missing |= raw[e] == kVarSentinel;
+      }
+      if (missing) __builtin_amdgcn_s_sleep(2);
+    }
+    if (missing && status) atomicOr(status, kStatusSpinExpired);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pv[e] = __uint_as_float(raw[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = 4 * tid - off + e; pv[e] = var_f32[i < 0 ? 0 : (i < D ? i : D - 1)]; }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) bad |= key_fits_u32(pv[e]) ? 0 : 1;
   if (__syncthreads_or(bad)) {                           // 64-bit words: the strided mapping of the LDS-round body
-    float pre[kSelPre];
+    float pre[kSelPre];                                  // (POLL: every thread has seen its own words, the barrier has passed: all are there)
 #pragma unroll
     for (int j = 0; j < kSelPre; ++j) { const int i = tid + j * kSelNT; pre[j] = var_f32[i < D ? i : D - 1]; }
     chan_select_body<uint64_t, kSelNT, kSelPre>(smem, pre, D, k, mask, cols, perm, nullptr, nullptr, status);
@@ -573,6 +615,43 @@ __global__ __launch_bounds__(kSelNT) void k_chan_select4(const float* __restrict
   else if (k > 0) introselect4<NW>(S, el, D, k - 1, tid, off);
   chan_select_epilogue<uint32_t, kSelNT>(S, D, k, mask, cols, perm, wperm, wcpos);
   if (tid == 0) VC2_STAMP(209);
+}
+__global__ __launch_bounds__(kSelNT) void k_chan_select4(const float* __restrict__ var_f32, int D, int k,
+                                                         uint8_t* __restrict__ mask, int* __restrict__ cols,
+                                                         int* __restrict__ perm, uint32_t* __restrict__ wperm,
+                                                         uint32_t* __restrict__ wcpos, int* status) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  chan_select4_body<false>(smem, var_f32, D, k, mask, cols, perm, wperm, wcpos, status);
+}
+
+// k_var_from_stats AND the channel selection in ONE launch (round 6; the full pass, 16-bit inputs, D <= 4096): workgroup 0 is
+// the selection -- it sets up and then POLLS the variances --, workgroups 1 .. are the variance reduction, four virtual
+// 256-thread workgroups of k_var_from_stats<DT, 16> each (same fold shape: same bits).  What it saves is a kernel boundary
+// (~1.5 us between the last wave of one launch and the first instruction of the next) and the selection's own load round
+// trip.  var_f32 must hold the sentinel when the launch begins: the sweep-1 launch of the same pass wrote it (k_chan_stats).
+struct VarSelArgs {
+  int NB; int64_t n_each, n_last; int D; float* var_f32; int* counters; PartSrc ps; FoldTab ft;
+  unsigned long long* fixq; int nfixq; unsigned long long* kstatus;
+  int k; int* cols; int* perm; uint32_t* wperm; uint32_t* wcpos; int* status;
+};
+template <int DT>
+__global__ __launch_bounds__(kSelNT) void k_var_select(VarSelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int CW = 16, VT = CW * kRedGL;                          // the variance workgroups use their first 256 threads (the other
+  __shared__ double sm[3][kRedGL][CW];                             //   waves leave at once): 224 CUs share the 7 MB of partials, as
+  if (blockIdx.x == 0) {                                           //   k_var_from_stats<DT, 16> has it (64-column workgroups: +1 us)
+    if (a.counters && threadIdx.x < 16) a.counters[threadIdx.x] = 0;     // strict-mode queues + status word of this pass (the word
+    __syncthreads();                                                     //   this workgroup's own replay may OR a bit into: zeroed here)
+    chan_select4_body<true>(smem, a.var_f32, a.D, a.k, nullptr, a.cols, a.perm, a.wperm, a.wcpos, a.status);
+    return;
+  }
+  if (threadIdx.x >= VT) return;
+  const int vb = int(blockIdx.x) - 1, nvt = (int(gridDim.x) - 1) * VT, vt = vb * VT + int(threadIdx.x);
+  if (vb == 0 && threadIdx.x == 0) VC2_STAMP(100);
+  if (a.kstatus && vt == 0) *a.kstatus = 0ull;                     // K_out[1]: k_select ORs its bits in
+  if (a.fixq) for (int i = vt; i < a.nfixq; i += nvt) a.fixq[i] = 0ull;
+  var_from_stats_body<DT, CW, true>(nullptr, a.NB, a.n_each, a.n_last, a.D, nullptr, a.var_f32, a.ps, a.ft, vb, int(threadIdx.x), sm);
+  if (vb == 0 && threadIdx.x == 0) VC2_STAMP(109);
 }
 
 // Round 6: the channel selection on FOUR waves (one per SIMD) with the whole array in registers for every partition round
@@ -1128,7 +1207,6 @@ __device__ __forceinline__ unsigned long long fixq_pack(int64_t row, float dn) {
 }
 // ticket words (ints at Plan::o_ticket)
 constexpr int kTkFixCount = 2, kTkCorrCount = 3, kTkVcFragile = 5, kTkStatus = 6, kTkFrameReplays = 7;
-constexpr int kStatusSpinExpired = 1;    // a bounded wait inside a launch ran out (reported through K_out[1])
 
 // One queued row, by one wave: replay torch's norm accumulation (the row's selected values scattered to their SORTED
 // positions, then the 8-chain / sequential fp32 sum).  Almost always the T-rounded norm equals the exactly rounded one;
@@ -3544,9 +3622,16 @@ __device__ __forceinline__ void select_frame_body(unsigned char* smem, const flo
   if (tid == 0) VC2_ROUND(S, 802, N);
   if (N > sel2_capacity(1, 4)) topk_smallest2<W, 4, 4, 8>(S, N, k, tid);
   else if (tid < 64) {
-    // (round-6 experiment, compile-time opt-in: every round above 64 elements in registers too -- sel3_rounds; measured
-    //  1.1-1.4 us per round against the LDS rounds' 1.2-1.4, k_select 14.0 against 13.0 us: not kept as the default)
-#ifdef VC2_SEL3_SOLO
+    // round 6: 32-bit words, frames of <= 512 tokens: barrier-free rounds on registers (sel4_round<1, true>; the LDS rounds
+    // cost 1.2-1.8 us each above 64 elements, these 0.7-0.8).  -DVC2_NO_SEL4_SOLO: the LDS rounds of rounds 3-5;
+    // -DVC2_SEL3_SOLO: the ballot form (sel3_rounds; measured no faster than the LDS rounds)
+#if !defined(VC2_NO_SEL4_SOLO) && !defined(VC2_SEL3_SOLO)
+    if constexpr (sizeof(W) == 4) {
+      if (N <= 256) topk_smallest4_solo<4>(S, N, k, tid);
+      else if (N <= 512) topk_smallest4_solo<8>(S, N, k, tid);
+      else topk_smallest2<W, 1, 4, 4>(S, N, k, tid);
+    } else
+#elif defined(VC2_SEL3_SOLO)
     if constexpr (sizeof(W) == 4) {
       if (N <= 256) topk_smallest3_solo<4>(S, N, k, tid);
       else if (N <= 512) topk_smallest3_solo<8>(S, N, k, tid);
@@ -4250,7 +4335,7 @@ int need_ws(const Plan& p, void* ws, size_t ws_bytes) {
 // sweep 1 -> per stat block (mean, M2) in bstats[NB][2][D] (ws when bstats == nullptr), and -- var_f32 / var_T --
 // the variance of THESE rows reduced from them (single-rank case)
 // sweep 1 alone: the per-group partials of x into ws (pool.xin != null: x is produced here, see k_chan_stats)
-int launch_stats_sweep(const Plan& p, const void* x, void* ws, const PoolSrc& pool, hipStream_t st) {
+int launch_stats_sweep(const Plan& p, const void* x, void* ws, const PoolSrc& pool, hipStream_t st, uint32_t* var_reset = nullptr) {
   double* part = wsp<double>(ws, p.o_part_stats);
   if (p.G > 65535) return fail(VC2_ERR_UNSUPPORTED, "too many sweep-1 row groups (%d)", p.G);
   dim3 grid(unsigned(cdiv(p.CV, 64)), unsigned(p.G));
@@ -4262,7 +4347,7 @@ int launch_stats_sweep(const Plan& p, const void* x, void* ws, const PoolSrc& po
   } else {
     VC2_DISPATCH_VEC(p, hipLaunchKernelGGL((k_chan_stats<DT, VEC, 8, 0>), grid, dim3(kStatsWaves * 64), 0, st, x,
                                             p.R, int(p.D), p.CV, int(p.N), p.stat_splits, p.rows_per_group, p.BF, part,
-                                            pool));
+                                            pool, var_reset));
   }
   return check_launch("chan_stats");
 }
@@ -5236,9 +5321,6 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   }
   float* var_f32 = wsp<float>(ws, p.o_var_f32);
   int* cols = wsp<int>(ws, p.o_cols);
-  if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true,
-                              /*have_partials=*/(flags & VC2_FLAG_HAVE_STATS) != 0, /*kstatus=*/K_out + 1)))
-    return rc;
   const int64_t kc = int64_t(double(D) * 0.5);            // int(x.shape[-1] * ratio), vidcom2.py:41
   const bool strict = cur_mode() && p.ES == 2;
   int* spos = strict ? wsp<int>(ws, p.o_spos) : nullptr;
@@ -5247,7 +5329,33 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   uint32_t* wperm = strict && 2 * kc <= std::max<int64_t>(p.R, D) ? wsp<uint32_t>(ws, p.o_tmp_f32) : nullptr;
   uint32_t* wcpos = wperm ? wperm + kc : nullptr;
   int* const status = wsp<int>(ws, p.o_ticket) + kTkStatus;       // the pass's status word (-> K_out[1])
-  if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos, status, /*words64_expected=*/p.ES == 4))) return rc;
+  // the variance reduction and the channel selection in ONE launch (k_var_select): 16-bit inputs, D <= 4096, this pass ran its
+  // own sweep 1 (which left the variance array at "not written yet"), no per-kernel timing.  VC2_VARSEL=0: two launches
+  static const int varsel_env = [] { const char* e = getenv("VC2_VARSEL"); return e ? atoi(e) : 1; }();
+  static const int sel4_env2 = [] { const char* e = getenv("VC2_SEL4"); const char* e3 = getenv("VC2_SEL3"); return (e ? atoi(e) : 1) != 0 && !(e3 && atoi(e3) != 0); }();
+  if (varsel_env != 0 && sel4_env2 && p.ES == 2 && D <= 4096 && !(flags & VC2_FLAG_HAVE_STATS) && !g_prof && kc > 0 && kc < D) {
+    if ((rc = launch_stats_sweep(p, x, ws, PoolSrc{}, st, reinterpret_cast<uint32_t*>(var_f32)))) return rc;
+    const int64_t n_each = int64_t(p.BF) * p.N, n_last = p.R - int64_t(p.NB - 1) * n_each;
+    VarSelArgs va{p.NB, n_each, n_last, int(D), var_f32, wsp<int>(ws, p.o_ticket),
+                  PartSrc{wsp<double>(ws, p.o_part_stats), x, p.R, p.BF * p.stat_splits, p.G, int(p.N), p.BF},
+                  make_fold_tab(p.NB, n_each, n_last), wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R + cdiv(p.F, 2)),
+                  reinterpret_cast<unsigned long long*>(K_out + 1), int(kc), cols, perm, wperm, wcpos, status};
+    const size_t smem = chan_select_lds(int(D));
+    const unsigned nvb = unsigned(cdiv(D, 16));                    // workgroups of the variance reduction
+    auto go = [&](auto kernel) -> int {
+      int rca = allow_big_lds(kernel, smem, "k_var_select", 3 * kRedGL * 16 * 8);
+      if (rca) return rca;
+      hipLaunchKernelGGL(kernel, dim3(1 + nvb), dim3(kSelNT), smem, st, va);
+      return check_launch("var_select");
+    };
+    if (p.dt == VC2_BF16) rc = go(k_var_select<VC2_BF16>); else rc = go(k_var_select<VC2_F16>);
+    if (rc) return rc;
+  } else {
+    if ((rc = launch_chan_stats(p, x, ws, nullptr, nullptr, var_f32, st, /*zero_queue_counters=*/true,
+                                /*have_partials=*/(flags & VC2_FLAG_HAVE_STATS) != 0, /*kstatus=*/K_out + 1)))
+      return rc;
+    if ((rc = launch_chan_select(var_f32, D, kc, nullptr, cols, perm, st, wperm, wcpos, status, /*words64_expected=*/p.ES == 4))) return rc;
+  }
   const ChanSet cs = make_chanset(p, cols, spos, kc);
   // torch.topk's ORDER of the selected channels (needed only by the "torch order" fix-ups, which run after sweep 2)
   // is replayed by a rider workgroup of sweep 2 itself

@@ -705,11 +705,11 @@ __device__ __forceinline__ void topk_smallest3_solo(const Sel2<uint32_t>& S, int
 constexpr int kX4State = 28;    // xch words [28, 31): lo, hi, depth after the round (for the waves that sleep through it)
 // ONE partition round.  SOLO = false: all awake waves of the workgroup together (three workgroup barriers); SOLO = true: the
 // range lies inside THIS wave's 256 positions -- no other wave is involved, no barrier (a wave's LDS accesses execute in order).
-template <int NW, bool SOLO>
-__device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&el)[4], int n, int& lo, int& hi, int nth,
+template <int NW, bool SOLO, int E = 4>
+__device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&el)[E], int n, int& lo, int& hi, int nth,
                                            int depth, uint32_t* mb, int mbtop, int p0, int lane, int wave, int off) {
   using T = WordTr<uint32_t>;
-  const int wspan_lo = wave * 256 - off, wspan_hi = wspan_lo + 256;
+  const int wspan_lo = wave * 64 * E - off, wspan_hi = wspan_lo + 64 * E;
   const int dumi = mbtop / 2 - 2;
   const int first = lo + 1;
   const uint32_t len = uint32_t(hi - first);
@@ -728,14 +728,14 @@ __device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&e
     wp = sel == 0 ? wa : (sel == 1 ? wb : wc);
   }
   const uint32_t pk = T::key(wp);
-  bool a[4], b[4];
+  bool a[E], b[E];
   uint32_t packed = 0u;
   if (SOLO || (msrc >= wspan_lo && msrc < wspan_hi) || (lo >= wspan_lo && lo < wspan_hi)) {   // iter_swap(lo, median), register copy
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { el[e] = (p0 + e == msrc) ? wlo : el[e]; el[e] = (p0 + e == lo) ? wp : el[e]; }
+    for (int e = 0; e < E; ++e) { el[e] = (p0 + e == msrc) ? wlo : el[e]; el[e] = (p0 + e == lo) ? wp : el[e]; }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < E; ++e) {
     const uint32_t k = T::key(el[e]);
     const bool in = uint32_t(p0 + e - first) < len;
     a[e] = in && k >= pk;
@@ -756,12 +756,12 @@ __device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&e
     bas += uint32_t(__builtin_amdgcn_readlane(int(wincl - wt), wave));
     totB = int(uint32_t(__builtin_amdgcn_readlane(int(wincl), 63)) >> 16);
   }
-  if (uint32_t(lo - p0) < 4u) { S.w[lo] = wp; S.w[msrc] = wlo; }    // iter_swap(lo, median), shadow copy: by the owner of `lo`
+  if (uint32_t(lo - p0) < uint32_t(E)) { S.w[lo] = wp; S.w[msrc] = wlo; }    // iter_swap(lo, median), shadow copy: by the owner of `lo`
   int rA = int(bas & 0xFFFFu), nBl = int(bas >> 16);                 // A's left of my first element; B's left of it
   uint32_t cand = 0xFFFFFFFFu;
-  int di[4];
+  int di[E];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < E; ++e) {
     const int Bge = totB - nBl;                                      // B's at or right of this element
     const bool swapA = a[e] && (Bge - (b[e] ? 1 : 0)) > rA;
     const bool swapB = b[e] && rA >= Bge;
@@ -779,11 +779,15 @@ __device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&e
     __syncthreads();                                                // ---- 2: mailbox, cut candidates
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < E; ++e) {
     const uint32_t got = mb[mbtop - di[e]];
     el[e] = di[e] != dumi ? got : el[e];
   }
-  if (uint32_t(p0) < uint32_t(n)) *reinterpret_cast<uint4*>(S.w + p0) = make_uint4(el[0], el[1], el[2], el[3]);   // (the pad takes p0 + 3 >= n)
+  if (uint32_t(p0) < uint32_t(n)) {                                 // (the pad takes positions >= n)
+#pragma unroll
+    for (int q = 0; q < E / 4; ++q)
+      reinterpret_cast<uint4*>(S.w + p0)[q] = make_uint4(el[4 * q], el[4 * q + 1], el[4 * q + 2], el[4 * q + 3]);
+  }
   if constexpr (!SOLO) {
     const uint32_t ct = lane < NW ? S.xch[kX3Cut + lane] : 0xFFFFFFFFu;
     cutv = wave_min_bcast_u32(ct);
@@ -868,6 +872,40 @@ __device__ __forceinline__ void introselect4(const Sel2<uint32_t>& S, uint32_t (
   if (tid == 0) S.dbg_i = int(S.xch[27]);
 #endif
   if (tid == 0) VC2_ROUND(S, 290, 0);
+}
+
+// one-wave selections (k_select: the N tokens of a frame, N <= 64 E): S.w[0, n) holds the words; lane l takes positions
+// E l .. E l + E - 1 into registers and runs barrier-free sel4 rounds down to 64 elements, then the register tail.  (The pad
+// behind S.w must hold E - 1 words more than the array: kSel2Pad = 64 does.)
+template <int E>
+__device__ __forceinline__ void topk_smallest4_solo(const Sel2<uint32_t>& S, int n, int k, int lane) {
+  static_assert(E == 4 || E == 8, "whole 16-byte vectors");
+  if (k <= 0 || k >= n) return;
+  if (int64_t(k) * 64 <= int64_t(n)) {
+    if (lane == 0) s2_heap_select(S.w, 0, k, n);
+    wave_lds_order();
+    return;
+  }
+  uint32_t el[E];
+  const int p0 = E * lane;
+#pragma unroll
+  for (int q = 0; q < E / 4; ++q) {
+    const uint4 v = reinterpret_cast<const uint4*>(S.w + (p0 < n ? p0 : 0))[q];
+    el[4 * q] = v.x; el[4 * q + 1] = v.y; el[4 * q + 2] = v.z; el[4 * q + 3] = v.w;
+  }
+  int lo = 0, hi = n, depth = 2 * (31 - __clz(n));
+  const int nth = k - 1;
+  uint32_t* const mb = reinterpret_cast<uint32_t*>(S.la);
+  const int mbtop = (n / 2) * 2 + 16;
+  for (int guard = 0; hi - lo > kSel2TailMax && depth > 0 && guard < 256; ++guard) {
+    if (lane == 0) VC2_ROUND(S, 430, hi - lo);
+    --depth;
+    sel4_round<1, true, E>(S, el, n, lo, hi, nth, depth, mb, mbtop, p0, lane, 0, 0);
+    if (guard == 255 && lane == 0) guard_hit(6, S.status);
+  }
+  introselect3_finish<1>(S, lo, hi, nth, depth, n + kSel2Pad - 1, mb, mbtop, lane);
+  wave_lds_order();
+  if (lane == 0) VC2_ROUND(S, 290, 0);
 }
 
 // std::nth_element(first, first + nth, first + n) on S.w[0, n).  All 64*NW threads of the workgroup call this
