@@ -48,18 +48,22 @@ const char* vc2_version(void);
 
 /* Accumulation semantics of the reference's fp32-accumulated reductions in half precision (token L2 norm,
  * squared-distance row sums, centre means):
- *   4 (default)  "torch order": wherever the exactly computed value lies within a few fp32-ulps (128 / 48 / 16)
- *                of a T rounding boundary, torch's own CPU accumulation order (8 interleaved fp32 chains over the
- *                variance-sorted channels / cascade sum / outer-sum cascade over the rows) is replayed for that
- *                token or centre element -> bit-exact to the CPU reference.  The margin of the FRAME-centre means has,
- *                besides the 16 ulps of the mean, a term relative to sum |x^| over the frame (4 u A / n, A bounded from
- *                sweep 1's statistics and the frame's smallest denominator, evaluated only for means that pass a cheap
- *                pre-test): it grows under cancellation, where torch's cascade errs by far more than ulps OF THE MEAN.
- *                Reproduces the reference on every fixture (incl. the adversarial `cancel` ones) and every soak case.
+ *   4 (default)  "torch order": wherever the exactly computed value lies within a few fp32-ulps (128 / 48) of a T rounding
+ *                boundary, torch's own CPU accumulation order (8 interleaved fp32 chains over the variance-sorted
+ *                channels / cascade sum) is replayed for that token -> bit-exact to the CPU reference.  FRAME-centre means
+ *                (round 6): the model shapes -- 16-bit inputs, D = 1024 / 3584 / 4096, frames of <= 512 tokens, every frame
+ *                workgroup resident -- add every frame's x^ in torch's OWN order inside sweep 2 (16-row blocks, fp32, the
+ *                outer-sum cascade of SumKernel.cpp): the frame means are the reference's bits by construction, no margin,
+ *                no replay (environment VC2_S2_ORD=0: the form below).  Other shapes, and the VIDEO-centre mean everywhere:
+ *                exact (fp64) sums, and a mean within 16 fp32-ulps of a T boundary is replayed in torch's order; for frame
+ *                means the margin has, besides the 16 ulps, a term relative to sum |x^| over the frame (4 u A / n, A bounded
+ *                from sweep 1's statistics and the frame's smallest denominator): it grows under cancellation, where torch's
+ *                cascade errs by far more than ulps OF THE MEAN.  Reproduces the reference on every fixture (incl. the
+ *                adversarial `cancel` ones) and every soak case.
  *   0            "exact": every reduction correctly rounded (DESIGN.md "Numerics contract").
  *   3            "proven": a PROVEN bound decides which centre means are replayed (forward error bound of torch's
  *                cascade relative to sum |x^|, bounded from sweep 1's statistics): flags 50x more means, costs ~45 %
- *                more time (256 against 178 us per pass at the target shape, round 5); the test-suite runs every fixture
+ *                more time (256 against 178 us per pass at the target shape, round 5; with VC2_S2_ORD=0); the test-suite runs every fixture
  *                in it as well and asserts the same results.
  *   1            "fast" (the default of rounds 1-3, now opt-in): the 16-ulp margin alone for all centre means.  ~1 %
  *                faster than mode 4 (176 against 178 us, round 5); NOT bit-exact under cancellation (0.2 % of random `cancel` inputs differ in last-bit
