@@ -497,6 +497,67 @@ __device__ __forceinline__ void chan_select_epilogue(const Sel2<W>& S, int D, in
   if (tid == 0) VC2_ROUND(S, 299, k);
 }
 
+// The full pass's epilogue (round 6; 1024 threads, D <= 4096, 32-bit words, no mask bytes wanted): ONE barrier instead of three.
+// The kept channels set their bits in a 128-word LDS bitmap (and the ORDER riders' words go out) -- barrier -- every wave
+// forms the prefix popcounts of the 128 words for itself (two DPP scans: no exchange), then thread t lists the kept ones of
+// channels 4t .. 4t + 3 in `cols`, and the position of a kept channel c in `cols` (wcpos) is prefix[c / 32] + the set bits
+// below c in its word -- no flag array, no per-thread chunk counts, no block scan.  bitmap: 128 zeroed words (S.xch is not
+// used by the replay's last phase; the caller zeroes them before the replay).
+__device__ __forceinline__ void chan_select_epilogue_bitmap(const Sel2<uint32_t>& S, uint32_t* bitmap, int D, int k,
+                                                            int* __restrict__ cols, int* __restrict__ perm,
+                                                            uint32_t* __restrict__ wperm, uint32_t* __restrict__ wcpos) {
+  using T = WordTr<uint32_t>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) VC2_STAMP(205);
+  if (tid == 0) VC2_ROUND(S, 291, k);
+  uint32_t wk[4];                                                  // my kept words: positions tid, tid + 1024, ... (k <= 4096)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + j * kSelNT;
+    wk[j] = 0u;
+    if (i < k) {
+      wk[j] = S.w[i];
+      const int c = T::idx(wk[j]);
+      atomicOr(&bitmap[c >> 5], 1u << (c & 31));
+      if (wperm) wperm[i] = wk[j];
+      if (perm) perm[i] = c;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) VC2_ROUND(S, 292, k);
+  const uint32_t w0 = bitmap[lane], w1 = bitmap[64 + lane];
+  const uint32_t c0 = uint32_t(__builtin_popcount(w0)), c1 = uint32_t(__builtin_popcount(w1));
+  const uint32_t i0 = wave_incl_scan_u32(c0);
+  const uint32_t t0 = uint32_t(__builtin_amdgcn_readlane(int(i0), 63));
+  const uint32_t i1 = wave_incl_scan_u32(c1) + t0;
+  const uint32_t e0 = i0 - c0, e1 = i1 - c1;                        // lane l: kept channels below word l / below word 64 + l
+  auto prefix_of = [&](int word) -> uint32_t {                      // (any lane asks for any word: two crossbar reads)
+    const uint32_t a = uint32_t(__builtin_amdgcn_ds_bpermute((word & 63) << 2, int(e0)));
+    const uint32_t b = uint32_t(__builtin_amdgcn_ds_bpermute((word & 63) << 2, int(e1)));
+    return word < 64 ? a : b;
+  };
+  {                                                                 // cols: thread t answers for channels 4t .. 4t + 3
+    const int cb = 4 * tid, word = cb >> 5;
+    const uint32_t wv = bitmap[word < 128 ? word : 127];
+    uint32_t o = prefix_of(word) + uint32_t(__builtin_popcount(wv & ((1u << (cb & 31)) - 1u)));
+    if (cols && cb < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if ((wv >> ((cb & 31) + e)) & 1u) cols[o++] = cb + e;
+    }
+  }
+  if (wcpos) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + j * kSelNT;
+      const int c = T::idx(wk[j]);
+      const uint32_t wv = bitmap[c >> 5];
+      const uint32_t pos = prefix_of(c >> 5) + uint32_t(__builtin_popcount(wv & ((1u << (c & 31)) - 1u)));
+      if (i < k) wcpos[i] = pos;
+    }
+  }
+  if (tid == 0) VC2_ROUND(S, 299, k);
+}
+
 // the LDS-round engine (vc2_select2.h, second generation) on NT threads: every D <= 8192, both word widths
 template <typename W, int NT, int NPRE>
 __device__ __forceinline__ void chan_select_body(unsigned char* smem, const float (&pre)[NPRE], int D, int k,
@@ -604,6 +665,9 @@ __device__ __forceinline__ void chan_select4_body(unsigned char* smem, const flo
   S.dbg_slot = 0;
 #endif
   if (tid == 0) VC2_ROUND(S, 201, D);
+  // the epilogue's bitmap of kept channels: 128 words behind the selection's own LDS (chan_select_lds reserves them), zeroed here
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(smem + (sel2_bytes(D, 4) + 15) / 16 * 16);
+  if (tid < 128) bitmap[tid] = 0u;
   uint32_t el[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) { const int i = 4 * tid - off + e; el[e] = T::pack(topk_key(pv[e]), (i >= 0 && i < D) ? i : 0); }
@@ -613,7 +677,8 @@ __device__ __forceinline__ void chan_select4_body(unsigned char* smem, const flo
   if (k >= D) { if (perm) introselect4<NW>(S, el, D, D - 1, tid, off); }                // nth_element(n-1) still permutes
   else if (k > 0 && int64_t(k) * 64 <= int64_t(D)) { if (tid == 0) s2_heap_select(S.w, 0, k, D); __syncthreads(); }   // partial_sort regime
   else if (k > 0) introselect4<NW>(S, el, D, k - 1, tid, off);
-  chan_select_epilogue<uint32_t, kSelNT>(S, D, k, mask, cols, perm, wperm, wcpos);
+  if (!mask && k > 0 && k < D) chan_select_epilogue_bitmap(S, bitmap, D, k, cols, perm, wperm, wcpos);
+  else chan_select_epilogue<uint32_t, kSelNT>(S, D, k, mask, cols, perm, wperm, wcpos);
   if (tid == 0) VC2_STAMP(209);
 }
 __global__ __launch_bounds__(kSelNT) void k_chan_select4(const float* __restrict__ var_f32, int D, int k,
@@ -702,7 +767,9 @@ __global__ __launch_bounds__(kSel3NT) void k_chan_select3(const float* __restric
   chan_select_epilogue<uint32_t, kSel3NT>(S, D, k, mask, cols, perm, wperm, wcpos);
   if (tid == 0) VC2_STAMP(209);
 }
-__host__ inline size_t chan_select_lds(int D) { return sel2_bytes(D, 8) + 64; }
+__host__ inline size_t chan_select_lds(int D) {     // 64-bit words (the fallback), or 32-bit words + the epilogue's 128-word bitmap
+  return std::max(sel2_bytes(D, 8) + 64, (sel2_bytes(D, 4) + 15) / 16 * 16 + 512 + 64);
+}
 
 // torch.topk(sorted=True)'s ORDER of the k kept channels from `perm` (what nth_element / partial_sort left in
 // [0, k)): std::sort(q, q + k - 1) with the nth_element pivot staying last, or sort_heap in the partial_sort

@@ -100,7 +100,7 @@ def cascade_modelled(n: int) -> bool:
 class CompressPlan:
     """Pre-allocated buffers for repeated passes over one (F, N, D, dtype) shape.
 
-    ``enqueue`` launches the whole pass (9 kernels, no host round trip) on the current stream;
+    ``enqueue`` launches the whole pass (8 kernels, no host round trip) on the current stream;
     ``finish`` performs the path's single device->host sync (the reference's ``.tolist()``,
     vidcom2.py:72) and slices the outputs to the K kept tokens.
     """
