@@ -705,9 +705,11 @@ __device__ __forceinline__ void topk_smallest3_solo(const Sel2<uint32_t>& S, int
 constexpr int kX4State = 28;    // xch words [28, 31): lo, hi, depth after the round (for the waves that sleep through it)
 // ONE partition round.  SOLO = false: all awake waves of the workgroup together (three workgroup barriers); SOLO = true: the
 // range lies inside THIS wave's 256 positions -- no other wave is involved, no barrier (a wave's LDS accesses execute in order).
+// (sel4_partition: the partition itself -- returns the cut, the same value in every thread; the shadow S.w is written but NOT
+//  yet ordered against other waves: the caller's next barrier / wave_lds_order does that)
 template <int NW, bool SOLO, int E = 4>
-__device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&el)[E], int n, int& lo, int& hi, int nth,
-                                           int depth, uint32_t* mb, int mbtop, int p0, int lane, int wave, int off) {
+__device__ __forceinline__ int sel4_partition(const Sel2<uint32_t>& S, uint32_t (&el)[E], int n, int lo, int hi,
+                                              uint32_t* mb, int mbtop, int p0, int lane, int wave, int off) {
   using T = WordTr<uint32_t>;
   const int wspan_lo = wave * 64 * E - off, wspan_hi = wspan_lo + 64 * E;
   const int dumi = mbtop / 2 - 2;
@@ -792,7 +794,13 @@ __device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&e
     const uint32_t ct = lane < NW ? S.xch[kX3Cut + lane] : 0xFFFFFFFFu;
     cutv = wave_min_bcast_u32(ct);
   }
-  const int cut = cutv < uint32_t(hi) ? int(cutv) : hi;
+  return cutv < uint32_t(hi) ? int(cutv) : hi;
+}
+// one introselect round: the partition, the side that holds nth, and (not SOLO) the new state for the waves that sleep
+template <int NW, bool SOLO, int E = 4>
+__device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&el)[E], int n, int& lo, int& hi, int nth,
+                                           int depth, uint32_t* mb, int mbtop, int p0, int lane, int wave, int off) {
+  const int cut = sel4_partition<NW, SOLO, E>(S, el, n, lo, hi, mb, mbtop, p0, lane, wave, off);
   if (cut <= nth) lo = cut; else hi = cut;
   if constexpr (SOLO) {
     wave_lds_order();
@@ -1072,6 +1080,9 @@ __device__ __forceinline__ void introsort2(const Sel2<W>& S, const SortScratch2&
     int first = 0, last = n, depth = n > 1 ? 2 * (31 - __clz(n)) : 0;
     int lo = 0, hi = nparts > 1 ? nparts : 1;
     bool mine_ = true;
+    // (round 6, measured and NOT kept: the walk's partitions on registers -- sel4_partition<4, false, 8>, thread t owning positions
+    //  8t .. 8t + 7 -- are bit-identical and SLOWER here: cfg2's sweep-2 launch, which the riders set, 22.0 -> 24.5 us.  Eight
+    //  elements per thread double the per-element code of a round; the LDS form re-blocks the range over the threads every round.)
     while (hi - lo > 1) {
       if (last - first <= 16 || depth == 0) { mine_ = part == lo; break; }   // a leaf (or a heapsort segment): one owner
       int cut;
