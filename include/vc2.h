@@ -353,6 +353,12 @@ int vc2_selftest_counters(int32_t* out8_host, int reset);
  * `frame` (-1: off) -- how the test-suite checks that a hit in ANY workgroup of the launch reaches K_out[1] and the host
  * mirror's final word.  Process-wide; nothing is computed differently. */
 int vc2_selftest_force_guard(int frame);
+/* Host arithmetic only (no device call): the geometry of sweep 2's ORD form for this shape in the current mode -- the
+ * workgroups that add a frame's x^ in torch's own order (vidcom2.py:51-52; k_norm_colsum2<.., ORD>, OrdGeo).  out5 = int32[cap][5]
+ * rows {frame, piece, pieces of that frame, first 16-row block, blocks}, in launch order.  Returns the number of streaming
+ * workgroups (0: the shape has no ORD geometry -- the row-interleaved sweep with margins and replays runs), or an error (< 0).
+ * The test-suite checks that the pieces tile every frame exactly once and fit the resident workgroup slots. */
+int vc2_selftest_ord_pieces(int64_t F, int64_t N, int64_t D, int dtype, int32_t* out5_host, int64_t cap);
 
 #ifdef __cplusplus
 }

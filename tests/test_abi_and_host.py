@@ -158,3 +158,52 @@ def test_f16_fast_quotient_is_the_ieee_quotient(tmp_path):
     out = subprocess.run([str(exe), "61"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout
     assert out.stdout.count("mismatches 0") == 9, out.stdout
+
+
+@pytest.mark.parametrize("shape", [(128, 196, 3584, "bf16"), (128, 196, 3584, "f16"), (128, 196, 4096, "f16"), (32, 196, 3584, "bf16"),
+                                   (64, 324, 3584, "bf16"), (5, 169, 1024, "bf16"), (2, 512, 1024, "f16"), (6, 7, 1024, "bf16"),
+                                   (40, 33, 1024, "bf16"), (130, 48, 1024, "f16"), (448, 16, 1024, "bf16"), (449, 16, 1024, "bf16"),
+                                   (512, 196, 3584, "bf16"), (128, 196, 3584, "f32"), (8, 196, 200, "bf16")],
+                         ids=lambda s_: "x".join(map(str, s_)))
+def test_ord_geometry_tiles_every_frame(shape):
+    """Sweep 2's ORD form (round 6: unequal pieces, OrdGeo): host arithmetic only.  Where a shape has the geometry, the
+    workgroups' 16-row blocks tile every frame exactly once, in order, every workgroup of a frame has floor or ceil of its
+    share, the larger workgroups come first in the launch, and all of them (+ the 64 ORDER riders) fit the 512 resident
+    slots; where it has none (fp32, odd widths, more frames than slots) the entry point says 0."""
+    import numpy as np
+    F, N, D, dn = shape
+    L = _ffi.lib()
+    cap = 1024
+    out = np.zeros((cap, 5), dtype=np.int32)
+    n = L.vc2_selftest_ord_pieces(F, N, D, _ffi.DTYPE_CODE[{"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dn]],
+                                  out.ctypes.data_as(ctypes.c_void_p), cap)
+    assert n >= 0
+    if dn == "f32" or D not in (1024, 3584, 4096) or N > 512:
+        assert n == 0
+        return
+    if n == 0:
+        assert F > 448                                    # more frames than streaming slots: the row-interleaved sweep
+        return
+    assert F <= n <= 448
+    rows = out[:n]
+    nblk = N // 16
+    by_frame = {}
+    for f, j, sf, b0, nb in rows.tolist():
+        by_frame.setdefault(f, []).append((j, sf, b0, nb))
+    assert sorted(by_frame) == list(range(F))
+    sizes = []
+    for f, pcs in by_frame.items():
+        pcs.sort()
+        sf = pcs[0][1]
+        assert [p[0] for p in pcs] == list(range(sf)) and all(p[1] == sf for p in pcs) and 1 <= sf <= 8
+        pos = 0
+        for _, _, b0, nb in pcs:
+            assert b0 == pos and (nb >= 1 or nblk == 0)
+            pos += nb
+        assert pos == nblk
+        assert max(p[3] for p in pcs) - min(p[3] for p in pcs) <= 1
+        sizes.append(sf)
+    assert max(sizes) - min(sizes) <= 1
+    # launch order: the frames with FEWER (= larger) workgroups first
+    order = [r[2] for r in rows.tolist()]
+    assert order == sorted(order)

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "vc2_pass_counters": [_i64, _i64, _i64, _i32, _vp, _vp],
     "vc2_selftest_counters": [_vp, _i32],
     "vc2_selftest_force_guard": [_i32],
+    "vc2_selftest_ord_pieces": [_i64, _i64, _i64, _i32, _vp, _i64],
     "vc2_last_error": [],
     "vc2_version": [],
 }

@@ -1137,12 +1137,26 @@ __device__ float norm_torch_order(const float* sv, int C, int lane) {
   if constexpr (DT == VC2_F16) {                                // generic path: ONE sequential fp32 chain
     if (lane == 0) {
       int p = 0;
-      for (; p + 32 <= C; p += 32) {                            // 32 LDS reads in flight per round trip
-        float v[32];
+      // (round 6) 32 values per step as eight 16-byte LDS reads, the NEXT step's reads in flight under this step's 32 dependent
+      // fused multiply-adds: the chain is 1792-2048 FMAs whatever is done, but with 32 single reads and a wait per step the
+      // replay of one norm took 12.4 us (fix_riders.py), 942 of them per fp16 pass, and they set k_frame_centres' time
+      const float4* sv4 = reinterpret_cast<const float4*>(sv);        // (sv: 16-byte aligned row buffer)
+      float4 cur[8], nxt[8];
+      if (C >= 32) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = sv[p + u];
+        for (int u = 0; u < 8; ++u) cur[u] = sv4[u];
+      }
+      for (; p + 32 <= C; p += 32) {
+        const int pn = p + 64 <= C ? p + 32 : p;                   // (last step: re-read this one, unused)
 #pragma unroll
-        for (int u = 0; u < 32; ++u) s = __builtin_fmaf(v[u], v[u], s);   // (fp16 x fp16 is exact in fp32: the fused form rounds like s + v * v, at half the dependent latency)
+        for (int u = 0; u < 8; ++u) nxt[u] = sv4[(pn >> 2) + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                             // (fp16 x fp16 is exact in fp32: the fused form rounds like s + v * v, at half the dependent latency)
+          s = __builtin_fmaf(cur[u].x, cur[u].x, s); s = __builtin_fmaf(cur[u].y, cur[u].y, s);
+          s = __builtin_fmaf(cur[u].z, cur[u].z, s); s = __builtin_fmaf(cur[u].w, cur[u].w, s);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
       }
       for (; p + 8 <= C; p += 8) {
         float v[8];
@@ -2144,32 +2158,37 @@ __device__ __attribute__((noinline)) float ord_frame_sum(const float* __restrict
   for (int b = 0; b < 33; ++b) v[b] = bs[size_t(b <= nb ? b : nb) * C];       // (all in flight; entry nb: the leftover chain)
   if (ntail == 0) v[32] = 0.f;                                   // (read below only through index nb)
   unsigned long long dirty = 0ull;
-  for (int e = 0; e < nc; ++e)
-    if (corr[e].frame == f) { const int b = (corr[e].row - f * N) >> 4; dirty |= 1ull << (b < nb ? b : nb); }
+  for (int e0 = 0; e0 < nc; e0 += 8) {                            // (eight entries' loads in flight: one by one they cost a round
+    int fr[8], rw[8];                                             //  trip each -- fp16 has ~30 corrected norms per pass, and this scan
+#pragma unroll                                                    //  alone made its correction riders 17-33 us long, round 6)
+    for (int u = 0; u < 8; ++u) { const int e = e0 + u < nc ? e0 + u : nc - 1; fr[u] = corr[e].frame; rw[u] = corr[e].row; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u < nc && fr[u] == f) { const int b = (rw[u] - f * N) >> 4; dirty |= 1ull << (b < nb ? b : nb); }
+  }
   float tail = 0.f;                                              // v[nb] without a run-time register index
 #pragma unroll
   for (int b = 0; b < 33; ++b) if (b == nb) tail = ntail ? v[b] : 0.f;
-  if (dirty) {                                                   // (wave-uniform: f is)
+  // (wave-uniform: f is.)  One dirty block at a time; its new sum replaces v[b] through constant-index selects -- a 33-fold
+  // unrolled body with sixteen loads each is not unrolled by the compiler, and the run-time index that is left put v[] in scratch
+  for (unsigned long long mk = dirty; mk; mk &= mk - 1ull) {
+    const int b = int(__builtin_ctzll(mk));
+    const int64_t r0 = int64_t(f) * N + 16 * b;
+    float xv[16];                                                 // (sixteen loads in flight, then the adds in row order)
+    const int nel = b < nb ? 16 : ntail;
 #pragma unroll
-    for (int b = 0; b < 33; ++b) {
-      if (b <= nb && ((dirty >> b) & 1ull)) {
-        const int64_t r0 = int64_t(f) * N + 16 * b;
-        float xv[16];                                             // (sixteen loads in flight, then the adds in row order)
-        const int nel = b < nb ? 16 : ntail;
+    for (int u = 0; u < 16; ++u) xv[u] = xhat_at<DT>(x, r0 + (u < nel ? u : nel - 1), D, col, den);
+    if (b < nb) {
+      float a = xv[0];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) xv[u] = xhat_at<DT>(x, r0 + (u < nel ? u : nel - 1), D, col, den);
-        if (b < nb) {
-          float a = xv[0];
+      for (int u = 1; u < 16; ++u) a += xv[u];
 #pragma unroll
-          for (int u = 1; u < 16; ++u) a += xv[u];
-          v[b] = a;
-        } else {
-          float r = 0.f;
+      for (int bb = 0; bb < 33; ++bb) v[bb] = bb == b ? a : v[bb];
+    } else {
+      float r = 0.f;
 #pragma unroll
-          for (int u = 0; u < 16; ++u) if (u < ntail) r += xv[u];
-          tail = r;
-        }
-      }
+      for (int u = 0; u < 16; ++u) if (u < ntail) r += xv[u];
+      tail = r;
     }
   }
   float acc2 = 0.f, acc1 = 0.f;
@@ -5557,6 +5576,23 @@ int vc2_selftest_counters(int32_t* out8_host, int reset) {
     return fail(VC2_ERR_LAUNCH, "counter read-back failed");
   if (reset) { int z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(vc2::g_sel2_guard_hits), z, 32); }
   return VC2_OK;
+}
+
+int vc2_selftest_ord_pieces(int64_t F, int64_t N, int64_t D, int dtype, int32_t* out5_host, int64_t cap) {
+  Plan p;
+  int rc = make_plan(F, N, D, dtype, &p);
+  if (rc) return rc;
+  if (p.ord_m == 0) return 0;
+  const OrdGeo g{p.ord_S, p.ord_nA};
+  const int n = ord_total_wgs(g, int(F));
+  if (out5_host) {
+    for (int b = 0; b < n && b < cap; ++b) {
+      const OrdPiece o = ord_piece(g, b, int(N >> 4));
+      int32_t* r = out5_host + int64_t(b) * 5;
+      r[0] = o.f; r[1] = o.j; r[2] = o.Sf; r[3] = o.b0; r[4] = o.nb;
+    }
+  }
+  return n;
 }
 
 int vc2_profile_enable(int on) {
