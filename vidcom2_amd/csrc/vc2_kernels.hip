@@ -5419,7 +5419,13 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   // own sweep 1 (which left the variance array at "not written yet"), no per-kernel timing.  VC2_VARSEL=0: two launches
   static const int varsel_env = [] { const char* e = getenv("VC2_VARSEL"); return e ? atoi(e) : 1; }();
   static const int sel4_env2 = [] { const char* e = getenv("VC2_SEL4"); const char* e3 = getenv("VC2_SEL3"); return (e ? atoi(e) : 1) != 0 && !(e3 && atoi(e3) != 0); }();
-  if (varsel_env != 0 && sel4_env2 && p.ES == 2 && D <= 4096 && !(flags & VC2_FLAG_HAVE_STATS) && !g_prof && kc > 0 && kc < D) {
+  // (the selection workgroup WAITS inside the launch for the variance workgroups: they must be able to run beside it -- a
+  //  device with a handful of CUs keeps the two launches; a stream whose CU mask leaves one CU must set VC2_VARSEL=0: the bounded
+  //  wait would expire, and the pass would report status bit 2 instead of hanging)
+  static const int n_cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev);
+                                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+                                return n; }();
+  if (varsel_env != 0 && n_cus >= 16 && sel4_env2 && p.ES == 2 && D <= 4096 && !(flags & VC2_FLAG_HAVE_STATS) && !g_prof && kc > 0 && kc < D) {
     if ((rc = launch_stats_sweep(p, x, ws, PoolSrc{}, st, reinterpret_cast<uint32_t*>(var_f32)))) return rc;
     const int64_t n_each = int64_t(p.BF) * p.N, n_last = p.R - int64_t(p.NB - 1) * n_each;
     VarSelArgs va{p.NB, n_each, n_last, int(D), var_f32, wsp<int>(ws, p.o_ticket),
