@@ -14,9 +14,11 @@ import torch
 import vidcom2_amd as vc
 from vidcom2_amd import _ffi, synth
 
-WHAT = {200: "load the variances", 201: "pack words into LDS + barrier", 202: "(dispatch into the replay)",
+WHAT = {200: "load the variances (k_var_select: wait for the variance workgroups of the same launch)", 201: "pack words into LDS + barrier", 202: "(dispatch into the replay)",
         210: "cooperative round (16 waves; LDS)", 230: "one-wave round (LDS)", 240: "insertion sort (<= 3 elements)",
-        250: "one-wave round (registers)", 290: "(return from the replay)", 291: "perm store; kept flags; block scan",
+        250: "one-wave round (registers, <= 64 elements: introselect_tail64)", 310: "round on four waves, ballot form (sel3_rounds)",
+        330: "one-wave round, ballot form (sel3_rounds)", 410: "round on the awake waves of 16 (sel4_round: thread-contiguous registers)",
+        430: "round on ONE wave, no barrier (sel4_round<.., true>)", 290: "(return from the replay)", 291: "perm store; kept flags; block scan",
         292: "cols / mask stores; words for the ORDER riders", 299: "end",
         800: "load words + score partials; derive budgets", 801: "publish k / offsets; barrier", 802: "(dispatch into the replay)",
         803: "kept flags; scan; ordered compaction + index map", 809: "end"}
