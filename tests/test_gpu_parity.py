@@ -775,6 +775,44 @@ def test_a_guard_hit_of_any_frame_reaches_the_caller():
         L.vc2_selftest_counters(c, 1)
 
 
+@pytest.mark.parametrize("shape", [(16, 196, 3584, "bf16", "drift"), (9, 100, 4096, "f16", "iid"), (12, 49, 1024, "bf16", "cancel"),
+                                   (5, 324, 3584, "f16", "drift"), (3, 37, 200, "bf16", "iid"), (7, 64, 2048, "f16", "cancel")],
+                         ids=lambda s_: "x".join(map(str, s_)))
+def test_selection_engines_and_launch_forms_agree(shape):
+    """Round 6 changed HOW the channel selection runs, not what it computes: thread-contiguous register rounds
+    (k_chan_select4 / sel4_round; VC2_SEL4=0: the 16-wave LDS rounds of rounds 3-5; VC2_SEL3=1: the ballot form) and the
+    variance reduction + selection in ONE launch with polled variances (k_var_select; VC2_VARSEL=0: two launches).  Every
+    form must give the same channel order, scores, budgets and kept indices -- and the oracle's."""
+    import os
+    F, N, D, dn, dist = shape
+    x = make_input(F, N, D, dn, 17, dist)
+    O.set_mode("torch")
+    ref = O.compress_indices(x, N, 0.25)
+    xd = x.to(dev())
+    keys = ("VC2_SEL4", "VC2_VARSEL", "VC2_SEL3")
+    old = {k: os.environ.get(k) for k in keys}
+    outs = []
+    try:
+        for form in ({}, {"VC2_VARSEL": "0"}, {"VC2_SEL4": "0"}, {"VC2_SEL3": "1"}):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(form)
+            r = vc.compress(xd, N, 0.25, want_scores=True)
+            chan = vc.vidcom2.low_var_channel_order(xd)       # (the stage call: channel ORDER as torch.topk returns it)
+            torch.cuda.synchronize()
+            outs.append((form, r, chan))
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+            if old[k] is not None:
+                os.environ[k] = old[k]
+    for form, r, chan in outs:
+        assert r.ks.cpu().tolist() == ref["ks"].tolist(), form
+        assert torch.equal(r.global_idx.cpu(), ref["global_idx"]), form
+        assert nan_eq(r.v_score, ref["v"]) and nan_eq(r.f_score, ref["f"]), form
+        assert torch.equal(chan.cpu(), outs[0][2].cpu()), form
+
+
 @pytest.mark.gpu
 def test_a_late_guard_hit_is_reported_when_the_plan_is_dropped():
     """VERDICT r5 item 7 / ADVICE r5: a pass that returned on the early words of the host mirror and whose plan is never

@@ -4498,9 +4498,10 @@ int launch_chan_select(const float* var_f32, int64_t D, int64_t k, uint8_t* mask
   // Bit-identical (409 selection / full-pass tests green with it) and SLOWER: 26.1 against 20.9 us at D = 3584 -- its
   // rounds are ~70 instructions per 64-element row with VALU -> SGPR -> VALU dependencies that one wave per SIMD cannot hide
   // (4.2 / 3.0 / 2.3 / 2.4 us for the rounds the 16-wave LDS form does in 2.0 each: profiles/r06_b_sel3_register_rounds.csv)
-  static const int sel3_env = [] { const char* e = getenv("VC2_SEL3"); return e ? atoi(e) : 0; }();
+  const int sel3_env = [] { const char* e = getenv("VC2_SEL3"); return e ? atoi(e) : 0; }();     // (read per call: the test-suite
+  //                                                                                                   compares the forms in one process)
   // VC2_SEL4 (default 1): D <= 4096, sixteen waves, thread-contiguous registers (k_chan_select4); 0: the LDS rounds
-  static const int sel4_env = [] { const char* e = getenv("VC2_SEL4"); return e ? atoi(e) : 1; }();
+  const int sel4_env = [] { const char* e = getenv("VC2_SEL4"); return e ? atoi(e) : 1; }();
   if (sel4_env != 0 && sel3_env == 0 && D <= 4096 && !words64_expected) {
     { int rca = allow_big_lds(&k_chan_select4, smem, "k_chan_select4"); if (rca) return rca; }
     ProfScope ps_(KID_CHAN_SELECT, st);
@@ -5417,8 +5418,8 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
   int* const status = wsp<int>(ws, p.o_ticket) + kTkStatus;       // the pass's status word (-> K_out[1])
   // the variance reduction and the channel selection in ONE launch (k_var_select): 16-bit inputs, D <= 4096, this pass ran its
   // own sweep 1 (which left the variance array at "not written yet"), no per-kernel timing.  VC2_VARSEL=0: two launches
-  static const int varsel_env = [] { const char* e = getenv("VC2_VARSEL"); return e ? atoi(e) : 1; }();
-  static const int sel4_env2 = [] { const char* e = getenv("VC2_SEL4"); const char* e3 = getenv("VC2_SEL3"); return (e ? atoi(e) : 1) != 0 && !(e3 && atoi(e3) != 0); }();
+  const int varsel_env = [] { const char* e = getenv("VC2_VARSEL"); return e ? atoi(e) : 1; }();          // (read per pass, like VC2_S2_ORD)
+  const int sel4_env2 = [] { const char* e = getenv("VC2_SEL4"); const char* e3 = getenv("VC2_SEL3"); return (e ? atoi(e) : 1) != 0 && !(e3 && atoi(e3) != 0); }();
   // (the selection workgroup WAITS inside the launch for the variance workgroups: they must be able to run beside it -- a
   //  device with a handful of CUs keeps the two launches; a stream whose CU mask leaves one CU must set VC2_VARSEL=0: the bounded
   //  wait would expire, and the pass would report status bit 2 instead of hanging)
