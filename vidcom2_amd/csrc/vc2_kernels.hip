@@ -62,7 +62,8 @@ __device__ __forceinline__ void dbg_stamp(int tag) {      // (one lane) wall clo
 }
 #define VC2_STAMP(tag) dbg_stamp(tag)
 // per-workgroup begin / end times of the three sweeps (slot 0: k_chan_stats, 1: k_norm_colsum, 2: k_dist)
-namespace vc2 { __device__ unsigned long long g_dbg_wg[8][2][4096]; }     // (slots 4, 5: sweep 2's first row landed / row loops over, combine done)
+namespace vc2 { __device__ unsigned long long g_dbg_wg[8][2][4096]; }
+namespace vc2 { __device__ unsigned long long g_dbg_vc[6][4096]; }        // k_video_centre (scripts/dev/vc_waves.py): see there     // (slots 4, 5: sweep 2's first row landed / row loops over, combine done)
 #define VC2_WGTIME(slot, which) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_dbg_wg[slot][which][blockIdx.x] = wall_clock64(); } while (0)
 #else
 #define VC2_STAMP(tag) ((void)0)
@@ -2524,7 +2525,15 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
     }
     if (lane == 0) r.fc[int64_t(ff) * C + cc] = rnT<DT>(s / float(N));
   };
+#ifdef VC2_DEBUG_TIMING
+  int dbg_entries = 0;
+  if (lane == 0 && rid < 4096) { g_dbg_vc[3][rid] = 0ull; g_dbg_vc[4][rid] = (unsigned long long)cnt1 | ((unsigned long long)cnt2 << 32); g_dbg_vc[5][rid] = 0ull; }
+#endif
   for (int e = rid; e < cnt1 + cnt2; e += nrid) {
+#ifdef VC2_DEBUG_TIMING
+    ++dbg_entries;
+    if (lane == 0 && rid < 4096) { g_dbg_vc[3][rid] = (unsigned long long)dbg_entries; if (dbg_entries == 2) g_dbg_vc[5][rid] = wall_clock64(); }
+#endif
     if (e >= cnt2) {
       const uint32_t ent = r.list[e - cnt2];
       const int ff = int(ent / uint32_t(C));
@@ -2728,6 +2737,10 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
     }
   }
   if (bx == 0 && y == 0 && lane == 0) VC2_STAMP(605);
+#ifdef VC2_DEBUG_TIMING
+  { const unsigned long long dbg_nf = (unsigned long long)__popcll(__ballot(flag));
+    if (lane == 0 && bx * Y + y < 4096) { g_dbg_vc[0][bx * Y + y] = wall_clock64(); g_dbg_vc[1][bx * Y + y] = 0ull; g_dbg_vc[2][bx * Y + y] = dbg_nf | ((unsigned long long)nvc << 32); } }
+#endif
   if (vflag && y == 0 && c < C) vflag[c] = flag ? 1 : 0;         // (frame-sharded pass: which columns to replay)
   if (!replay) return;
   const uint64_t flagged = __ballot(flag);
@@ -2792,6 +2805,9 @@ __global__ __launch_bounds__(64) void k_video_centre(const double* __restrict__ 
   // stores, s_waitcnt vmcnt(0), a relaxed ticket, coherent loads in the last arriver -- was 0.8 us faster and WRONG:
   // the soak caught a stale group in 1 of 972 cases, 5 of 40 repeats of that case.  vmcnt(0) does not mean the
   // write-through has reached the point the other XCDs read from.)
+#ifdef VC2_DEBUG_TIMING
+  if (lane == 0 && bx * Y + y < 4096) g_dbg_vc[1][bx * Y + y] = wall_clock64();
+#endif
   __threadfence();                                   // release my groups ...
   int last = 0;
   if (lane == 0) last = atomicAdd(&vtick[bx], 1) == Y - 1;
@@ -5653,6 +5669,10 @@ int vc2_debug_wg(unsigned long long* out /*[8][2][4096]*/) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_wg), sizeof(unsigned long long) * 8 * 2 * 4096);
   return 0;
+}
+int vc2_debug_vc(unsigned long long* out) {      // [6][4096]: k_video_centre's per-wave stamps (scripts/dev/vc_waves.py)
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(vc2::g_dbg_vc), sizeof(unsigned long long) * 6 * 4096) == hipSuccess ? 0 : -1;
 }
 int vc2_debug_read_rounds(unsigned long long* t, int* v) {      // [2][128] each: the per-round stamps (VC2_ROUND)
   (void)hipDeviceSynchronize();
