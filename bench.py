@@ -662,23 +662,23 @@ def main():
         # ... and THREE: the throughput operating point of a serving loop -- one clip's 60 us chain of
         # single-workgroup kernels runs under the sweeps of the two others.  Three DIFFERENT clips (513 MiB: X no longer
         # fits the Infinity Cache, as with real clips); per-clip time, tokens/s and fraction of the 8 TB/s roofline
-        streams3 = streams + [torch.cuda.Stream()]
-        plans3 = plans + [vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base)]
-        xs3 = xs2 + [synth.make(F, N, D, dtype, seed=2, dist="drift").to(dev)]
-
-        def three():
-            for st, pl, xi in zip(streams3, plans3, xs3):
-                with torch.cuda.stream(st):
-                    pl.enqueue(xi)
-        for _ in range(args.warmup):
-            three()
-        e5 = min(time_steps(three, args.steps, False) for _ in range(2))
-        per_clip = e5 / args.steps / 3
-        out["three_clips_in_flight"] = {"us_per_clip": round(per_clip * 1e6, 2), "tokens_per_s": round(F * N / per_clip, 1),
-                                        "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / per_clip / 1e9, 1),
-                                        "pass_frac_of_8TBs": round(alg_bytes_pass(F, N, D, es, base) / per_clip / 1e9 / HBM_PEAK_GBS, 4),
-                                        "note": "three different clips, one stream and one plan each; inputs resident"}
-        del plans3, xs3
+        streams4 = streams + [torch.cuda.Stream(), torch.cuda.Stream()]
+        plans4 = plans + [vc.vidcom2.CompressPlan(F, N, D, dtype, dev, base) for _ in range(2)]
+        xs4 = xs2 + [synth.make(F, N, D, dtype, seed=sd, dist="drift").to(dev) for sd in (2, 3)]
+        for lanes, key in ((3, "three_clips_in_flight"), (4, "four_clips_in_flight")):
+            def many():
+                for st, pl, xi in zip(streams4[:lanes], plans4[:lanes], xs4[:lanes]):
+                    with torch.cuda.stream(st):
+                        pl.enqueue(xi)
+            for _ in range(args.warmup):
+                many()
+            e5 = min(time_steps(many, args.steps, False) for _ in range(2))
+            per_clip = e5 / args.steps / lanes
+            out[key] = {"us_per_clip": round(per_clip * 1e6, 2), "tokens_per_s": round(F * N / per_clip, 1),
+                        "pass_alg_GBs": round(alg_bytes_pass(F, N, D, es, base) / per_clip / 1e9, 1),
+                        "pass_frac_of_8TBs": round(alg_bytes_pass(F, N, D, es, base) / per_clip / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": f"{lanes} different clips, one stream and one plan each; inputs resident"}
+        del plans4, xs4
 
     # ---- side: the other dtypes of BASELINE.json's shapes, each behind its own parity gate (C++ oracle, same tensor):
     #      the target shape in fp32, and ONE clip of the batched-eval config (128 x 196 x 4096 fp16) --------------
