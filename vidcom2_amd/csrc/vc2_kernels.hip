@@ -2333,16 +2333,20 @@ __global__ __launch_bounds__(64 * kCentreFL) void k_frame_centres(const double* 
       const size_t rowb = row_lds_bytes(D, ES);
       const size_t stride = (std::max(rowb, size_t(C) * 4 + 16) + 15) / 16 * 16;
       if (wave >= fr.waves) return;
-      const int cnt = min(*fr.nfix_count, fr.max_entries);
       const int nslots = fy * int(gridDim.x) * fr.waves;
       const int first = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * fr.waves + wave;
+      // (the wave's first entry is asked for TOGETHER with the count: behind the early return it was a second round trip --
+      //  1.5 us of a replay that is ~8 us and sets this launch's time)
+      unsigned long long q_first = fr.fixq[first < fr.max_entries ? first : 0];
+      const int cnt = min(*fr.nfix_count, fr.max_entries);
+      asm volatile("" : "+v"(q_first));
       if (first >= cnt) return;
 #ifdef VC2_DEBUG_TIMING
       if (lane == 0 && first < 4096) g_dbg_wg[5][0][first] = wall_clock64();
 #endif
       unsigned char* buf0 = fix_rows + size_t(wave) * stride;
       if (lane < 4) reinterpret_cast<uint32_t*>(buf0 + rowb - 16)[lane] = 0u;
-      unsigned long long q = fr.fixq[first];
+      unsigned long long q = q_first;
       row_issue<DT, VEC>(x, int64_t(uint32_t(q)) - 1, D, fr.CV, buf0, lane);       // the first row's DMA overlaps the index loads
       NormFixer<DT, VEC, NPLB> fx;
       fx.init(cols, spos, C, int((rowb - 16) / ES), lane);
@@ -2504,7 +2508,13 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
   const int N = r.N;
   const int group = C >= 8 ? 32 : 4;
   const int simple_end = (C / group) * group;
+  // (round 6: the wave's first entry of either list, the number of corrected norms and its column index are asked for TOGETHER
+  //  with the two counts -- behind them they were a second and a third round trip of a chain of five)
+  uint32_t ent2_first = r.list2 ? r.list2[rid < r.cap2 ? rid : 0] : 0u;
+  uint32_t ent1_first = r.list[rid < r.cap ? rid : 0];
+  int nc_all = r.fix.corr_count ? *r.fix.corr_count : 0;
   const int cnt1 = min(*r.count, r.cap), cnt2 = r.list2 ? min(*r.count2, r.cap2) : 0;
+  asm volatile("" : "+v"(ent2_first), "+v"(ent1_first), "+v"(nc_all));
   auto replay_one = [&](int ff, int cc) {                          // (wave-uniform arguments)
     const int col = cols ? cols[cc] : cc, sp = spos ? spos[cc] : cc;
     float s;
@@ -2535,14 +2545,14 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
     if (lane == 0 && rid < 4096) { g_dbg_vc[3][rid] = (unsigned long long)dbg_entries; if (dbg_entries == 2) g_dbg_vc[5][rid] = wall_clock64(); }
 #endif
     if (e >= cnt2) {
-      const uint32_t ent = r.list[e - cnt2];
+      const uint32_t ent = (e == rid && cnt2 == 0) ? ent1_first : r.list[e - cnt2];
       const int ff = int(ent / uint32_t(C));
       if (r.fmark && cnt2 > 0 && r.fmark[ff] != 0) continue;      // (its correction entries answer for the whole frame)
       replay_one(ff, int(ent - uint32_t(ff) * uint32_t(C)));
       continue;
     }
     // ---- a correction entry: lane = column bx * 64 + lane of frame f
-    const uint32_t ent = r.list2[e];
+    const uint32_t ent = e == rid ? ent2_first : r.list2[e];
     const FrameFix& m = r.fix;
     const int nbx = (C + 63) / 64;
     const int f = int(ent / uint32_t(nbx)), bx = int(ent - uint32_t(f) * uint32_t(nbx));
@@ -2551,7 +2561,7 @@ __device__ __forceinline__ void frame_replay_wave(const FrameReplay& r, int rid,
     if (m.ord.on) {                                               // ORD: the block sums, the corrected rows' blocks redone
       if (active) {
         const int col = cols ? cols[c] : c;
-        r.fc[int64_t(f) * C + c] = rnT<DT>(ord_frame_sum<DT>(m.ord.bsum, f, c, C, N, *m.corr_count, m.corr, x, D, col, den) / float(N));
+        r.fc[int64_t(f) * C + c] = rnT<DT>(ord_frame_sum<DT>(m.ord.bsum, f, c, C, N, nc_all, m.corr, x, D, col, den) / float(N));
       }
       continue;
     }
