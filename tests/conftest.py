@@ -2,9 +2,26 @@ import json
 import os
 import sys
 
+# numpy asks for transparent huge pages on every allocation >= 4 MiB; with THP in "madvise" mode and defrag = madvise a first
+# touch then compacts memory in the page fault.  On a long-running box that made the fixture generator's temporaries cost
+# 16 s of system time per 25k-token input instead of 4 (the whole CPU suite 17 min instead of 8).  Off for the tests.
+os.environ.setdefault("NUMPY_MADVISE_HUGEPAGE", "0")
+try:                                     # ... and glibc keeps freed blocks up to 32 MiB in the heap instead of handing every
+    import ctypes                        #     multi-megabyte temporary back to the kernel (M_MMAP_THRESHOLD, M_TRIM_THRESHOLD,
+    _libc = ctypes.CDLL("libc.so.6")     #     M_TOP_PAD): the generator's per-frame temporaries stop page-faulting
+    _libc.mallopt(-3, 32 << 20), _libc.mallopt(-1, 1 << 30), _libc.mallopt(-2, 64 << 20)
+except Exception:                        # pragma: no cover - not glibc
+    pass
+
 import numpy as np
 import pytest
 import torch
+
+try:                                     # (numpy may have been imported before this file: the switch also exists at run time)
+    from numpy._core.multiarray import _set_madvise_hugepage
+    _set_madvise_hugepage(False)
+except Exception:                        # pragma: no cover - older numpy layouts
+    pass
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
