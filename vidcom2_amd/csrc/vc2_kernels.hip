@@ -699,6 +699,7 @@ struct VarSelArgs {
   int NB; int64_t n_each, n_last; int D; float* var_f32; int* counters; PartSrc ps; FoldTab ft;
   unsigned long long* fixq; int nfixq; unsigned long long* kstatus;
   int k; int* cols; int* perm; uint32_t* wperm; uint32_t* wcpos; int* status;
+  int warm;      // bytes of this kernel's own code the selection workgroup reads (as data) while it waits: see k_var_select
 };
 template <int DT>
 __global__ __launch_bounds__(kSelNT) void k_var_select(VarSelArgs a) {
@@ -708,6 +709,18 @@ __global__ __launch_bounds__(kSelNT) void k_var_select(VarSelArgs a) {
   if (blockIdx.x == 0) {                                           //   k_var_from_stats<DT, 16> has it (64-column workgroups: +1 us)
     if (a.counters && threadIdx.x < 16) a.counters[threadIdx.x] = 0;     // strict-mode queues + status word of this pass (the word
     __syncthreads();                                                     //   this workgroup's own replay may OR a bit into: zeroed here)
+    if (a.warm > 0) {
+      // ONE workgroup runs ~40 KB of branchy code once per pass, after three sweeps have pushed it out of the L2: every jump
+      // into a new piece (the first multi-wave round, the one-wave rounds, the tail, the epilogue) waits for an instruction
+      // fetch from memory.  The variances take ~4 us to arrive: meanwhile the threads read the kernel's code as DATA, one
+      // 64-byte line each, so that the fetches that follow hit the L2.  (a.warm < this function's code size: the range
+      // [pc, pc + warm) lies inside it.)
+      const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+      const int o0 = int(threadIdx.x) * 64, o1 = o0 + kSelNT * 64;  // (warm <= 128 KB: two lines per thread, both in flight)
+      const uint32_t w0 = o0 < a.warm ? *reinterpret_cast<const uint32_t*>(pc + o0) : 0u;
+      const uint32_t w1 = o1 < a.warm ? *reinterpret_cast<const uint32_t*>(pc + o1) : 0u;
+      asm volatile("" :: "v"(w0), "v"(w1));                        // (keeps the loads; nobody waits for them before the poll does)
+    }
     chan_select4_body<true>(smem, a.var_f32, a.D, a.k, nullptr, a.cols, a.perm, a.wperm, a.wcpos, a.status);
     return;
   }
@@ -5458,7 +5471,8 @@ int vc2_compress_ex2(const void* x, int64_t F, int64_t N, int64_t D, int dtype, 
     VarSelArgs va{p.NB, n_each, n_last, int(D), var_f32, wsp<int>(ws, p.o_ticket),
                   PartSrc{wsp<double>(ws, p.o_part_stats), x, p.R, p.BF * p.stat_splits, p.G, int(p.N), p.BF},
                   make_fold_tab(p.NB, n_each, n_last), wsp<unsigned long long>(ws, p.o_nfixlist), int(p.R + cdiv(p.F, 2)),
-                  reinterpret_cast<unsigned long long*>(K_out + 1), int(kc), cols, perm, wperm, wcpos, status};
+                  reinterpret_cast<unsigned long long*>(K_out + 1), int(kc), cols, perm, wperm, wcpos, status,
+                  [] { const char* e = getenv("VC2_CODE_WARM"); const int v = e ? atoi(e) : 88; return v < 0 ? 0 : (v > 88 ? 88 : v) * 1024; }()};
     const size_t smem = chan_select_lds(int(D));
     const unsigned nvb = unsigned(cdiv(D, 16));                    // workgroups of the variance reduction
     auto go = [&](auto kernel) -> int {
