@@ -816,8 +816,9 @@ __device__ __forceinline__ void sel4_round(const Sel2<uint32_t>& S, uint32_t (&e
 // range contains -- sits in the MIDDLE of a wave's 256 positions: with k = D / 2 = 7 x 256 it stood on a wave boundary and
 // no range ever fitted one wave.
 // Phase 1: rounds by all the waves whose positions meet the range (the others sleep through the barriers) while the range is
-// longer than 64 and spans more than one wave's 256 positions.  Phase 2: the ONE wave that holds the range goes on alone --
-// barrier-free rounds, then introselect_tail64 / the serial libstdc++ pieces -- while the others wait at the final barrier.
+// longer than 64 and does not fit 256 positions from a 16-byte boundary.  Phase 2: wave 0 re-blocks the range from the shadow
+// into its registers and goes on alone -- barrier-free rounds, then introselect_tail64 / the serial libstdc++ pieces -- while
+// the others wait at the final barrier.
 __host__ __device__ inline int sel4_offset(int n, int nth, int nw) {
   const int off = ((128 - (nth & 255) + 256) & 255) & ~3;
   return n + off <= 256 * nw ? off : 0;
@@ -836,8 +837,11 @@ __device__ __forceinline__ void introselect4(const Sel2<uint32_t>& S, uint32_t (
   const int wspan_lo = wave * 256 - off, wspan_hi = wspan_lo + 256;
   bool asleep = false;                                              // (wave-uniform) the range has left my wave's positions for good
   auto more = [&]() { return hi - lo > kSel2TailMax && depth > 0; };
-  auto one_wave = [&]() { return ((lo + off) >> 8) == ((hi - 1 + off) >> 8); };   // the range lies inside one wave's positions
-  for (int guard = 0; more() && !one_wave() && guard < 256; ++guard) {
+  // the range fits ONE wave's registers once it is re-blocked: 256 positions from the 16-byte boundary at or below lo.  (Until
+  // the last hours of round 6 the hand-over waited for the range to lie inside one wave's OWN 256 positions: the rounds at
+  // 252 and 141 elements of the target input straddled two waves and cost 1.2 / 1.5 us instead of 0.76.)
+  auto fits = [&]() { return hi - (lo & ~3) <= 256; };
+  for (int guard = 0; more() && !fits() && guard < 256; ++guard) {
     if (tid == 0) VC2_ROUND(S, 410, hi - lo);
     if (!asleep && !(wspan_hi > lo && wspan_lo < hi)) {             // the range only shrinks: from now on this wave keeps the
       asleep = true;                                                //   barriers company and reads what the others decide
@@ -854,31 +858,24 @@ __device__ __forceinline__ void introselect4(const Sel2<uint32_t>& S, uint32_t (
     sel4_round<NW, false>(S, el, n, lo, hi, nth, depth, mb, mbtop, p0, lane, wave, off);
     if (guard == 255 && tid == 0) guard_hit(6, S.status);
   }
-  // (every wave arrives here with the same lo / hi / depth; the shadow is current: the last round ended with a barrier)
-  const int owner = one_wave() ? ((lo + off) >> 8) : 0;
-#if defined(VC2_DEBUG_TIMING)                                      // (the stamp counter follows the work: thread 0 -> the owner's lane 0 -> thread 0)
-  if (tid == 0) S.xch[27] = uint32_t(S.dbg_i);
-  __syncthreads();
-  if (wave == owner && lane == 0) S.dbg_i = int(S.xch[27]);
-#endif
-  if (wave == owner) {
-    if (one_wave()) {
+  // (every wave arrives here with the same lo / hi / depth; the shadow S.w is current: the last round -- or the caller's pack --
+  //  ended with a barrier.)  Wave 0 goes on alone: it takes the 256 positions from `base` out of the shadow -- lane l: base + 4 l
+  //  ... + 3 -- and runs barrier-free rounds, then the register tail; the others wait at the final barrier.
+  if (wave == 0) {
+    if (more()) {
+      const int base = lo & ~3, q0 = base + 4 * lane;
+      const uint4 v = *reinterpret_cast<const uint4*>(S.w + (q0 < n ? q0 : 0));     // (the pad takes the last lanes' excess)
+      uint32_t r4[4] = {v.x, v.y, v.z, v.w};
       for (int guard = 0; more() && guard < 256; ++guard) {
         if (lane == 0) VC2_ROUND(S, 430, hi - lo);
         --depth;
-        sel4_round<NW, true>(S, el, n, lo, hi, nth, depth, mb, mbtop, p0, lane, wave, off);
+        sel4_round<NW, true>(S, r4, n, lo, hi, nth, depth, mb, mbtop, q0, lane, wave, off);
         if (guard == 255 && lane == 0) guard_hit(6, S.status);
       }
     }
     introselect3_finish<1>(S, lo, hi, nth, depth, n + kSel2Pad - 1, mb, mbtop, lane);
-#if defined(VC2_DEBUG_TIMING)
-    if (lane == 0) S.xch[27] = uint32_t(S.dbg_i);
-#endif
   }
   __syncthreads();
-#if defined(VC2_DEBUG_TIMING)
-  if (tid == 0) S.dbg_i = int(S.xch[27]);
-#endif
   if (tid == 0) VC2_ROUND(S, 290, 0);
 }
 
