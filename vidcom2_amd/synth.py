@@ -127,8 +127,9 @@ def to_torch(x32: np.ndarray, dtype):
     import torch
     if dtype == torch.float32:
         return torch.from_numpy(np.ascontiguousarray(x32))
-    if dtype == torch.bfloat16:
-        bits = f32_to_bf16_bits(x32)
+    if dtype == torch.bfloat16:                    # (cache-sized slices: the whole-array form allocates ten arrays of x32's size)
+        bits = np.empty(x32.shape, dtype=np.uint16)
+        _cast_into(bits, np.ascontiguousarray(x32, dtype=np.float32), "bf16")
         return torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16).reshape(x32.shape)
     if dtype == torch.float16:
         return torch.from_numpy(x32.astype(np.float16))
@@ -176,5 +177,6 @@ def sha256_tensor(t) -> str:
     """sha256 over the raw bytes of a contiguous CPU tensor (dtype-agnostic)."""
     import torch
     t = t.detach().cpu().contiguous()
-    raw = t.view(torch.uint8).numpy().tobytes() if t.numel() else b""
-    return hashlib.sha256(raw).hexdigest()
+    if not t.numel():
+        return hashlib.sha256(b"").hexdigest()
+    return hashlib.sha256(memoryview(t.reshape(-1).view(torch.uint8).numpy())).hexdigest()      # (no copy of the bytes)
